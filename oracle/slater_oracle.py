@@ -1,0 +1,500 @@
+"""CPU oracle for the Slater-determinant -> MPS sweep.  TEST INFRASTRUCTURE ONLY.
+
+A plain-NumPy restatement of the algorithm TeMFpy runs on this path
+(``/root/reference/src/temfpy``; citations are ``file:line`` in that tree).  It is
+the checker for the HIP path and the ``cpu_baseline`` of ``bench.py``; nothing in
+``temfpy_amd`` imports it and the product never falls back to it.
+
+Pinned: ``tests/test_oracle_golden.py`` compares every quantity below with the
+fixtures in ``tests/golden/*.npz``, which were produced by the reference's own
+NumPy core (``tests/golden/make_golden.py``).  Integer outputs (chi, subsets,
+sector slices) match exactly, floating-point outputs to <= 1e-12.
+Not pinned (TeNPy is not installed anywhere we can run): the row permutation of
+TeNPy's ``LegPipe`` (slater.py:1118).  The order used here is the one
+slater.py:943-952 documents.
+
+The structure is deliberately *not* the reference's class hierarchy: a cut is a
+plain ``Cut`` record, a site is a ``Site`` record holding dense charge blocks.
+"""
+from __future__ import annotations
+
+import heapq
+from dataclasses import dataclass, field
+
+import numpy as np
+
+DEFAULT_SVD_MIN = 1e-6  # schmidt_utils.py:14
+DEFAULT_DEG_TOL = 1e-12  # schmidt_utils.py:15
+
+
+# --------------------------------------------------------------------------------------
+# truncation policy (schmidt_utils.py:18-208)
+# --------------------------------------------------------------------------------------
+@dataclass
+class Trunc:
+    chi_max: int | None = None
+    svd_min: float = DEFAULT_SVD_MIN
+    degeneracy_tol: float = DEFAULT_DEG_TOL
+    sectors: object = None  # None | int | iterable | callable   (schmidt_utils.py:67-77)
+
+    def __post_init__(self):
+        if self.svd_min is None:
+            self.svd_min = DEFAULT_SVD_MIN
+        if self.degeneracy_tol is None:
+            self.degeneracy_tol = DEFAULT_DEG_TOL
+        assert self.chi_max is None or self.chi_max > 0
+        assert 0 < self.svd_min < 1
+        assert self.degeneracy_tol > 0
+        # schmidt_utils.py:96
+        self.max_logval = -np.log(self.svd_min) + self.degeneracy_tol
+
+    def is_sector(self, q) -> bool:
+        s = self.sectors
+        if s is None:
+            return True
+        if isinstance(s, (int, np.integer)):
+            return q == s
+        if callable(s):
+            return bool(s(q))
+        return q in s
+
+    def keep_generating(self, sums) -> bool:
+        """schmidt_utils.py:99-138 (chi_max+1 states, range <= max_logval)."""
+        if self.chi_max is not None and len(sums) > self.chi_max:
+            return False
+        if len(sums) and sums[-1] - sums[0] > self.max_logval:
+            return False
+        return True
+
+    def truncate(self, sums: np.ndarray) -> int:
+        """schmidt_utils.py:140-185: largest admissible prefix length."""
+        n = len(sums)
+        ok = np.ones(n, bool)
+        if self.chi_max is not None:
+            ok[self.chi_max :] = False
+        ok &= (sums - sums[0]) < -np.log(self.svd_min)
+        gap_ok = np.ones(n, bool)
+        gap_ok[:-1] = (sums[1:] - sums[:-1]) > self.degeneracy_tol
+        ok &= gap_ok
+        return int(np.nonzero(ok)[0][-1]) + 1
+
+
+def as_trunc(t) -> Trunc:
+    if isinstance(t, Trunc):
+        return t
+    if isinstance(t, dict):
+        return Trunc(**t)
+    raise TypeError(f"expected dict or Trunc, got {t!r}")
+
+
+# --------------------------------------------------------------------------------------
+# best-first subset enumeration (schmidt_utils.py:211-324)
+# --------------------------------------------------------------------------------------
+def lowest_sums(a, trunc: Trunc, filled_left=None, filled_right=None):
+    """Subsets of ``a`` by increasing sum; heap order (sum, seq) as the reference.
+
+    Subsets are kept as Python ints (bit i = orbital i) instead of bool arrays;
+    the float accumulation order of schmidt_utils.py:304-315 is kept.
+    """
+    a = np.asarray(a, float)
+    k = a.size
+
+    def charge(bits):  # schmidt_utils.py:257-266
+        n = bin(bits).count("1")
+        if filled_left is not None:
+            return filled_left + n
+        if filled_right is not None:
+            return filled_right + k - n
+        return n
+
+    if k == 0:  # schmidt_utils.py:268-271
+        m = int(trunc.is_sector(charge(0)))
+        return np.zeros(m), np.zeros((m, 0), bool), 1
+
+    min_sum = np.sum(a[a < 0])  # numpy pairwise order, as the reference
+    min_bits = 0
+    for i in range(k):
+        if a[i] < 0:
+            min_bits |= 1 << i
+    sums, sets = [], []
+    if trunc.is_sector(charge(min_bits)):
+        sums.append(min_sum)
+        sets.append(min_bits)
+
+    av = np.abs(a)
+    order = np.argsort(av)  # same (default quicksort/introsort) call as the reference
+    seq = 0
+    heap = [(min_sum + av[order[0]], seq, 0, min_bits ^ (1 << int(order[0])))]
+    n_checked = 1
+    while heap and trunc.keep_generating(sums):
+        n_checked += 1
+        s, _, i, bits = heapq.heappop(heap)
+        if trunc.is_sector(charge(bits)):
+            sums.append(s)
+            sets.append(bits)
+        if i < k - 1:
+            c1 = bits ^ (1 << int(order[i + 1]))
+            s = s + av[order[i + 1]]
+            seq += 1
+            heapq.heappush(heap, (s, seq, i + 1, c1))
+            c2 = c1 ^ (1 << int(order[i]))
+            s = s - av[order[i]]
+            seq += 1
+            heapq.heappush(heap, (s, seq, i + 1, c2))
+    sums = np.asarray(sums, float)
+    if len(sums) == 0:
+        return sums, np.zeros((0, k), bool), n_checked
+    cut = trunc.truncate(sums)
+    bits = np.array(sets[:cut], dtype=object)
+    out = np.zeros((cut, k), bool)
+    for r, b in enumerate(bits):
+        for i in range(k):
+            out[r, i] = (b >> i) & 1
+    return sums[:cut], out, n_checked
+
+
+# --------------------------------------------------------------------------------------
+# one entanglement cut
+# --------------------------------------------------------------------------------------
+@dataclass
+class Cut:
+    x: int
+    nL: int
+    nR: int
+    n_fermion: int
+    e: np.ndarray  # entangled eigenvalues of C_LL, descending
+    vL: np.ndarray | None  # columns [filled | entangled(desc) | empty]      slater.py:355-361
+    vR: np.ndarray | None  # columns [empty | entangled(desc) | filled]      slater.py:362-368
+    nfL: int | None  # number of filled columns in vL
+    nfR: int | None
+    sets: np.ndarray = None  # (chi, k) bool, entangled orbital occupied on the LEFT
+    lam_raw: np.ndarray = None
+    lam: np.ndarray = None
+    sectors: dict = field(default_factory=dict)  # N_left -> (start, stop)
+
+    @property
+    def k(self):
+        return self.e.size
+
+    def n_filled(self, side):  # slater.py:145-174
+        if side == "L":
+            return self.nfL if self.vL is not None else self.n_fermion - self.k - self.nfR
+        return self.nfR if self.vR is not None else self.n_fermion - self.k - self.nfL
+
+    def occupations(self, side):
+        """Full orbital occupations of every kept Schmidt vector (slater.py:430-470)."""
+        chi = len(self.sets)
+        if side == "L":
+            occ = np.zeros((chi, self.nL), bool)
+            occ[:, : self.nfL] = True
+            occ[:, self.nfL : self.nfL + self.k] = self.sets
+        else:
+            n0 = self.nR - self.nfR - self.k
+            occ = np.zeros((chi, self.nR), bool)
+            occ[:, n0 : n0 + self.k] = ~self.sets[:, ::-1]
+            occ[:, n0 + self.k :] = True
+        return occ
+
+
+def _split_block(c, side, cutoff):
+    """eigh of one diagonal block + empty/entangled/filled split (slater.py:324-375)."""
+    n = len(c)
+    if n == 0:
+        return np.zeros(0), np.zeros((0, 0), c.dtype), 0, 0
+    w, v = np.linalg.eigh(c)
+    x0, x1 = np.searchsorted(w, [cutoff, 1 - cutoff])
+    if side == "L":  # descending: filled, entangled, empty
+        return w[::-1][n - x1 : n - x0], v[:, ::-1], n - x1, x1 - x0
+    idx = np.arange(n)
+    idx[x0:x1] = idx[x0:x1][::-1]  # empty (asc), entangled (desc), filled (asc)
+    return w[idx][x0:x1], v[:, idx], n - x1, x1 - x0
+
+
+def _pair_singular_vectors(CLR, vL, vR, e, tol):
+    """utils.py:19-96: rotate degenerate groups so vL, vR hold singular vectors of C_LR."""
+    k = e.size
+    if k == 0:
+        return
+    brk = np.nonzero(np.abs(np.diff(e)) > tol)[0] + 1
+    starts = np.concatenate(([0], brk))
+    mult = np.diff(np.concatenate((starts, [k])))
+    for m in np.unique(mult):
+        ix = starts[mult == m, None] + np.arange(m)
+        blk = np.einsum("kdi,km,mdj->dij", vL[:, ix].conj(), CLR, vR[:, ix])
+        U, _, Vh = np.linalg.svd(blk)
+        vL[:, ix] = np.einsum("idk,dkj->idj", vL[:, ix], U)
+        vR[:, ix] = np.einsum("idk,djk->idj", vR[:, ix], Vh.conj())
+
+
+def cut_modes(C, x, trunc: Trunc, which="LR") -> Cut:
+    """slater.py:270-423 (``SchmidtModes.from_correlation_matrix``)."""
+    cutoff = trunc.svd_min**2  # slater.py:318
+    L = len(C)
+    vL = vR = nfL = nfR = None
+    if "L" in which:
+        eL, vL, nfL, kL = _split_block(C[:x, :x], "L", cutoff)
+    if "R" in which:
+        eR, vR, nfR, kR = _split_block(C[x:, x:], "R", cutoff)
+    if vL is None:
+        e = 1.0 - eR[::-1]  # slater.py:386
+    elif vR is None:
+        e = eL
+    else:
+        assert kL == kR  # slater.py:394
+        e = eL
+        a, b = nfL, nfL + kL
+        n0 = (L - x) - nfR - kR
+        vRE_rev = vR[:, n0 : n0 + kR][:, ::-1]  # a view: rotated in place like utils.py:65-94
+        _pair_singular_vectors(C[:x, x:], vL[:, a:b], vRE_rev, e, trunc.degeneracy_tol)
+        vR[:, n0 + 1 : n0 + kR : 2] *= -1  # slater.py:410
+    n_fermion = int(np.round(np.trace(C).real))  # slater.py:414
+    return Cut(x=x, nL=x, nR=L - x, n_fermion=n_fermion, e=e, vL=vL, vR=vR, nfL=nfL, nfR=nfR)
+
+
+def cut_vectors(C, x, trunc: Trunc, which="LR") -> Cut:
+    """slater.py:633-700 + 702-755: enumerate and order the kept Schmidt vectors."""
+    cut = cut_modes(C, x, trunc, which)
+    a = np.log((1 - cut.e) / cut.e) / 2  # slater.py:428,663
+    _, sets, cut.n_checked = lowest_sums(a, trunc, filled_left=cut.n_filled("L"), filled_right=cut.n_filled("R"))
+    if len(sets) == 0:
+        raise ValueError("No Schmidt vectors left after filtering by `trunc_par.sectors`!")  # slater.py:668
+    nl = cut.n_filled("L") + sets.sum(axis=1)
+    order = np.argsort(nl, kind="stable")  # slater.py:676
+    nl, sets = nl[order], sets[order]
+    q, start = np.unique(nl, return_index=True)
+    stop = np.concatenate((start[1:], [len(sets)]))
+    cut.sets = sets
+    cut.sectors = {int(qq): (int(s0), int(s1)) for qq, s0, s1 in zip(q, start, stop)}
+    cut.lam_raw = np.where(sets, cut.e, 1 - cut.e).prod(axis=1) ** 0.5  # slater.py:489
+    cut.lam = cut.lam_raw / np.linalg.norm(cut.lam_raw)  # utils.py:99-103
+    return cut
+
+
+# --------------------------------------------------------------------------------------
+# one site tensor
+# --------------------------------------------------------------------------------------
+@dataclass
+class Site:
+    mode: str  # "left" (A tensor) or "right" (B tensor)
+    det_always: complex
+    M: np.ndarray  # Schur complement on the sometimes-occupied orbitals
+    sets_bra: np.ndarray  # (2 chi_bra, s_b) bool
+    sets_ket: np.ndarray  # (chi_ket, s_k) bool
+    qtotal: int
+    blocks: dict  # ket charge q -> (row0, row1, col0, col1, dense block)
+    bra_p: np.ndarray = None  # physical occupation of every bra row
+    bra_alpha: np.ndarray = None  # Schmidt-vector index (on the bra cut) of every bra row
+
+
+def _classify_columns(occ, V, mode):
+    """slater.py:760-825: keep always+sometimes columns, with reordering signs."""
+    always = np.nonzero(occ.all(axis=0))[0]
+    some = np.nonzero(occ.any(axis=0) & ~occ.all(axis=0))[0]
+    k = len(always)
+    n_left_of = np.searchsorted(always, some)
+    if mode == "left":
+        idx = np.concatenate((always, some))
+        sign = np.concatenate((np.ones(k), (-1.0) ** (k - n_left_of)))
+    else:
+        idx = np.concatenate((some, always))
+        sign = np.concatenate(((-1.0) ** n_left_of, np.ones(k)))
+    return occ[:, idx], V[:, idx] * sign, k
+
+
+def batched_minors(M, rows_occ, cols_occ):
+    """slater.py:828-869: det of M[rows(a)][:, cols(b)] for all pairs (a, b)."""
+    n = int(rows_occ[0].sum())
+    assert np.all(rows_occ.sum(axis=1) == n) and np.all(cols_occ.sum(axis=1) == n)
+    ri = np.nonzero(rows_occ)[1].reshape(len(rows_occ), n)
+    ci = np.nonzero(cols_occ)[1].reshape(len(cols_occ), n)
+    sub = M[ri[:, None, :, None], ci[None, :, None, :]]
+    return np.linalg.det(sub)
+
+
+def site_tensor(bra: Cut, ket: Cut, mode: str) -> Site:
+    """slater.py:975-1104 and the sector loop of slater.py:1132-1141."""
+    side = "L" if mode == "left" else "R"
+    v_bra = bra.vL if side == "L" else bra.vR
+    v_ket = ket.vL if side == "L" else ket.vR
+    occ_bra, occ_ket = bra.occupations(side), ket.occupations(side)
+    chi_b, n_b = occ_bra.shape
+    assert n_b + 1 == occ_ket.shape[1], "bra must be one site shorter than ket"
+    dt = np.result_type(v_bra.dtype, v_ket.dtype)
+    big = np.zeros((n_b + 1, n_b + 1), dt)
+    z, o = np.zeros((chi_b, 1), bool), np.ones((chi_b, 1), bool)
+    if mode == "left":  # physical orbital appended last (slater.py:1030-1040)
+        big[:n_b, :n_b], big[n_b, n_b] = v_bra, 1
+        occ2 = np.block([[occ_bra, z], [occ_bra, o]])
+        key = occ2.sum(axis=1)
+    else:  # physical orbital first (slater.py:1041-1051)
+        big[1:, 1:], big[0, 0] = v_bra, 1
+        occ2 = np.block([[z, occ_bra], [o, occ_bra]])
+        key = -occ2.sum(axis=1)
+    perm = np.argsort(key, kind="stable")  # slater.py:1053-1058
+    occ2 = occ2[perm]
+    bra_p = (perm >= chi_b).astype(np.int64)
+    bra_alpha = perm % chi_b
+
+    sb, vb, kb = _classify_columns(occ2, big, mode)
+    sk, vk, kk = _classify_columns(occ_ket, v_ket, mode)
+    k = min(kb, kk)
+    O = vb.conj().T @ vk  # slater.py:1071
+    if k == 0:
+        det_always, M = 1.0, O
+    elif mode == "left":  # slater.py:1077-1082
+        det_always = np.linalg.det(O[:k, :k])
+        M = O[k:, k:] - O[k:, :k] @ np.linalg.inv(O[:k, :k]) @ O[:k, k:]
+        sb, sk = sb[:, k:], sk[:, k:]
+    else:  # slater.py:1083-1090
+        det_always = np.linalg.det(O[-k:, -k:])
+        M = O[:-k, :-k] - O[:-k, -k:] @ np.linalg.inv(O[-k:, -k:]) @ O[-k:, :-k]
+        sb, sk = sb[:, :-k], sk[:, :-k]
+    qtotal = 0 if mode == "left" else ket.n_fermion - bra.n_fermion  # slater.py:1092
+
+    pc_bra = sb.sum(axis=1)
+    blocks = {}
+    for q, (c0, c1) in ket.sectors.items():
+        n = int(sk[c0].sum())
+        rows = np.nonzero(pc_bra == n)[0]
+        if len(rows) == 0:
+            continue
+        r0, r1 = int(rows[0]), int(rows[-1]) + 1
+        blocks[q] = (r0, r1, c0, c1, det_always * batched_minors(M, sb[r0:r1], sk[c0:c1]))
+    return Site(mode, det_always, M, sb, sk, qtotal, blocks, bra_p, bra_alpha)
+
+
+# --------------------------------------------------------------------------------------
+# drivers (slater.py:1150-1353)
+# --------------------------------------------------------------------------------------
+def correlation_matrix(H, N=None):
+    """slater.py:1150-1180."""
+    w, v = np.linalg.eigh(H)
+    if N is None:
+        occ = w < 0
+        v, N = v[:, occ], int(occ.sum())
+    else:
+        v = v[:, :N]
+    C = v @ v.conj().T
+    if np.iscomplexobj(C) and np.allclose(C.imag, 0.0, rtol=0, atol=1e-14):
+        C = C.real
+    return C, N
+
+
+def spinful_correlation_matrix(C, ph=True):
+    """slater.py:1183-1213."""
+    n = len(C)
+    C2 = np.zeros((2 * n, 2 * n), C.dtype)
+    C2[::2, ::2] = C
+    C2[1::2, 1::2] = (np.eye(n) - C) if ph else C
+    return C2
+
+
+def c_to_mps(C, trunc, ortho_center=None, spinful=None):
+    """slater.py:1216-1353 without the TeNPy container: returns (cuts, sites)."""
+    trunc = as_trunc(trunc)
+    if spinful == "simple":
+        C = spinful_correlation_matrix(C, False)
+    elif spinful == "PH":
+        C = spinful_correlation_matrix(C, True)
+    elif spinful is not None:
+        raise ValueError(f"`spinful` must be 'simple', 'PH', or `None`, got {spinful!r}")
+    L = len(C)
+    oc = ortho_center or L // 2  # slater.py:1291
+    cuts, sites = [None] * (L + 1), [None] * L
+    cuts[oc] = cut_vectors(C, oc, trunc, "LR")
+    for i in range(oc, L):
+        cuts[i + 1] = cut_vectors(C, i + 1, trunc, "R")
+        sites[i] = site_tensor(cuts[i + 1], cuts[i], "right")
+    for i in reversed(range(oc)):
+        cuts[i] = cut_vectors(C, i, trunc, "L")
+        sites[i] = site_tensor(cuts[i], cuts[i + 1], "left")
+    return cuts, sites
+
+
+def entropies(cuts):
+    """S(b) = -sum lam^2 ln lam^2 with per-bond normalised lam."""
+    out = np.zeros(len(cuts))
+    for b, c in enumerate(cuts):
+        p = c.lam**2
+        p = p[p > 0]
+        out[b] = -(p * np.log(p)).sum()
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# dense helpers used by gauge-invariant parity tests
+# --------------------------------------------------------------------------------------
+def dense_site(site: Site, chi_bra, chi_ket):
+    """(2, chi_left, chi_right) dense tensor from the charge blocks.
+
+    left  mode (A): A[p, alpha(bra=left cut),  beta(ket=right cut)]
+    right mode (B): B[p, beta(ket=left cut), alpha(bra=right cut)]
+    """
+    dt = np.result_type(site.M.dtype, np.asarray(site.det_always).dtype)
+    T = np.zeros((2, chi_bra, chi_ket), dt)
+    for q, (r0, r1, c0, c1, blk) in site.blocks.items():
+        for r in range(r0, r1):
+            T[site.bra_p[r], site.bra_alpha[r], c0:c1] = blk[r - r0]
+    return T if site.mode == "left" else T.transpose(0, 2, 1)
+
+
+def dense_tensors(cuts, sites):
+    """List of dense (2, chi_left, chi_right) site tensors."""
+    out = []
+    for i, s in enumerate(sites):
+        bra, ket = (cuts[i], cuts[i + 1]) if s.mode == "left" else (cuts[i + 1], cuts[i])
+        out.append(dense_site(s, len(bra.lam), len(ket.lam)))
+    return out
+
+
+def mps_correlation(T, lam_c, oc):
+    """C_ij = <c_j^dag c_i> of the state  A..A diag(lam[oc]) B..B  by dense contraction.
+
+    The acceptance check of src/examples/slater.py:30-36 (TeNPy's
+    ``correlation_function("Cd","C").T``), for small L.  Jordan-Wigner:
+    c_i = (prod_{k<i} Z_k) s^-_i with Z = diag(1,-1), so for i < j
+    c_j^dag c_i = (Z s^-)_i Z_{i+1} .. Z_{j-1} s^+_j.
+    """
+    L = len(T)
+    T = [t.astype(complex) for t in T]
+    if oc > 0:
+        T[oc - 1] = T[oc - 1] * lam_c[None, None, :]
+    else:
+        T[0] = T[0] * lam_c[None, :, None]
+    sm = np.array([[0, 1], [0, 0]], complex)  # |0><1|
+    sp = sm.T
+    Z = np.diag([1.0, -1.0]).astype(complex)
+    I2 = np.eye(2, dtype=complex)
+
+    def expect(ops):
+        E = np.ones((1, 1), complex)
+        for i in range(L):
+            E = np.einsum("ab,pac,pq,qbd->cd", E, T[i].conj(), ops.get(i, I2), T[i])
+        return E[0, 0]
+
+    G = np.zeros((L, L), complex)
+    for i in range(L):
+        G[i, i] = expect({i: sp @ sm})
+        for j in range(i + 1, L):
+            ops = {k: Z for k in range(i + 1, j)}
+            ops[i] = Z @ sm
+            ops[j] = sp
+            G[i, j] = expect(ops)
+            G[j, i] = np.conj(G[i, j])
+    return G
+
+
+def mps_overlap(T1, lam1, T2, lam2, oc):
+    """<psi1|psi2> of two finite MPS given as dense tensors with the same centre."""
+    A = [t.astype(complex) for t in T1]
+    B = [t.astype(complex) for t in T2]
+    if oc > 0:
+        A[oc - 1] = A[oc - 1] * lam1[None, None, :]
+        B[oc - 1] = B[oc - 1] * lam2[None, None, :]
+    else:
+        A[0] = A[0] * lam1[None, :, None]
+        B[0] = B[0] * lam2[None, :, None]
+    E = np.ones((1, 1), complex)
+    for a, b in zip(A, B):
+        E = np.einsum("ab,pac,pbd->cd", E, a.conj(), b)
+    return E[0, 0]
