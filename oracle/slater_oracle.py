@@ -469,7 +469,9 @@ def mps_correlation(T, lam_c, oc):
     def expect(ops):
         E = np.ones((1, 1), complex)
         for i in range(L):
-            E = np.einsum("ab,pac,pq,qbd->cd", E, T[i].conj(), ops.get(i, I2), T[i])
+            X = np.tensordot(E, T[i].conj(), axes=(0, 1))  # [b, p, c]
+            Y = np.tensordot(ops.get(i, I2), T[i], axes=(1, 0))  # [p, b, d]
+            E = np.tensordot(X, Y, axes=([0, 1], [1, 0]))
         return E[0, 0]
 
     G = np.zeros((L, L), complex)
@@ -496,5 +498,6 @@ def mps_overlap(T1, lam1, T2, lam2, oc):
         B[0] = B[0] * lam2[None, :, None]
     E = np.ones((1, 1), complex)
     for a, b in zip(A, B):
-        E = np.einsum("ab,pac,pbd->cd", E, a.conj(), b)
+        X = np.tensordot(E, a.conj(), axes=(0, 1))  # [b, p, c]
+        E = np.tensordot(X, b, axes=([0, 1], [1, 0]))
     return E[0, 0]
