@@ -1,0 +1,215 @@
+/* temfpy_hip.h -- C ABI of the MI355X (gfx950) backend for TeMFpy's Slater -> MPS sweep.
+ *
+ * The reference (/root/reference/src/temfpy) is pure Python and has no FFI seam on
+ * this path; its only native calls are LAPACK through NumPy.  The seam is therefore
+ * introduced *below* the reference's per-cut / per-site numerics, and every entry
+ * point names the reference code it replaces (file:line in /root/reference/src/temfpy).
+ * INTEGRATION.md shows the ctypes binding a TeMFpy maintainer would add.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Device entry
+ *    points only enqueue work; they never synchronise and never allocate.
+ *  - dtype: TMF_F64 (real double) or TMF_C128 (interleaved re,im doubles).
+ *  - All matrices are column-major with an explicit leading dimension (in elements).
+ *  - Batched entry points take a device array of descriptors (one per problem) so that
+ *    problems of different sizes run in one launch.  Descriptor pointers are device
+ *    addresses stored as uint64_t.
+ *  - Return value: 0 on success, negative TMF_E_* otherwise; tmf_last_error() gives text.
+ */
+#ifndef TEMFPY_HIP_H
+#define TEMFPY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMF_F64 0
+#define TMF_C128 1
+
+#define TMF_OK 0
+#define TMF_E_ARG (-1)     /* bad argument (maps to ValueError / AssertionError) */
+#define TMF_E_HIP (-2)     /* HIP runtime error (maps to RuntimeError)           */
+#define TMF_E_LIMIT (-3)   /* problem exceeds a compiled-in limit                 */
+
+const char* tmf_last_error(void);
+int tmf_version(void);
+/* number of visible HIP devices, or a negative TMF_E_HIP */
+int tmf_device_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * Device: batched dense kernels (the arithmetic behind numpy.linalg.eigh / @ / det / inv
+ * at slater.py:347, :1071, :1079-1088, :869)
+ * ---------------------------------------------------------------------------------- */
+
+/* C = alpha * op(A) * B + beta * C ; op(A) = A (opA=0) or A^H (opA=1).
+ * fp64 MFMA (v_mfma_f64_16x16x4_f64).  Replaces the `@` products of slater.py:1071,
+ * :1080, :1087 and the GEMM-shaped part of the block diagonalisation (slater.py:347). */
+typedef struct {
+  uint64_t A, B, C;          /* device addresses                                    */
+  int32_t M, N, K;           /* C is M x N, contraction length K                    */
+  int32_t lda, ldb, ldc;
+} tmf_gemm_desc;             /* 48 bytes */
+
+int tmf_gemm_batched(int dtype, int opA, double alpha, double beta, const tmf_gemm_desc* d_desc,
+                     const int32_t* d_tiles /* [ntiles][4]: problem, tile_m, tile_n, 0 */, int ntiles,
+                     int tile_n /* 64 or 16 */, void* stream);
+
+/* Orthonormalise the columns [c0, c0+w) of A (n x *) in place against themselves
+ * (classical Gram-Schmidt, twice), one workgroup per problem, panel staged in LDS.
+ * Columns whose norm collapses (numerical rank deficiency) are replaced by a unit
+ * vector orthogonal to the panel so that the result is always orthonormal.
+ * Building block of the blocked QR that orthonormalises orbital slabs (the
+ * orthonormal eigenvector blocks of slater.py:347). */
+typedef struct {
+  uint64_t A;                /* device address of the first panel column            */
+  int32_t n, w, lda, pad;
+} tmf_panel_desc;            /* 24 bytes */
+
+int tmf_orth_panel_batched(int dtype, const tmf_panel_desc* d_desc, int nprob, int max_n, int max_w,
+                           void* stream);
+
+/* One-sided (Hestenes) Jacobi on a p x p matrix X held in LDS: X V = U diag(s).
+ * Outputs s (descending) and V (columns permuted accordingly); optionally U.
+ * p <= 64.  Used for the small SVD / Hermitian eigenproblems that replace
+ * numpy.linalg.eigh (slater.py:347) and numpy.linalg.svd (utils.py:90). */
+typedef struct {
+  uint64_t X;                /* in: p x p, ldx                                      */
+  uint64_t V;                /* out: p x p, ldv                                     */
+  uint64_t U;                /* out (may be 0): p x p normalised columns of X V      */
+  uint64_t s;                /* out: p doubles, descending                          */
+  uint64_t count;            /* out (may be 0): int32, #columns with s^2 >= thresh2 */
+  double thresh2;            /* > 0: columns of V (and U) with s^2 < thresh2 are zeroed */
+  int32_t p, ldx, ldv, ldu;
+} tmf_jacobi_desc;           /* 64 bytes */
+
+int tmf_jacobi_batched(int dtype, const tmf_jacobi_desc* d_desc, int nprob, int max_p, int32_t* d_sweeps,
+                       void* stream);
+
+/* Blocked LU with partial pivoting restricted to the leading k x k "always" block of
+ * W (mb x mk).  Returns det(W[:k,:k]) and leaves the Schur
+ * complement W[k:,k:] - W[k:,:k] W[:k,:k]^-1 W[:k,k:] in S.  Replaces det/inv and the two
+ * products of slater.py:1077-1090. */
+typedef struct {
+  uint64_t W;                /* in/out workspace mb x mk, ldw                       */
+  uint64_t S;                /* out: (mb-k) x (mk-k), lds                           */
+  uint64_t det;              /* out: one element (re[, im])                          */
+  int32_t mb, mk, k, ldw, lds, pad;
+} tmf_schur_desc;            /* 48 bytes */
+
+/* max_mb = largest mb of the batch (sizes the LDS panel). S may be 0: the Schur complement is then
+ * read in place at W + k + k*ldw. */
+int tmf_lu_schur_batched(int dtype, const tmf_schur_desc* d_desc, int nprob, int max_mb, void* stream);
+
+/* The hot kernel: batched gathered determinants (slater.py:828-869, `_tensor_block`,
+ * 90 % of the reference's wall time).  For every tile, for every pair (a, b) of a bra
+ * row and a ket row of one charge sector, out[a, b] = scale * det(S[rows(a)][:, cols(b)]).
+ * S (<= 4096 elements) is staged in LDS once per workgroup. */
+typedef struct {
+  uint64_t S;                /* sb x sk, lds                                        */
+  uint64_t scale;            /* device address of det_always (2 doubles re,im)      */
+  uint64_t bra_idx;          /* uint8 [nsb][n]: row positions, ascending            */
+  uint64_t ket_idx;          /* uint8 [nsk][n]: column positions, ascending         */
+  uint64_t out;              /* nsb x nsk row-major block                           */
+  int32_t sb, sk, lds, n;    /* n = order of every determinant of the sector        */
+  int32_t nsb, nsk, a0, a1;  /* this tile handles bra rows [a0, a1), all ket rows   */
+} tmf_det_desc;              /* 72 bytes */
+
+/* n_class in {8, 16, 32, 64}: every tile of the launch has n <= n_class (8/16/32 lanes own one
+ * determinant; 64 = LDS-resident fallback).  lds_bytes = dynamic LDS per workgroup:
+ * align16(sb*sk*elem) + align16(nsk*n) + align16((a1-a0)*n) [+ n*n*elem for class 64], max over tiles. */
+int tmf_det_gather_batched(int dtype, int n_class, const tmf_det_desc* d_desc, int ntiles, int lds_bytes,
+                           void* stream);
+
+/* ---- small device utilities ------------------------------------------------------ */
+/* out (n x n col-major) = transpose of the row-major host layout already on device   */
+int tmf_transpose(int dtype, const void* d_in, void* d_out, int n, void* stream);
+/* fill with a counter-based standard-normal stream (deterministic in seed, index)    */
+int tmf_fill_normal(int dtype, void* d_out, int64_t count, uint64_t seed, void* stream);
+/* column norms / scaling, W assembly: generic "gather with signs" kernel              */
+typedef struct {
+  uint64_t src;              /* col-major, lds_                                     */
+  uint64_t dst;              /* col-major, ldd                                      */
+  uint64_t row_sel;          /* int32[rows]: source row, or -1 -> take from `phys`  */
+  uint64_t col_sel;          /* int32[cols]: source col                              */
+  uint64_t row_sign;         /* int8[rows]                                          */
+  uint64_t col_sign;         /* int8[cols]                                          */
+  uint64_t phys;             /* col-major vector base for row_sel == -1: element (col_sel[c]) * ldp */
+  int32_t rows, cols, lds_, ldd, ldp, pad;
+} tmf_gather_desc;           /* 80 bytes */
+int tmf_gather_signed_batched(int dtype, const tmf_gather_desc* d_desc, int nprob, void* stream);
+
+/* normalise each column of A (n x c) by its 2-norm; optionally reverse column order
+ * and flip the sign of odd columns (slater.py:410) while copying into dst            */
+typedef struct {
+  uint64_t src, dst;
+  int32_t n, c, lds_, ldd, reverse, flip_odd;
+} tmf_colnorm_desc;          /* 40 bytes */
+int tmf_normalise_columns_batched(int dtype, const tmf_colnorm_desc* d_desc, int nprob, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Host: integer / combinatorial part of the sweep (no GPU needed)
+ * ---------------------------------------------------------------------------------- */
+
+/* Best-first enumeration of the most probable occupation patterns
+ * (schmidt_utils.py:211-324 incl. StoppingCondition.__call__/truncate :99-185), followed
+ * by the stable sort by left charge and the Schmidt values of slater.py:672-689.
+ *   e[k]         entangled eigenvalues of C_LL, descending (k <= 128)
+ *   sectors      NULL (all) or an array of `n_sectors` allowed left charges
+ * Outputs (caller-allocated, capacity chi_cap rows; chi_cap >= chi_max + 1 when chi_max > 0):
+ *   sets[chi][2]   128-bit occupation masks (bit i: orbital i occupied on the left)
+ *   lam_raw[chi]   unnormalised Schmidt values, q_left[chi] left charges (ascending)
+ *   *chi           number of kept vectors, *n_checked  subsets popped (for logging)
+ * chi_max <= 0 means "no limit".  Returns TMF_E_LIMIT if chi_cap is too small. */
+int tmf_cut_vectors(const double* e, int k, int filled_left, int64_t chi_max, double svd_min,
+                    double degeneracy_tol, const int64_t* sectors, int n_sectors, int64_t chi_cap,
+                    uint64_t* sets, double* lam_raw, int32_t* q_left, int64_t* chi, int64_t* n_checked);
+
+/* Everything integer that slater.py:1023-1067 (+ _select_orbitals :760-825, the sector
+ * loop :1132-1141 and the index lists of _tensor_block :857-864) derives from the
+ * occupation patterns of the two cuts next to a site.
+ *
+ * Orbital numbering of a cut side (matches the device layout V = [entangled | filled]):
+ * columns 0..k-1 are the entangled orbitals in that side's order, k..k+nf-1 the filled ones.
+ * For the left side entangled column j is occupied iff bit j of the mask is set; for the
+ * right side entangled column j is occupied iff bit (k-1-j) is NOT set (slater.py:465).
+ *
+ * Outputs (caller-allocated with the capacities given in `cap`):
+ *   row_sel/row_sign [mb], col_sel/col_sign [mk]  rows/cols of W = [always block | S order];
+ *        row_sel == -1 marks the physical orbital
+ *   k_always, sb, sk
+ *   bra_p/bra_alpha [2 chi_b]  physical occupation and bra Schmidt index of every merged row
+ *   sectors: for each ket charge sector with matching bra rows: q, r0, r1, c0, c1, n, and the
+ *        offsets of its uint8 index lists in idx_pool and of its block in the site output.
+ */
+typedef struct {
+  int32_t mode;              /* 0 = left (A tensor), 1 = right (B tensor)           */
+  int32_t k_b, nf_b, chi_b;  /* bra cut side: entangled, filled, kept vectors        */
+  int32_t k_k, nf_k, chi_k;  /* ket cut side                                        */
+  int32_t pad;
+} tmf_site_in;
+
+typedef struct {
+  int32_t mb, mk, k_always, sb, sk, n_sectors;
+  int64_t idx_bytes;         /* bytes used in idx_pool                              */
+  int64_t out_elems;         /* elements of the site's concatenated blocks          */
+} tmf_site_out;
+
+typedef struct {
+  int32_t q, r0, r1, c0, c1, n;
+  int64_t bra_off, ket_off;  /* byte offsets into idx_pool                          */
+  int64_t out_off;           /* element offset into the site output                 */
+} tmf_sector;
+
+int tmf_site_prepare(const tmf_site_in* in, const uint64_t* sets_b, const int32_t* q_b,
+                     const uint64_t* sets_k, const int32_t* q_k, int32_t* row_sel, int8_t* row_sign,
+                     int32_t* col_sel, int8_t* col_sign, int32_t* bra_p, int32_t* bra_alpha,
+                     tmf_sector* sectors, int32_t sector_cap, uint8_t* idx_pool, int64_t idx_cap,
+                     tmf_site_out* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,155 @@
+"""ctypes binding of ``libtemfpy_hip.so`` (C ABI declared in ``include/temfpy_hip.h``).
+
+There is no CPU fallback: if the library is missing or a symbol is absent, ``load()``
+raises, and every entry point raises on a non-zero status with the library's message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_LIB = None
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtemfpy_hip.so")
+
+TMF_F64, TMF_C128 = 0, 1
+
+# numpy mirrors of the descriptor structs (field order/offsets as in the header)
+gemm_desc = np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"),
+                      ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4")])
+panel_desc = np.dtype([("A", "<u8"), ("n", "<i4"), ("w", "<i4"), ("lda", "<i4"), ("pad", "<i4")])
+jacobi_desc = np.dtype([("X", "<u8"), ("V", "<u8"), ("U", "<u8"), ("s", "<u8"), ("count", "<u8"),
+                        ("thresh2", "<f8"), ("p", "<i4"), ("ldx", "<i4"), ("ldv", "<i4"), ("ldu", "<i4")])
+schur_desc = np.dtype([("W", "<u8"), ("S", "<u8"), ("det", "<u8"), ("mb", "<i4"), ("mk", "<i4"), ("k", "<i4"),
+                       ("ldw", "<i4"), ("lds", "<i4"), ("pad", "<i4")])
+det_desc = np.dtype([("S", "<u8"), ("scale", "<u8"), ("bra_idx", "<u8"), ("ket_idx", "<u8"), ("out", "<u8"),
+                     ("sb", "<i4"), ("sk", "<i4"), ("lds", "<i4"), ("n", "<i4"), ("nsb", "<i4"), ("nsk", "<i4"),
+                     ("a0", "<i4"), ("a1", "<i4")])
+gather_desc = np.dtype([("src", "<u8"), ("dst", "<u8"), ("row_sel", "<u8"), ("col_sel", "<u8"),
+                        ("row_sign", "<u8"), ("col_sign", "<u8"), ("phys", "<u8"), ("rows", "<i4"),
+                        ("cols", "<i4"), ("lds_", "<i4"), ("ldd", "<i4"), ("ldp", "<i4"), ("pad", "<i4")])
+colnorm_desc = np.dtype([("src", "<u8"), ("dst", "<u8"), ("n", "<i4"), ("c", "<i4"), ("lds_", "<i4"),
+                         ("ldd", "<i4"), ("reverse", "<i4"), ("flip_odd", "<i4")])
+site_in = np.dtype([("mode", "<i4"), ("k_b", "<i4"), ("nf_b", "<i4"), ("chi_b", "<i4"), ("k_k", "<i4"),
+                    ("nf_k", "<i4"), ("chi_k", "<i4"), ("pad", "<i4")])
+site_out = np.dtype([("mb", "<i4"), ("mk", "<i4"), ("k_always", "<i4"), ("sb", "<i4"), ("sk", "<i4"),
+                     ("n_sectors", "<i4"), ("idx_bytes", "<i8"), ("out_elems", "<i8")])
+sector = np.dtype([("q", "<i4"), ("r0", "<i4"), ("r1", "<i4"), ("c0", "<i4"), ("c1", "<i4"), ("n", "<i4"),
+                   ("bra_off", "<i8"), ("ket_off", "<i8"), ("out_off", "<i8")])
+
+assert gemm_desc.itemsize == 48 and panel_desc.itemsize == 24 and jacobi_desc.itemsize == 64
+assert schur_desc.itemsize == 48 and det_desc.itemsize == 72 and gather_desc.itemsize == 80
+assert colnorm_desc.itemsize == 40 and sector.itemsize == 48 and site_out.itemsize == 40
+
+SYMBOLS = [
+    "tmf_last_error", "tmf_version", "tmf_device_count", "tmf_gemm_batched", "tmf_orth_panel_batched",
+    "tmf_jacobi_batched", "tmf_lu_schur_batched", "tmf_det_gather_batched", "tmf_transpose", "tmf_fill_normal",
+    "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_cut_vectors", "tmf_site_prepare",
+]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and check that every symbol of the header is exported."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_PATH):
+        raise NativeError(
+            f"{_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)")
+    lib = C.CDLL(_PATH)
+    for s in SYMBOLS:
+        if not hasattr(lib, s):
+            raise NativeError(f"{_PATH} does not export {s}")
+    lib.tmf_last_error.restype = C.c_char_p
+    vp, i32, i64, f64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_uint64
+    lib.tmf_gemm_batched.argtypes = [i32, i32, f64, f64, vp, vp, i32, i32, vp]
+    lib.tmf_orth_panel_batched.argtypes = [i32, vp, i32, i32, i32, vp]
+    lib.tmf_jacobi_batched.argtypes = [i32, vp, i32, i32, vp, vp]
+    lib.tmf_lu_schur_batched.argtypes = [i32, vp, i32, i32, vp]
+    lib.tmf_det_gather_batched.argtypes = [i32, i32, vp, i32, i32, vp]
+    lib.tmf_transpose.argtypes = [i32, vp, vp, i32, vp]
+    lib.tmf_fill_normal.argtypes = [i32, vp, i64, u64, vp]
+    lib.tmf_gather_signed_batched.argtypes = [i32, vp, i32, vp]
+    lib.tmf_normalise_columns_batched.argtypes = [i32, vp, i32, vp]
+    lib.tmf_cut_vectors.argtypes = [vp, i32, i32, i64, f64, f64, vp, i32, i64, vp, vp, vp, vp, vp]
+    lib.tmf_site_prepare.argtypes = [vp] * 13 + [i32, vp, i64, vp]
+    lib.tmf_site_prepare.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i64, vp]
+    _LIB = lib
+    return lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = load().tmf_last_error().decode()
+        if status == -1:
+            raise ValueError(f"{what}: {msg}")
+        if status == -3:
+            raise NotImplementedError(f"{what}: {msg}")
+        raise NativeError(f"{what}: {msg} (status {status})")
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---- host entry points (no GPU) ---------------------------------------------------------------
+def cut_vectors(e, filled_left, chi_max, svd_min, degeneracy_tol, sectors=None):
+    """schmidt_utils.lowest_sums + the ordering of slater.py:672-689.  Returns
+    (sets uint64[chi,2], lam_raw[chi], q_left[chi], n_checked)."""
+    lib = load()
+    e = np.ascontiguousarray(e, np.float64)
+    k = e.size
+    cm = int(chi_max) if chi_max else 0
+    sec = None if sectors is None else np.ascontiguousarray(sectors, np.int64)
+    cap = cm + 1 if cm > 0 else 1024
+    while True:
+        sets = np.zeros((cap, 2), np.uint64)
+        lam = np.zeros(cap)
+        q = np.zeros(cap, np.int32)
+        chi, nchk = C.c_int64(0), C.c_int64(0)
+        st = lib.tmf_cut_vectors(_p(e), k, int(filled_left), cm, float(svd_min), float(degeneracy_tol),
+                                 None if sec is None else _p(sec), 0 if sec is None else sec.size, cap, _p(sets),
+                                 _p(lam), _p(q), C.byref(chi), C.byref(nchk))
+        if st == -3 and chi.value > cap:
+            cap = int(chi.value)
+            continue
+        check(st, "tmf_cut_vectors")
+        n = chi.value
+        return sets[:n], lam[:n], q[:n], nchk.value
+
+
+def site_prepare(mode, k_b, nf_b, sets_b, q_b, k_k, nf_k, sets_k, q_k):
+    """Integer part of MPSTensorData.from_schmidt_vectors / to_npc_array (slater.py:1023-1141)."""
+    lib = load()
+    chi_b, chi_k = len(sets_b), len(sets_k)
+    sin = np.zeros(1, site_in)
+    sin["mode"], sin["k_b"], sin["nf_b"], sin["chi_b"] = mode, k_b, nf_b, chi_b
+    sin["k_k"], sin["nf_k"], sin["chi_k"] = k_k, nf_k, chi_k
+    mb_cap, mk_cap = k_b + nf_b + 1, k_k + nf_k
+    row_sel, row_sign = np.zeros(mb_cap, np.int32), np.zeros(mb_cap, np.int8)
+    col_sel, col_sign = np.zeros(max(mk_cap, 1), np.int32), np.zeros(max(mk_cap, 1), np.int8)
+    bra_p, bra_alpha = np.zeros(2 * chi_b, np.int32), np.zeros(2 * chi_b, np.int32)
+    sec_cap = chi_k + 1
+    secs = np.zeros(sec_cap, sector)
+    idx_cap = (2 * chi_b + chi_k) * (max(k_b + 1, k_k) + 1) + 16
+    pool = np.zeros(idx_cap, np.uint8)
+    sout = np.zeros(1, site_out)
+    sets_b = np.ascontiguousarray(sets_b, np.uint64)
+    sets_k = np.ascontiguousarray(sets_k, np.uint64)
+    q_b = np.ascontiguousarray(q_b, np.int32)
+    q_k = np.ascontiguousarray(q_k, np.int32)
+    st = lib.tmf_site_prepare(_p(sin), _p(sets_b), _p(q_b), _p(sets_k), _p(q_k), _p(row_sel), _p(row_sign),
+                              _p(col_sel), _p(col_sign), _p(bra_p), _p(bra_alpha), _p(secs), sec_cap, _p(pool),
+                              idx_cap, _p(sout))
+    check(st, "tmf_site_prepare")
+    o = sout[0]
+    return dict(mb=int(o["mb"]), mk=int(o["mk"]), k=int(o["k_always"]), sb=int(o["sb"]), sk=int(o["sk"]),
+                row_sel=row_sel[: o["mb"]], row_sign=row_sign[: o["mb"]], col_sel=col_sel[: o["mk"]],
+                col_sign=col_sign[: o["mk"]], bra_p=bra_p, bra_alpha=bra_alpha, sectors=secs[: o["n_sectors"]].copy(),
+                idx_pool=pool[: o["idx_bytes"]].copy(), out_elems=int(o["out_elems"]))

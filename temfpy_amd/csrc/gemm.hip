@@ -1,0 +1,189 @@
+// Batched variable-size GEMM on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+//   C[p] = alpha * op(A[p]) * B[p] + beta * C[p]       op = identity | conjugate-transpose
+//
+// One 256-thread workgroup (4 waves) owns one 64 x TN tile of one problem; a host-built
+// tile table maps blockIdx -> (problem, tile_m, tile_n) so that thousands of problems of
+// different shapes (one per entanglement cut / site) fill the 256 CUs in one launch.
+//
+// Replaces the dense products of the reference: slater.py:1071 (O = v_bra^H v_ket),
+// :1080/:1087 and the GEMM-shaped share of the block diagonalisation (slater.py:347).
+//
+// MFMA operand maps (cdna_hip_programming.md section 3, "f64 MFMA does NOT use these maps"):
+//   a-operand lane l : X[i = l & 15][k = l >> 4]        b-operand : Y[k = l >> 4][j = l & 15]
+//   result reg r     : D[row = (l >> 4) + 4 r][col = l & 15]
+// We feed a := B-values (i -> n) and b := A-values (j -> m), so that D[n][m] puts
+// consecutive lanes on consecutive m: column-major C is then written in 128/256-byte runs.
+#include "common.hpp"
+
+namespace tmf {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int TM = 64;
+constexpr int KT = 16;
+constexpr int LDT = KT + 1;  // padded k-stride of the LDS tiles (doubles)
+
+template <typename T, int OPA, int TN>
+__global__ __launch_bounds__(256) void gemm_kernel(const tmf_gemm_desc* __restrict__ desc,
+                                                   const int32_t* __restrict__ tiles, double alpha, double beta) {
+  constexpr int CP = sc<T>::cplx;
+  constexpr int NP = CP ? 2 : 1;               // planes (re, im)
+  constexpr int WM = (TN == 64) ? 32 : 16;     // rows of C per wave
+  constexpr int MI = WM / 16;
+  constexpr int NI = (TN == 64) ? 2 : 1;
+
+  __shared__ double As[NP][TM][LDT];
+  __shared__ double Bs[NP][TN][LDT];
+
+  const int4 tl = reinterpret_cast<const int4*>(tiles)[blockIdx.x];
+  const tmf_gemm_desc d = desc[tl.x];
+  const int m0 = tl.y * TM, n0 = tl.z * TN;
+  const T* __restrict__ A = reinterpret_cast<const T*>(d.A);
+  const T* __restrict__ B = reinterpret_cast<const T*>(d.B);
+  T* __restrict__ C = reinterpret_cast<T*>(d.C);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (TN == 64) ? (wave >> 1) * 32 : wave * 16;
+  const int wn0 = (TN == 64) ? (wave & 1) * 32 : 0;
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  d4 acc[NP][MI][NI];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[p][i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  for (int k0 = 0; k0 < d.K; k0 += KT) {
+    // ---- stage A tile (64 x 16) ---------------------------------------------------
+    if (OPA == 0) {
+      const int i = tid & 63;
+#pragma unroll
+      for (int kk = tid >> 6; kk < KT; kk += 4) {
+        T v = sc<T>::zero();
+        if (m0 + i < d.M && k0 + kk < d.K) v = A[(size_t)(m0 + i) + (size_t)(k0 + kk) * d.lda];
+        if constexpr (CP) {
+          As[0][i][kk] = v.x;
+          As[1][i][kk] = v.y;
+        } else {
+          As[0][i][kk] = v;
+        }
+      }
+    } else {
+      const int kk = tid & 15;
+#pragma unroll
+      for (int i = tid >> 4; i < TM; i += 16) {
+        T v = sc<T>::zero();
+        if (m0 + i < d.M && k0 + kk < d.K) v = A[(size_t)(k0 + kk) + (size_t)(m0 + i) * d.lda];
+        if constexpr (CP) {
+          As[0][i][kk] = v.x;
+          As[1][i][kk] = -v.y;  // conjugate
+        } else {
+          As[0][i][kk] = v;
+        }
+      }
+    }
+    // ---- stage B tile (16 x TN) ---------------------------------------------------
+    {
+      const int kk = tid & 15;
+#pragma unroll
+      for (int j = tid >> 4; j < TN; j += 16) {
+        T v = sc<T>::zero();
+        if (n0 + j < d.N && k0 + kk < d.K) v = B[(size_t)(k0 + kk) + (size_t)(n0 + j) * d.ldb];
+        if constexpr (CP) {
+          Bs[0][j][kk] = v.x;
+          Bs[1][j][kk] = v.y;
+        } else {
+          Bs[0][j][kk] = v;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kc = 0; kc < KT; kc += 4) {
+      double ar[MI], ai[MI], br[NI], bi[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        ar[i] = As[0][wm0 + i * 16 + l15][kc + l4];
+        if constexpr (CP) ai[i] = As[1][wm0 + i * 16 + l15][kc + l4];
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        br[j] = Bs[0][wn0 + j * 16 + l15][kc + l4];
+        if constexpr (CP) bi[j] = Bs[1][wn0 + j * 16 + l15][kc + l4];
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[j], ar[i], acc[0][i][j], 0, 0, 0);
+          if constexpr (CP) {
+            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bi[j], ai[i], acc[0][i][j], 0, 0, 0);
+            acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[j], ar[i], acc[1][i][j], 0, 0, 0);
+            acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[j], ai[i], acc[1][i][j], 0, 0, 0);
+          }
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[m = l15][n = l4 + 4 r] of each 16 x 16 sub-tile -----------
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm0 + i * 16 + l15;
+        const int n = n0 + wn0 + j * 16 + l4 + 4 * r;
+        if (m < d.M && n < d.N) {
+          T* c = C + (size_t)m + (size_t)n * d.ldc;
+          if constexpr (CP) {
+            cd v = make_cd(alpha * acc[0][i][j][r], alpha * acc[1][i][j][r]);
+            if (beta != 0.0) {
+              cd o = *c;
+              v.x = fma(beta, o.x, v.x);
+              v.y = fma(beta, o.y, v.y);
+            }
+            *c = v;
+          } else {
+            double v = alpha * acc[0][i][j][r];
+            if (beta != 0.0) v = fma(beta, *c, v);
+            *c = v;
+          }
+        }
+      }
+}
+
+template <typename T>
+static int launch(int opA, double alpha, double beta, const tmf_gemm_desc* d, const int32_t* t, int nt, int tile_n,
+                  hipStream_t s) {
+  dim3 g(nt), b(256);
+  if (tile_n == 64) {
+    if (opA) hipLaunchKernelGGL((gemm_kernel<T, 1, 64>), g, b, 0, s, d, t, alpha, beta);
+    else hipLaunchKernelGGL((gemm_kernel<T, 0, 64>), g, b, 0, s, d, t, alpha, beta);
+  } else {
+    if (opA) hipLaunchKernelGGL((gemm_kernel<T, 1, 16>), g, b, 0, s, d, t, alpha, beta);
+    else hipLaunchKernelGGL((gemm_kernel<T, 0, 16>), g, b, 0, s, d, t, alpha, beta);
+  }
+  return check_hip(hipGetLastError(), "tmf_gemm_batched launch");
+}
+
+}  // namespace tmf
+
+extern "C" int tmf_gemm_batched(int dtype, int opA, double alpha, double beta, const tmf_gemm_desc* d_desc,
+                                const int32_t* d_tiles, int ntiles, int tile_n, void* stream) {
+  if (ntiles <= 0) return TMF_OK;
+  if (tile_n != 64 && tile_n != 16) {
+    tmf::set_error("tmf_gemm_batched: tile_n must be 64 or 16, got %d", tile_n);
+    return TMF_E_ARG;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == TMF_C128) return tmf::launch<tmf::cd>(opA, alpha, beta, d_desc, d_tiles, ntiles, tile_n, s);
+  if (dtype == TMF_F64) return tmf::launch<double>(opA, alpha, beta, d_desc, d_tiles, ntiles, tile_n, s);
+  tmf::set_error("tmf_gemm_batched: bad dtype %d", dtype);
+  return TMF_E_ARG;
+}

@@ -1,0 +1,405 @@
+// Host side of the sweep: the integer / combinatorial work between the dense kernels.
+//
+//  tmf_cut_vectors   best-first enumeration of occupation patterns and their ordering
+//                    (schmidt_utils.py:211-324, :99-185; slater.py:662-689)
+//  tmf_site_prepare  merged bra leg, always/sometimes/never split with anticommutation
+//                    signs, charge-sector matching and the index lists of every minor
+//                    (slater.py:1023-1067, :760-825, :1132-1141, :857-864)
+//
+// Occupation patterns are 128-bit masks instead of boolean arrays; everything else keeps the
+// reference's ordering rules so that integer outputs are identical.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <queue>
+#include <vector>
+
+#include "../../include/temfpy_hip.h"
+
+namespace tmf {
+void set_error(const char* fmt, ...);
+}
+
+namespace {
+
+struct Mask {
+  uint64_t lo, hi;
+  bool get(int i) const { return i < 64 ? (lo >> i) & 1 : (hi >> (i - 64)) & 1; }
+  void flip(int i) {
+    if (i < 64) lo ^= (1ull << i);
+    else hi ^= (1ull << (i - 64));
+  }
+  int count() const { return __builtin_popcountll(lo) + __builtin_popcountll(hi); }
+};
+
+// numpy's pairwise summation (the order np.sum uses on a contiguous double array)
+double np_pairwise_sum(const double* a, int n) {
+  if (n < 8) {
+    double res = 0.0;
+    for (int i = 0; i < n; ++i) res += a[i];
+    return res;
+  }
+  if (n <= 128) {
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+struct Node {
+  double sum;
+  int64_t seq;
+  int i;
+  Mask set;
+};
+struct NodeGreater {  // min-heap on (sum, seq): the tuple order of schmidt_utils.py:290-314
+  bool operator()(const Node& a, const Node& b) const {
+    if (a.sum != b.sum) return a.sum > b.sum;
+    return a.seq > b.seq;
+  }
+};
+
+}  // namespace
+
+extern "C" int tmf_cut_vectors(const double* e, int k, int filled_left, int64_t chi_max, double svd_min,
+                               double degeneracy_tol, const int64_t* sectors, int n_sectors, int64_t chi_cap,
+                               uint64_t* sets_out, double* lam_raw, int32_t* q_left, int64_t* chi_out,
+                               int64_t* n_checked_out) {
+  if (k < 0 || k > 128) {
+    tmf::set_error("tmf_cut_vectors: %d entangled orbitals (supported: 0..128)", k);
+    return TMF_E_LIMIT;
+  }
+  if (!(svd_min > 0.0 && svd_min < 1.0) || !(degeneracy_tol > 0.0)) {
+    tmf::set_error("tmf_cut_vectors: svd_min must be in (0,1) and degeneracy_tol positive");
+    return TMF_E_ARG;
+  }
+  auto in_sector = [&](int q) {
+    if (!sectors) return true;
+    for (int i = 0; i < n_sectors; ++i)
+      if (sectors[i] == q) return true;
+    return false;
+  };
+  const double max_logval = -log(svd_min) + degeneracy_tol;  // schmidt_utils.py:96
+
+  std::vector<double> sums;
+  std::vector<Mask> sets;
+  int64_t n_checked = 1;
+
+  if (k == 0) {  // schmidt_utils.py:268-271
+    if (in_sector(filled_left)) {
+      sums.push_back(0.0);
+      sets.push_back(Mask{0, 0});
+    }
+  } else {
+    std::vector<double> a(k), av(k), neg;
+    for (int i = 0; i < k; ++i) {
+      a[i] = log((1.0 - e[i]) / e[i]) / 2.0;  // slater.py:428, :663
+      av[i] = fabs(a[i]);
+    }
+    Mask min_set{0, 0};
+    for (int i = 0; i < k; ++i)
+      if (a[i] < 0) {
+        neg.push_back(a[i]);
+        min_set.flip(i);
+      }
+    const double min_sum = np_pairwise_sum(neg.data(), (int)neg.size());
+    if (in_sector(filled_left + min_set.count())) {
+      sums.push_back(min_sum);
+      sets.push_back(min_set);
+    }
+    std::vector<int> idx(k);
+    for (int i = 0; i < k; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return av[x] < av[y]; });
+
+    std::priority_queue<Node, std::vector<Node>, NodeGreater> heap;
+    int64_t seq = 0;
+    {
+      Mask s = min_set;
+      s.flip(idx[0]);
+      heap.push(Node{min_sum + av[idx[0]], seq, 0, s});
+    }
+    auto keep_generating = [&]() {  // schmidt_utils.py:99-138
+      if (chi_max > 0 && (int64_t)sums.size() > chi_max) return false;
+      if (!sums.empty() && sums.back() - sums.front() > max_logval) return false;
+      return true;
+    };
+    while (!heap.empty() && keep_generating()) {
+      ++n_checked;
+      Node nd = heap.top();
+      heap.pop();
+      if (in_sector(filled_left + nd.set.count())) {
+        sums.push_back(nd.sum);
+        sets.push_back(nd.set);
+      }
+      if (nd.i < k - 1) {
+        Mask c1 = nd.set;
+        c1.flip(idx[nd.i + 1]);
+        double s = nd.sum + av[idx[nd.i + 1]];
+        heap.push(Node{s, ++seq, nd.i + 1, c1});
+        Mask c2 = c1;
+        c2.flip(idx[nd.i]);
+        s = s - av[idx[nd.i]];
+        heap.push(Node{s, ++seq, nd.i + 1, c2});
+      }
+    }
+  }
+  if (n_checked_out) *n_checked_out = n_checked;
+
+  // truncate (schmidt_utils.py:140-185)
+  int64_t cut = 0;
+  const int64_t n = (int64_t)sums.size();
+  if (n > 0) {
+    const double lim = -log(svd_min);
+    for (int64_t i = 0; i < n; ++i) {
+      bool ok = true;
+      if (chi_max > 0 && i >= chi_max) ok = false;
+      if (!(sums[i] - sums[0] < lim)) ok = false;
+      if (i + 1 < n && !((sums[i + 1] - sums[i]) > degeneracy_tol)) ok = false;
+      if (ok) cut = i + 1;
+    }
+    if (cut == 0) {
+      // numpy: np.nonzero(good)[0][-1] raises IndexError here; report it as an argument error
+      tmf::set_error("tmf_cut_vectors: no admissible truncation point (degenerate multiplet wider than chi_max)");
+      return TMF_E_ARG;
+    }
+  }
+  *chi_out = cut;
+  if (cut > chi_cap) {
+    tmf::set_error("tmf_cut_vectors: %lld vectors exceed the output capacity %lld", (long long)cut,
+                   (long long)chi_cap);
+    return TMF_E_LIMIT;
+  }
+  // stable sort by left charge (slater.py:672-678), Schmidt values (slater.py:489)
+  std::vector<int64_t> ord(cut);
+  for (int64_t i = 0; i < cut; ++i) ord[i] = i;
+  std::stable_sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) { return sets[x].count() < sets[y].count(); });
+  for (int64_t r = 0; r < cut; ++r) {
+    const Mask& s = sets[ord[r]];
+    sets_out[2 * r] = s.lo;
+    sets_out[2 * r + 1] = s.hi;
+    q_left[r] = filled_left + s.count();
+    double prod = 1.0;
+    for (int i = 0; i < k; ++i) prod *= s.get(i) ? e[i] : 1.0 - e[i];
+    lam_raw[r] = sqrt(prod);
+  }
+  return TMF_OK;
+}
+
+// -------------------------------------------------------------------------------------------
+namespace {
+
+struct Side {
+  int k, nf, chi;
+  const uint64_t* sets;
+  bool right;
+  // occupation of entangled orbital j (side order) in Schmidt vector alpha
+  bool occ(int alpha, int j) const {
+    Mask m{sets[2 * alpha], sets[2 * alpha + 1]};
+    return right ? !m.get(k - 1 - j) : m.get(j);
+  }
+  int ent_count(int alpha) const {
+    Mask m{sets[2 * alpha], sets[2 * alpha + 1]};
+    return right ? k - m.count() : m.count();
+  }
+};
+
+}  // namespace
+
+extern "C" int tmf_site_prepare(const tmf_site_in* in, const uint64_t* sets_b, const int32_t* q_b,
+                                const uint64_t* sets_k, const int32_t* q_k, int32_t* row_sel, int8_t* row_sign,
+                                int32_t* col_sel, int8_t* col_sign, int32_t* bra_p, int32_t* bra_alpha,
+                                tmf_sector* sectors, int32_t sector_cap, uint8_t* idx_pool, int64_t idx_cap,
+                                tmf_site_out* out) {
+  (void)q_b;
+  const bool right = in->mode == 1;
+  Side B{in->k_b, in->nf_b, in->chi_b, sets_b, right};
+  Side K{in->k_k, in->nf_k, in->chi_k, sets_k, right};
+  if (B.chi <= 0 || K.chi <= 0) {
+    tmf::set_error("tmf_site_prepare: empty Schmidt basis");
+    return TMF_E_ARG;
+  }
+
+  // ---- classify entangled orbitals: 0 never, 1 sometimes, 2 always --------------------------
+  auto classify = [](const Side& s, std::vector<int>& cls) {
+    cls.assign(s.k, 0);
+    for (int j = 0; j < s.k; ++j) {
+      int cnt = 0;
+      for (int a = 0; a < s.chi; ++a) cnt += s.occ(a, j);
+      cls[j] = cnt == 0 ? 0 : (cnt == s.chi ? 2 : 1);
+    }
+  };
+  std::vector<int> cb, ck;
+  classify(B, cb);
+  classify(K, ck);
+
+  // orbital lists in the reference's column order; entry = device column (-1: physical)
+  struct Orb {
+    int src;    // device column: entangled j -> j ; filled f -> k + f ; physical -> -1
+    int ent;    // entangled index or -1
+    int sign;
+  };
+  auto build = [&](const Side& s, const std::vector<int>& cls, bool with_phys, std::vector<Orb>& always,
+                   std::vector<Orb>& some) {
+    always.clear();
+    some.clear();
+    if (!right) {  // reference order: filled, entangled, [physical]
+      for (int f = 0; f < s.nf; ++f) always.push_back(Orb{s.k + f, -1, 1});
+      for (int j = 0; j < s.k; ++j)
+        if (cls[j] == 2) always.push_back(Orb{j, j, 1});
+      const int ka = (int)always.size();
+      int n_always_before = s.nf;
+      for (int j = 0; j < s.k; ++j) {
+        if (cls[j] == 2) ++n_always_before;
+        if (cls[j] == 1) some.push_back(Orb{j, j, ((ka - n_always_before) & 1) ? -1 : 1});  // slater.py:813
+      }
+      if (with_phys) some.push_back(Orb{-1, -1, 1});  // last column: no always orbital to its right
+    } else {  // reference order: [physical], entangled, filled
+      if (with_phys) some.push_back(Orb{-1, -1, 1});  // first column: no always orbital to its left
+      int n_always_before = 0;
+      for (int j = 0; j < s.k; ++j) {
+        if (cls[j] == 2) {
+          always.push_back(Orb{j, j, 1});
+          ++n_always_before;
+        }
+        if (cls[j] == 1) some.push_back(Orb{j, j, (n_always_before & 1) ? -1 : 1});  // slater.py:820
+      }
+      for (int f = 0; f < s.nf; ++f) always.push_back(Orb{s.k + f, -1, 1});
+    }
+  };
+  std::vector<Orb> ab, sb_, ak, sk_;
+  build(B, cb, true, ab, sb_);
+  build(K, ck, false, ak, sk_);
+  const int kb = (int)ab.size(), kk = (int)ak.size();
+  const int k = std::min(kb, kk);  // slater.py:1069
+
+  // W rows: [always block (k)] then the S rows in the reference's trimmed order
+  std::vector<Orb> rows, cols;
+  std::vector<Orb> srows, scols;  // S-row / S-col orbitals (positions used by the minors)
+  auto assemble = [&](const std::vector<Orb>& always, const std::vector<Orb>& some, std::vector<Orb>& all,
+                      std::vector<Orb>& s_part) {
+    const int ka = (int)always.size();
+    all.clear();
+    s_part.clear();
+    if (!right) {  // O[:k,:k] is the always block; O[k:] = remaining always, then sometimes
+      for (int i = 0; i < k; ++i) all.push_back(always[i]);
+      for (int i = k; i < ka; ++i) s_part.push_back(always[i]);
+      for (auto& o : some) s_part.push_back(o);
+    } else {  // O[-k:,-k:] is the always block; O[:-k] = sometimes, then the first ka-k always
+      for (int i = ka - k; i < ka; ++i) all.push_back(always[i]);
+      for (auto& o : some) s_part.push_back(o);
+      for (int i = 0; i < ka - k; ++i) s_part.push_back(always[i]);
+    }
+    for (auto& o : s_part) all.push_back(o);
+  };
+  assemble(ab, sb_, rows, srows);
+  assemble(ak, sk_, cols, scols);
+  const int mb = (int)rows.size(), mk = (int)cols.size();
+  const int sb = mb - k, sk = mk - k;
+  if (sb > 255 || sk > 255) {
+    tmf::set_error("tmf_site_prepare: %d x %d sometimes-matrix exceeds the 8-bit index lists", sb, sk);
+    return TMF_E_LIMIT;
+  }
+  for (int i = 0; i < mb; ++i) row_sel[i] = rows[i].src, row_sign[i] = (int8_t)rows[i].sign;
+  for (int i = 0; i < mk; ++i) col_sel[i] = cols[i].src, col_sign[i] = (int8_t)cols[i].sign;
+
+  // ---- merged bra leg: (p, alpha) sorted stably by the charge to the left (slater.py:1053-1058)
+  const int nb2 = 2 * B.chi;
+  std::vector<int> cnt(nb2), perm(nb2);
+  for (int r = 0; r < nb2; ++r) {
+    const int p = r >= B.chi, a = r % B.chi;
+    cnt[r] = B.nf + B.ent_count(a) + p;  // particles in the bra orbitals incl. the physical one
+    perm[r] = r;
+  }
+  if (!right) std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return cnt[x] < cnt[y]; });
+  else std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return cnt[x] > cnt[y]; });
+  for (int r = 0; r < nb2; ++r) {
+    bra_p[r] = perm[r] >= B.chi;
+    bra_alpha[r] = perm[r] % B.chi;
+  }
+
+  // ---- charge sectors of the ket leg and the matching bra rows (slater.py:1132-1141) ----------
+  auto occupied = [&](const Side& s, const Orb& o, int alpha, int p) -> bool {
+    if (o.src < 0) return p != 0;
+    if (o.ent < 0) return true;  // filled
+    return s.occ(alpha, o.ent);
+  };
+  int nsec = 0;
+  int64_t idx_used = 0, out_elems = 0;
+  int c0 = 0;
+  while (c0 < K.chi) {
+    int c1 = c0;
+    while (c1 < K.chi && q_k[c1] == q_k[c0]) ++c1;
+    const int kcnt = K.nf + K.ent_count(c0);
+    // bra rows with the same particle number (contiguous in the sorted order)
+    int r0 = -1, r1 = -1;
+    for (int r = 0; r < nb2; ++r)
+      if (cnt[perm[r]] == kcnt) {
+        if (r0 < 0) r0 = r;
+        r1 = r + 1;
+      }
+    if (r0 >= 0) {
+      if (nsec >= sector_cap) {
+        tmf::set_error("tmf_site_prepare: more than %d charge sectors", sector_cap);
+        return TMF_E_LIMIT;
+      }
+      // order of the minors: occupied S-columns of the first ket row
+      int n = 0;
+      for (int i = 0; i < sk; ++i) n += occupied(K, scols[i], c0, 0);
+      const int64_t need = (int64_t)(r1 - r0 + c1 - c0) * n;
+      if (idx_used + need > idx_cap) {
+        tmf::set_error("tmf_site_prepare: index pool too small (%lld > %lld)", (long long)(idx_used + need),
+                       (long long)idx_cap);
+        return TMF_E_LIMIT;
+      }
+      tmf_sector& S = sectors[nsec++];
+      S.q = q_k[c0];
+      S.r0 = r0, S.r1 = r1, S.c0 = c0, S.c1 = c1, S.n = n;
+      S.bra_off = idx_used;
+      for (int r = r0; r < r1; ++r) {
+        int m = 0;
+        for (int i = 0; i < sb; ++i)
+          if (occupied(B, srows[i], bra_alpha[r], bra_p[r])) {
+            if (m < n) idx_pool[idx_used + m] = (uint8_t)i;
+            ++m;
+          }
+        if (m != n) {  // slater.py:847-855
+          tmf::set_error("tmf_site_prepare: bra row %d has %d particles in the minor, ket sector has %d", r, m, n);
+          return TMF_E_ARG;
+        }
+        idx_used += n;
+      }
+      S.ket_off = idx_used;
+      for (int c = c0; c < c1; ++c) {
+        int m = 0;
+        for (int i = 0; i < sk; ++i)
+          if (occupied(K, scols[i], c, 0)) {
+            if (m < n) idx_pool[idx_used + m] = (uint8_t)i;
+            ++m;
+          }
+        if (m != n) {
+          tmf::set_error("tmf_site_prepare: ket row %d has %d particles in the minor, sector has %d", c, m, n);
+          return TMF_E_ARG;
+        }
+        idx_used += n;
+      }
+      S.out_off = out_elems;
+      out_elems += (int64_t)(r1 - r0) * (c1 - c0);
+    }
+    c0 = c1;
+  }
+  out->mb = mb, out->mk = mk, out->k_always = k, out->sb = sb, out->sk = sk, out->n_sectors = nsec;
+  out->idx_bytes = idx_used;
+  out->out_elems = out_elems;
+  return TMF_OK;
+}

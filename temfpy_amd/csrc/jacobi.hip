@@ -1,0 +1,171 @@
+// One-sided (Hestenes) Jacobi for small dense matrices, one workgroup per problem,
+// X (p x p) and the accumulated rotations V resident in LDS:   X V = U diag(s).
+//
+// Used twice per entanglement cut instead of numpy.linalg.eigh (slater.py:347):
+//  * on the column-graded triangular factor of the projected off-diagonal block, where
+//    its high relative accuracy resolves singular values around sqrt(cutoff) = 1e-6 that a
+//    Gram-matrix eigensolver would bury in rounding noise, and
+//  * on the Rayleigh-Ritz matrix of the entangled subspace (Hermitian PSD: s = eigenvalues,
+//    V = eigenvectors).
+// Rotations of one round (p/2 disjoint pairs, round-robin tournament) run in parallel, each
+// pair on TPP lanes of one wavefront; dot products are reduced with width-TPP shuffles.
+#include "common.hpp"
+
+namespace tmf {
+
+template <typename T>
+__global__ __launch_bounds__(256) void jacobi_kernel(const tmf_jacobi_desc* __restrict__ desc,
+                                                     int32_t* __restrict__ sweeps_out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const tmf_jacobi_desc d = desc[blockIdx.x];
+  const int p = d.p;
+  if (p <= 0) return;
+  T* X = reinterpret_cast<T*>(smem);        // X[c * p + r]
+  T* V = X + (size_t)p * p;
+  double* nrm = reinterpret_cast<double*>(V + (size_t)p * p);  // p norms
+  int* flag = reinterpret_cast<int*>(nrm + p);                 // rotation counter
+
+  const int tid = threadIdx.x;
+  const T* __restrict__ Xg = reinterpret_cast<const T*>(d.X);
+  for (int e = tid; e < p * p; e += 256) {
+    const int r = e % p, c = e / p;
+    X[e] = Xg[(size_t)r + (size_t)c * d.ldx];
+    V[e] = (r == c) ? sc<T>::one() : sc<T>::zero();
+  }
+  if (tid == 0) *flag = 0;
+  __syncthreads();
+
+  const int pe = (p + 1) & ~1;      // players (even)
+  const int m = pe - 1;             // players on the circle; player m sits still
+  const int npairs = pe / 2;
+  int tpp = 64;                     // lanes per pair: largest power of two with npairs*tpp <= 256
+  while (tpp * npairs > 256) tpp >>= 1;
+  const int pair = tid / tpp, pl = tid % tpp;
+  const double eps = 1.1e-16;
+
+  int sweep = 0;
+  for (; sweep < 60; ++sweep) {
+    for (int rho = 0; rho < m; ++rho) {
+      if (pair < npairs) {  // a pair never straddles wavefronts (tpp divides 64)
+        int i, j;
+        if (pair == 0) {
+          i = m;
+          j = rho;
+        } else {
+          i = (rho + pair) % m;
+          j = (rho - pair + m) % m;
+        }
+        if (i > j) {
+          const int t = i;
+          i = j;
+          j = t;
+        }
+        if (j < p) {
+          T* xi = X + (size_t)i * p;
+          T* xj = X + (size_t)j * p;
+          double al = 0.0, be = 0.0;
+          T ga = sc<T>::zero();
+          for (int r = pl; r < p; r += tpp) {
+            const T a = xi[r], b = xj[r];
+            al += sc<T>::abs2(a);
+            be += sc<T>::abs2(b);
+            ga = sc<T>::fmacc(ga, a, b);
+          }
+          for (int o = tpp >> 1; o > 0; o >>= 1) {
+            al += __shfl_xor(al, o, tpp);
+            be += __shfl_xor(be, o, tpp);
+            ga = sc<T>::add(ga, shfl_xor_t<T>(ga, o, tpp));
+          }
+          const double g2 = sc<T>::abs2(ga);
+          if (g2 > eps * eps * al * be && g2 > 0.0) {
+            const double g = sqrt(g2);
+            const double zeta = (be - al) / (2.0 * g);
+            const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+            // phase e^{-i theta} of gamma, folded into column j
+            const T ph = sc<T>::scale(sc<T>::conj(ga), 1.0 / g);
+            const T sph = sc<T>::scale(ph, s), cph = sc<T>::scale(ph, c);
+            for (int r = pl; r < p; r += tpp) {
+              const T a = xi[r], b = xj[r];
+              xi[r] = sc<T>::sub(sc<T>::scale(a, c), sc<T>::mul(sph, b));
+              xj[r] = sc<T>::add(sc<T>::scale(a, s), sc<T>::mul(cph, b));
+            }
+            T* vi = V + (size_t)i * p;
+            T* vj = V + (size_t)j * p;
+            for (int r = pl; r < p; r += tpp) {
+              const T a = vi[r], b = vj[r];
+              vi[r] = sc<T>::sub(sc<T>::scale(a, c), sc<T>::mul(sph, b));
+              vj[r] = sc<T>::add(sc<T>::scale(a, s), sc<T>::mul(cph, b));
+            }
+            if (pl == 0) atomicAdd(flag, 1);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    const int rot = *flag;
+    __syncthreads();
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    if (rot == 0) break;
+  }
+  if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sweep;
+
+  // column norms, rank by descending norm (ties: lower index first)
+  for (int c = tid; c < p; c += 256) {
+    double s = 0.0;
+    for (int r = 0; r < p; ++r) s += sc<T>::abs2(X[(size_t)c * p + r]);
+    nrm[c] = sqrt(s);
+  }
+  __syncthreads();
+  T* __restrict__ Vg = reinterpret_cast<T*>(d.V);
+  T* __restrict__ Ug = reinterpret_cast<T*>(d.U);
+  double* __restrict__ sg = reinterpret_cast<double*>(d.s);
+  for (int e = tid; e < p * p; e += 256) {
+    const int r = e % p, c = e / p;
+    const double sc_ = nrm[c];
+    int rank = 0;
+    for (int c2 = 0; c2 < p; ++c2) rank += (nrm[c2] > sc_) || (nrm[c2] == sc_ && c2 < c);
+    const bool keep = !(d.thresh2 > 0.0) || sc_ * sc_ >= d.thresh2;
+    Vg[(size_t)r + (size_t)rank * d.ldv] = keep ? V[e] : sc<T>::zero();
+    if (Ug) Ug[(size_t)r + (size_t)rank * d.ldu] = sc<T>::scale(X[e], (keep && sc_ > 0.0) ? 1.0 / sc_ : 0.0);
+    if (r == 0) sg[rank] = sc_;
+  }
+  if (tid == 0 && d.count) {
+    int cnt = 0;
+    for (int c = 0; c < p; ++c) cnt += !(d.thresh2 > 0.0) || nrm[c] * nrm[c] >= d.thresh2;
+    *reinterpret_cast<int32_t*>(d.count) = cnt;
+  }
+}
+
+}  // namespace tmf
+
+extern "C" int tmf_jacobi_batched(int dtype, const tmf_jacobi_desc* d_desc, int nprob, int max_p, int32_t* d_sweeps,
+                                  void* stream) {
+  using namespace tmf;
+  if (nprob <= 0) return TMF_OK;
+  const size_t elem = (dtype == TMF_C128) ? 16 : 8;
+  const size_t lds = 2 * (size_t)max_p * max_p * elem + (size_t)max_p * 8 + 64;
+  if (max_p <= 0 || max_p > 128 || lds > 160 * 1024) {
+    set_error("tmf_jacobi_batched: p = %d needs %zu B of LDS (limit 160 KiB: p <= 64 complex, p <= 96 real)", max_p,
+              lds);
+    return TMF_E_LIMIT;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)jacobi_kernel<cd>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)jacobi_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_done = true;
+  }
+  if (dtype == TMF_C128)
+    hipLaunchKernelGGL(jacobi_kernel<cd>, dim3(nprob), dim3(256), lds, s, d_desc, d_sweeps);
+  else if (dtype == TMF_F64)
+    hipLaunchKernelGGL(jacobi_kernel<double>, dim3(nprob), dim3(256), lds, s, d_desc, d_sweeps);
+  else {
+    set_error("tmf_jacobi_batched: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+  return check_hip(hipGetLastError(), "tmf_jacobi_batched launch");
+}

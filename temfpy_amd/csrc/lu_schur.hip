@@ -1,0 +1,193 @@
+// Blocked LU restricted to the leading k x k "always" block, producing its determinant
+// and the Schur complement onto the "sometimes" orbitals in one pass:
+//
+//   W = [ A  B ]      det_always = det(A),      S = D - C A^-1 B   (left in W[k:, k:])
+//       [ C  D ]
+//
+// Reference: slater.py:1077-1090 (numpy det + inv + two matrix products per site).
+// One 256-thread workgroup per site.  A panel of NB columns (all rows below the diagonal)
+// is factored in LDS with partial pivoting among the always rows only; the trailing matrix
+// is then updated once per panel (each thread keeps its row of the L panel in registers and
+// streams the columns), so the matrix crosses L2/HBM k/NB times instead of k times.
+#include "common.hpp"
+
+namespace tmf {
+
+constexpr int NBMAX = 16;
+constexpr int UCH = 32;  // columns of U12 staged per chunk
+
+template <typename T>
+__global__ __launch_bounds__(256) void lu_schur_kernel(const tmf_schur_desc* __restrict__ desc, const int NB) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const tmf_schur_desc d = desc[blockIdx.x];
+  const int mb = d.mb, mk = d.mk, k = d.k, ldw = d.ldw;
+  T* __restrict__ W = reinterpret_cast<T*>(d.W);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // LDS: panel P[c * rows + r] (rows <= mb), U chunk [UCH][NBMAX], reduction scratch
+  T* P = reinterpret_cast<T*>(smem);
+  T* Uc = P + (size_t)mb * NB;
+  double* rv = reinterpret_cast<double*>(Uc + UCH * NBMAX);
+  int* ri = reinterpret_cast<int*>(rv + 4);
+  int* pivs = ri + 4;  // NBMAX pivots of the current panel
+
+  T det = sc<T>::one();
+
+  for (int j0 = 0; j0 < k; j0 += NB) {
+    const int jb = min(NB, k - j0);
+    const int rows = mb - j0;       // panel rows j0 .. mb-1
+    const int prow = k - j0;        // rows eligible as pivots: local [j, prow)
+    for (int e = tid; e < rows * jb; e += 256) {
+      const int r = e % rows, c = e / rows;
+      P[(size_t)c * rows + r] = W[(size_t)(j0 + r) + (size_t)(j0 + c) * ldw];
+    }
+    __syncthreads();
+    // ---- factor the panel -------------------------------------------------------------
+    for (int j = 0; j < jb; ++j) {
+      T* pj = P + (size_t)j * rows;
+      double bv = -1.0;
+      int bi = j;
+      for (int r = j + tid; r < prow; r += 256) {
+        const double v = sc<T>::abs2(pj[r]);
+        if (v > bv) bv = v, bi = r;
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
+      }
+      if (lane == 0) rv[wave] = bv, ri[wave] = bi;
+      __syncthreads();
+      if (tid == 0) {
+        double b = rv[0];
+        int ix = ri[0];
+        for (int q = 1; q < 4; ++q)
+          if (rv[q] > b || (rv[q] == b && ri[q] < ix)) b = rv[q], ix = ri[q];
+        pivs[j] = ix;
+      }
+      __syncthreads();
+      const int piv = pivs[j];
+      if (piv != j && tid < jb) {  // swap rows j <-> piv inside the panel
+        const T t = P[(size_t)tid * rows + j];
+        P[(size_t)tid * rows + j] = P[(size_t)tid * rows + piv];
+        P[(size_t)tid * rows + piv] = t;
+      }
+      __syncthreads();
+      const T pv = pj[j];
+      det = sc<T>::mul(det, pv);
+      if (piv != j) det = sc<T>::neg(det);
+      const T pinv = sc<T>::abs2(pv) > 0.0 ? sc<T>::inv(pv) : sc<T>::zero();
+      for (int r = j + 1 + tid; r < rows; r += 256) {
+        const T l = sc<T>::mul(pj[r], pinv);
+        pj[r] = l;
+        for (int c = j + 1; c < jb; ++c) {
+          T* pc = P + (size_t)c * rows;
+          pc[r] = sc<T>::fms(pc[r], l, pc[j]);
+        }
+      }
+      __syncthreads();
+    }
+    // ---- apply the row swaps to the trailing columns ---------------------------------------
+    const int c0 = j0 + jb;
+    const int ncols = mk - c0;
+    for (int c = tid; c < ncols; c += 256) {
+      T* col = W + (size_t)(c0 + c) * ldw + j0;
+      for (int j = 0; j < jb; ++j) {
+        const int piv = pivs[j];
+        if (piv != j) {
+          const T t = col[j];
+          col[j] = col[piv];
+          col[piv] = t;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- trailing update in column chunks: U12 = L11^-1 A12 ; A22 -= L21 U12 ----------------
+    const int r2 = rows - jb;  // rows below the panel's diagonal block
+    for (int cc = 0; cc < ncols; cc += UCH) {
+      const int nc = min(UCH, ncols - cc);
+      if (tid < nc) {  // one thread per column: forward substitution with unit-lower L11
+        T* col = W + (size_t)(c0 + cc + tid) * ldw + j0;
+        T u[NBMAX];
+#pragma unroll
+        for (int q = 0; q < NBMAX; ++q) u[q] = (q < jb) ? col[q] : sc<T>::zero();
+#pragma unroll
+        for (int q = 0; q < NBMAX; ++q) {
+          if (q < jb) {
+#pragma unroll
+            for (int r = q + 1; r < NBMAX; ++r)
+              if (r < jb) u[r] = sc<T>::fms(u[r], P[(size_t)q * rows + r], u[q]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NBMAX; ++q) {
+          if (q < jb) {
+            col[q] = u[q];
+            Uc[tid * NBMAX + q] = u[q];
+          }
+        }
+      }
+      __syncthreads();
+      for (int rb = 0; rb < r2; rb += 256) {
+        const int r = rb + tid;
+        if (r < r2) {
+          T l[NBMAX];
+#pragma unroll
+          for (int q = 0; q < NBMAX; ++q) l[q] = (q < jb) ? P[(size_t)q * rows + jb + r] : sc<T>::zero();
+          T* rowp = W + (size_t)(j0 + jb + r) + (size_t)(c0 + cc) * ldw;
+          for (int c = 0; c < nc; ++c) {
+            T x = rowp[(size_t)c * ldw];
+#pragma unroll
+            for (int q = 0; q < NBMAX; ++q)
+              if (q < jb) x = sc<T>::fms(x, l[q], Uc[c * NBMAX + q]);
+            rowp[(size_t)c * ldw] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) *reinterpret_cast<T*>(d.det) = det;
+  if (d.S) {  // optional compact copy of the Schur complement
+    T* __restrict__ S = reinterpret_cast<T*>(d.S);
+    const int sr = mb - k, scn = mk - k;
+    __syncthreads();
+    for (int e = tid; e < sr * scn; e += 256) {
+      const int r = e % sr, c = e / sr;
+      S[(size_t)r + (size_t)c * d.lds] = W[(size_t)(k + r) + (size_t)(k + c) * ldw];
+    }
+  }
+}
+
+}  // namespace tmf
+
+extern "C" int tmf_lu_schur_batched(int dtype, const tmf_schur_desc* d_desc, int nprob, int max_mb, void* stream) {
+  using namespace tmf;
+  if (nprob <= 0) return TMF_OK;
+  const size_t elem = (dtype == TMF_C128) ? 16 : 8;
+  int nb = NBMAX;  // panel width: shrink until the mb x nb panel fits the 160 KiB LDS
+  auto need = [&](int w) { return ((size_t)max_mb * w + UCH * NBMAX) * elem + 256; };
+  while (need(nb) > 160 * 1024 && nb > 1) nb >>= 1;
+  const size_t lds = need(nb);
+  if (lds > 160 * 1024) {
+    set_error("tmf_lu_schur_batched: mb = %d needs %zu B of LDS (> 160 KiB)", max_mb, lds);
+    return TMF_E_LIMIT;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)lu_schur_kernel<cd>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lu_schur_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_done = true;
+  }
+  if (dtype == TMF_C128)
+    hipLaunchKernelGGL(lu_schur_kernel<cd>, dim3(nprob), dim3(256), lds, s, d_desc, nb);
+  else if (dtype == TMF_F64)
+    hipLaunchKernelGGL(lu_schur_kernel<double>, dim3(nprob), dim3(256), lds, s, d_desc, nb);
+  else {
+    set_error("tmf_lu_schur_batched: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+  return check_hip(hipGetLastError(), "tmf_lu_schur_batched launch");
+}

@@ -1,0 +1,180 @@
+// Error plumbing + small utility kernels (transpose, RNG fill, signed gather, column normalise).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.hpp"
+
+namespace tmf {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return TMF_OK;
+  set_error("%s: %s", what, hipGetErrorString(e));
+  return TMF_E_HIP;
+}
+
+// ---- transpose: row-major host layout -> column-major device layout -----------------
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int n) {
+  __shared__ T tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int i = by + r, j = bx + tx;  // in[i][j] row-major
+    if (i < n && j < n) tile[r][tx] = in[(size_t)i * n + j];
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    // out column-major: out[i + j*n] = in[i*n + j] -> write runs along i
+    const int j = bx + r, i = by + tx;
+    if (i < n && j < n) out[(size_t)i + (size_t)j * n] = tile[tx][r];
+  }
+}
+
+// ---- counter-based normal fill (splitmix64 + Box-Muller) -----------------------------
+__device__ inline uint64_t splitmix(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void fill_normal_kernel(double* __restrict__ out, int64_t pairs, int64_t count,
+                                                          uint64_t seed) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < pairs; i += stride) {
+    const uint64_t a = splitmix(seed ^ (uint64_t)(2 * i)), b = splitmix(seed ^ (uint64_t)(2 * i + 1));
+    const double u1 = ((a >> 11) + 1.0) * (1.0 / 9007199254740993.0);  // (0,1]
+    const double u2 = (b >> 11) * (1.0 / 9007199254740992.0);
+    const double r = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincospi(2.0 * u2, &s, &c);
+    if (2 * i < count) out[2 * i] = r * c;
+    if (2 * i + 1 < count) out[2 * i + 1] = r * s;
+  }
+}
+
+// ---- signed gather: dst[r,c] = sr[r]*sc[c]*src[row_sel[r], col_sel[c]] -----------------
+template <typename T>
+__global__ __launch_bounds__(256) void gather_kernel(const tmf_gather_desc* __restrict__ desc) {
+  const tmf_gather_desc d = desc[blockIdx.x];
+  const T* __restrict__ src = reinterpret_cast<const T*>(d.src);
+  const T* __restrict__ phys = reinterpret_cast<const T*>(d.phys);
+  T* __restrict__ dst = reinterpret_cast<T*>(d.dst);
+  const int32_t* rs = reinterpret_cast<const int32_t*>(d.row_sel);
+  const int32_t* cs = reinterpret_cast<const int32_t*>(d.col_sel);
+  const int8_t* rg = reinterpret_cast<const int8_t*>(d.row_sign);
+  const int8_t* cg = reinterpret_cast<const int8_t*>(d.col_sign);
+  const int total = d.rows * d.cols;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int r = e % d.rows, c = e / d.rows;
+    const int sr = rs[r], sc_ = cs[c];
+    T v = (sr < 0) ? phys[(size_t)sc_ * d.ldp] : src[(size_t)sr + (size_t)sc_ * d.lds_];
+    const double sg = (double)(rg[r] * cg[c]);
+    dst[(size_t)r + (size_t)c * d.ldd] = sc<T>::scale(v, sg);
+  }
+}
+
+// ---- column normalise (+ optional reversal / odd sign flip, slater.py:410) -------------
+template <typename T>
+__global__ __launch_bounds__(256) void colnorm_kernel(const tmf_colnorm_desc* __restrict__ desc) {
+  const tmf_colnorm_desc d = desc[blockIdx.x];
+  const T* __restrict__ src = reinterpret_cast<const T*>(d.src);
+  T* __restrict__ dst = reinterpret_cast<T*>(d.dst);
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = 0; c < d.c; ++c) {
+    double s = 0.0;
+    for (int r = threadIdx.x; r < d.n; r += 256) s += sc<T>::abs2(src[(size_t)r + (size_t)c * d.lds_]);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __syncthreads();
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const double nrm = sqrt(red[0] + red[1] + red[2] + red[3]);
+    const int cd_ = d.reverse ? d.c - 1 - c : c;
+    double f = nrm > 0.0 ? 1.0 / nrm : 0.0;
+    if (d.flip_odd && (cd_ & 1)) f = -f;
+    for (int r = threadIdx.x; r < d.n; r += 256)
+      dst[(size_t)r + (size_t)cd_ * d.ldd] = sc<T>::scale(src[(size_t)r + (size_t)c * d.lds_], f);
+  }
+}
+
+}  // namespace tmf
+
+using namespace tmf;
+
+extern "C" const char* tmf_last_error(void) { return tmf::g_err; }
+extern "C" int tmf_version(void) { return 100; }
+
+extern "C" int tmf_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+    return TMF_E_HIP;
+  }
+  return n;
+}
+
+extern "C" int tmf_transpose(int dtype, const void* d_in, void* d_out, int n, void* stream) {
+  if (n <= 0) return TMF_OK;
+  dim3 g((n + 31) / 32, (n + 31) / 32), b(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == TMF_C128)
+    hipLaunchKernelGGL(transpose_kernel<cd>, g, b, 0, s, (const cd*)d_in, (cd*)d_out, n);
+  else if (dtype == TMF_F64)
+    hipLaunchKernelGGL(transpose_kernel<double>, g, b, 0, s, (const double*)d_in, (double*)d_out, n);
+  else {
+    set_error("tmf_transpose: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+  return check_hip(hipGetLastError(), "tmf_transpose");
+}
+
+extern "C" int tmf_fill_normal(int dtype, void* d_out, int64_t count, uint64_t seed, void* stream) {
+  if (count <= 0) return TMF_OK;
+  const int64_t doubles = (dtype == TMF_C128) ? 2 * count : count;
+  const int64_t pairs = (doubles + 1) / 2;
+  int64_t blocks = (pairs + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     (double*)d_out, pairs, doubles, seed);
+  return check_hip(hipGetLastError(), "tmf_fill_normal");
+}
+
+extern "C" int tmf_gather_signed_batched(int dtype, const tmf_gather_desc* d_desc, int nprob, void* stream) {
+  if (nprob <= 0) return TMF_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == TMF_C128)
+    hipLaunchKernelGGL(gather_kernel<cd>, dim3(nprob), dim3(256), 0, s, d_desc);
+  else if (dtype == TMF_F64)
+    hipLaunchKernelGGL(gather_kernel<double>, dim3(nprob), dim3(256), 0, s, d_desc);
+  else {
+    set_error("tmf_gather_signed_batched: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+  return check_hip(hipGetLastError(), "tmf_gather_signed_batched");
+}
+
+extern "C" int tmf_normalise_columns_batched(int dtype, const tmf_colnorm_desc* d_desc, int nprob, void* stream) {
+  if (nprob <= 0) return TMF_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == TMF_C128)
+    hipLaunchKernelGGL(colnorm_kernel<cd>, dim3(nprob), dim3(256), 0, s, d_desc);
+  else if (dtype == TMF_F64)
+    hipLaunchKernelGGL(colnorm_kernel<double>, dim3(nprob), dim3(256), 0, s, d_desc);
+  else {
+    set_error("tmf_normalise_columns_batched: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+  return check_hip(hipGetLastError(), "tmf_normalise_columns_batched");
+}

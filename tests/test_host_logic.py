@@ -1,0 +1,144 @@
+"""CPU tests of the C-ABI host entry points (tmf_cut_vectors, tmf_site_prepare) against the
+oracle and the reference fixtures.  No GPU calls."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_names
+from oracle import slater_oracle as orc
+from temfpy_amd import _native as nat
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def masks_to_bool(sets, k):
+    out = np.zeros((len(sets), k), bool)
+    for i in range(k):
+        out[:, i] = (sets[:, i // 64] >> np.uint64(i % 64)) & np.uint64(1)
+    return out
+
+
+def test_library_exports_every_symbol():
+    lib = nat.load()
+    for s in nat.SYMBOLS:
+        assert hasattr(lib, s)
+    assert lib.tmf_version() >= 100
+    hdr = open(os.path.join(os.path.dirname(GOLDEN), "..", "include", "temfpy_hip.h")).read()
+    import re
+    declared = set(re.findall(r"\b(tmf_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(nat.SYMBOLS), declared ^ set(nat.SYMBOLS)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_cut_vectors_matches_reference_fixture(name):
+    g = load(name)
+    L = int(g["L"])
+    for b in range(L + 1):
+        e = g[f"b{b}_e"]
+        sets, lam, q, _ = nat.cut_vectors(e, int(g[f"b{b}_nfilled"][0]), int(g["chi_max"]), 1e-6, 1e-12)
+        ref = g[f"b{b}_sets"]
+        got = masks_to_bool(sets, e.size)
+        if not np.array_equal(got, ref):
+            # only the order inside a numerically degenerate multiplet may differ (libm log vs numpy log)
+            assert got.shape == ref.shape
+            assert sorted(map(bytes, got)) == sorted(map(bytes, ref))
+            np.testing.assert_allclose(np.sort(lam), np.sort(g[f"b{b}_lam_raw"]), rtol=1e-12)
+        else:
+            np.testing.assert_allclose(lam, g[f"b{b}_lam_raw"], rtol=1e-13, atol=0)
+        # charges ascending, sector boundaries as in the fixture
+        qs, start = np.unique(q, return_index=True)
+        np.testing.assert_array_equal(qs, g[f"b{b}_q"])
+        np.testing.assert_array_equal(start, g[f"b{b}_qstart"])
+
+
+def test_cut_vectors_edge_cases():
+    sets, lam, q, _ = nat.cut_vectors(np.zeros(0), 3, 8, 1e-6, 1e-12)
+    assert sets.shape == (1, 2) and lam[0] == 1.0 and q[0] == 3
+    sets, lam, q, _ = nat.cut_vectors(np.zeros(0), 3, 8, 1e-6, 1e-12, sectors=[2])
+    assert len(lam) == 0
+    # sector filter
+    e = np.array([0.9, 0.5, 0.2])
+    sets, lam, q, _ = nat.cut_vectors(e, 1, 0, 1e-6, 1e-12, sectors=[2])
+    assert np.all(q == 2) and len(q) == 3
+    # unlimited chi, all 8 subsets
+    sets, lam, q, _ = nat.cut_vectors(e, 0, 0, 1e-6, 1e-12)
+    assert len(lam) == 8 and abs((lam**2).sum() - 1) < 1e-14
+    # degenerate pair straddling chi_max is dropped whole (schmidt_utils.py:163-185)
+    e2 = 1 / (1 + np.exp(2 * np.array([1.0, 1.0, 3.0])))
+    sets, lam, q, _ = nat.cut_vectors(e2, 0, 2, 1e-6, 1e-12)
+    assert len(lam) == 1
+    with pytest.raises(NotImplementedError):
+        nat.cut_vectors(np.full(129, 0.5), 0, 4, 1e-6, 1e-12)
+
+
+def _device_layout(cut, side):
+    """V = [entangled | filled] as the HIP path stores it, from an oracle Cut."""
+    if side == "L":
+        v, nf, k = cut.vL, cut.nfL, cut.k
+        return np.concatenate((v[:, nf:nf + k], v[:, :nf]), axis=1), nf
+    v, nf, k = cut.vR, cut.nfR, cut.k
+    n0 = cut.nR - nf - k
+    return np.concatenate((v[:, n0:n0 + k], v[:, n0 + k:]), axis=1), nf
+
+
+def _masks(cut):
+    m = np.zeros((len(cut.sets), 2), np.uint64)
+    for i in range(cut.k):
+        m[:, i // 64] |= cut.sets[:, i].astype(np.uint64) << np.uint64(i % 64)
+    return m
+
+
+@pytest.mark.parametrize("name", ["rand_L16_s0_chi32", "rand_L24_s3_oc7_chi48", "chain_L16_chi32",
+                                  "chainPH_L8_chi64", "rand_L8_s0_chi8", "randSimple_L6_s4_chi32"])
+def test_site_prepare_matches_oracle(name):
+    g = load(name)
+    kw = {}
+    if "kw_ortho_center" in g:
+        kw["ortho_center"] = int(g["kw_ortho_center"])
+    if "kw_spinful" in g:
+        kw["spinful"] = str(g["kw_spinful"])
+    cuts, sites = orc.c_to_mps(g["C_in"], {"chi_max": int(g["chi_max"])}, **kw)
+    L, oc = int(g["L"]), int(g["ortho_center"])
+    for i in range(L):
+        s = sites[i]
+        mode = 0 if s.mode == "left" else 1
+        side = "L" if mode == 0 else "R"
+        bra, ket = (cuts[i], cuts[i + 1]) if mode == 0 else (cuts[i + 1], cuts[i])
+        Vb, nfb = _device_layout(bra, side)
+        Vk, nfk = _device_layout(ket, side)
+        qb = bra.n_filled("L") + bra.sets.sum(axis=1)
+        qk = ket.n_filled("L") + ket.sets.sum(axis=1)
+        r = nat.site_prepare(mode, bra.k, nfb, _masks(bra), qb, ket.k, nfk, _masks(ket), qk)
+        np.testing.assert_array_equal(r["bra_p"], s.bra_p)
+        np.testing.assert_array_equal(r["bra_alpha"], s.bra_alpha)
+        assert (r["sb"], r["sk"]) == s.M.shape
+        # W assembled from the selections reproduces det_always and the Schur complement
+        nb = Vb.shape[0]
+        Vk_sub = Vk[1:] if mode == 1 else Vk[:nb]
+        phys = Vk[0] if mode == 1 else Vk[nb]
+        Ofull = Vb.conj().T @ Vk_sub
+        W = np.zeros((r["mb"], r["mk"]), complex)
+        for a, (rs, sg) in enumerate(zip(r["row_sel"], r["row_sign"])):
+            row = phys[r["col_sel"]] if rs < 0 else Ofull[rs, r["col_sel"]]
+            W[a] = sg * row * r["col_sign"]
+        k = r["k"]
+        if k:
+            det = np.linalg.det(W[:k, :k])
+            M = W[k:, k:] - W[k:, :k] @ np.linalg.inv(W[:k, :k]) @ W[:k, k:]
+        else:
+            det, M = 1.0, W
+        np.testing.assert_allclose(det, s.det_always, rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(M, s.M, rtol=0, atol=1e-10)
+        # sectors and index lists
+        assert sorted(int(x) for x in r["sectors"]["q"]) == sorted(s.blocks)
+        for sec in r["sectors"]:
+            r0, r1, c0, c1, blk = s.blocks[int(sec["q"])]
+            assert (sec["r0"], sec["r1"], sec["c0"], sec["c1"]) == (r0, r1, c0, c1)
+            n = int(sec["n"])
+            bl = r["idx_pool"][sec["bra_off"]: sec["bra_off"] + (r1 - r0) * n].reshape(r1 - r0, n)
+            kl = r["idx_pool"][sec["ket_off"]: sec["ket_off"] + (c1 - c0) * n].reshape(c1 - c0, n)
+            np.testing.assert_array_equal(bl, np.nonzero(s.sets_bra[r0:r1])[1].reshape(r1 - r0, n))
+            np.testing.assert_array_equal(kl, np.nonzero(s.sets_ket[c0:c1])[1].reshape(c1 - c0, n))
