@@ -1,0 +1,502 @@
+"""Host driver of the MI355X Slater -> MPS sweep.
+
+The reference walks the chain site by site (slater.py:1300-1346) and calls LAPACK per cut.
+All L+1 cuts and all L sites are independent given C, so here every stage is ONE batched
+launch over all of them (descriptor arrays, variable sizes), with only two host
+round-trips: the entangled eigenvalues come back for the best-first enumeration
+(integer work, C++ on the host), and the index lists go up for the determinant stage.
+
+Per cut side (block A = C_LL or C_RR, off-diagonal block F = C_LR or C_RL), using that C is a
+projector (A - A^2 = F F^H, so entangled orbitals = left singular vectors of F with
+sigma^2 = e (1 - e) >= cutoff (1 - cutoff), the same set as slater.py:350):
+  E1  Y = F Omega                      MFMA GEMM     randomised range finder, p <= 64 columns
+  E2  Q = qr(Y)                        BCGS2: MFMA GEMM projections + LDS panel kernel
+  E3  B^H = F^H Q ; R = qr(B^H).R      GEMM + BCGS2 + GEMM
+  E4  R Z = U diag(sigma)              one-sided Jacobi in LDS (relative accuracy near 1e-6)
+  E5  U0 = Q Z[:, sigma^2 >= thr]      GEMM
+  E6  T = U0^H A U0 ; T X = X diag(e)  2 GEMMs + Jacobi   (Rayleigh-Ritz: eigenpairs of A)
+  E7  U_E = U0 X                       GEMM
+  F   filled basis: orthonormalise (1 - U_E U_E^H) A A Omega_f  (2 GEMMs + BCGS2 against U_E)
+Per site:
+  S1  O = V_bra^H V_ket                MFMA GEMM  (slater.py:1071)
+  S2  W = signed gather of O           [always block | sometimes], physical orbital row
+  S3  det_always, Schur complement     blocked LU in LDS panels (slater.py:1077-1090)
+  S4  all minors of all sectors        gathered-determinant kernel (slater.py:828-869)
+"""
+from __future__ import annotations
+
+import logging
+import os
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import _native as nat
+from .mps_data import BondData, MPSData, SiteData
+
+logger = logging.getLogger("temfpy_amd.slater")
+
+P_RANGE = 64     # columns of the range finder = LDS limit of the Jacobi kernel (complex128)
+PANEL_W = 16
+
+
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
+class Engine:
+    def __init__(self, device="cuda:0", profile=None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise nat.NativeError("temfpy_amd needs a HIP device (torch.cuda.is_available() is False); "
+                                  "there is no CPU fallback")
+        self.torch = torch
+        self.device = torch.device(device)
+        self.lib = nat.load()
+        self.profile = bool(int(os.environ.get("TMF_PROFILE", "0"))) if profile is None else profile
+        self.timings = {}
+        self._keep = []  # descriptor tensors must outlive the launches that read them
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def _up(self, a: np.ndarray):
+        t = self.torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(self.device, non_blocking=False)
+        self._keep.append(t)
+        return t
+
+    def _alloc(self, count, real=False, zero=False):
+        dt = self.torch.float64 if (real or self.dtype == nat.TMF_F64) else self.torch.complex128
+        f = self.torch.zeros if zero else self.torch.empty
+        return f(max(int(count), 1), dtype=dt, device=self.device)
+
+    def _tick(self, name, t0):
+        if self.profile:
+            self.torch.cuda.synchronize(self.device)
+        self.timings[name] = self.timings.get(name, 0.0) + time.perf_counter() - t0
+
+    # ------------------------------------------------------------------ batched ops
+    def gemm(self, opA, alpha, beta, A, B, C, M, N, K, lda, ldb, ldc):
+        """Batched C = alpha op(A) B + beta C over arrays of problems (device addresses)."""
+        M, N, K = (np.asarray(x, np.int64) for x in (M, N, K))
+        sel = np.nonzero((M > 0) & (N > 0))[0]
+        if sel.size == 0:
+            return
+        d = np.zeros(sel.size, nat.gemm_desc)
+        for f, v in (("A", A), ("B", B), ("C", C), ("M", M), ("N", N), ("K", K), ("lda", lda), ("ldb", ldb), ("ldc", ldc)):
+            d[f] = np.broadcast_to(np.asarray(v), M.shape)[sel]
+        d["lda"] = np.maximum(d["lda"], 1)
+        d["ldb"] = np.maximum(d["ldb"], 1)
+        tn = 16 if int(d["N"].max()) <= 16 else 64
+        tm = _cdiv(d["M"].astype(np.int64), 64)
+        tnn = _cdiv(d["N"].astype(np.int64), tn)
+        cnt = tm * tnn
+        total = int(cnt.sum())
+        prob = np.repeat(np.arange(sel.size), cnt)
+        local = np.arange(total) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        tiles = np.zeros((total, 4), np.int32)
+        tiles[:, 0] = prob
+        tiles[:, 1] = local % tm[prob]
+        tiles[:, 2] = local // tm[prob]
+        order = np.argsort(-d["K"][prob].astype(np.int64), kind="stable")  # longest tiles first
+        tiles = tiles[order]
+        dd, dt = self._up(d), self._up(tiles)
+        nat.check(self.lib.tmf_gemm_batched(self.dtype, opA, float(alpha), float(beta), dd.data_ptr(), dt.data_ptr(),
+                                            total, tn, self.stream), "tmf_gemm_batched")
+
+    def bcgs2(self, base, rows, ld, c_begin, c_end, scratch_ptr):
+        """Orthonormalise columns [c_begin, c_end) of every matrix against all columns before
+        them (blocked classical Gram-Schmidt, two passes), panels of width w."""
+        base, rows, ld, c_begin, c_end = (np.asarray(x, np.int64) for x in (base, rows, ld, c_begin, c_end))
+        if base.size == 0:
+            return
+        max_rows = int(rows.max())
+        w = PANEL_W
+        while max_rows * w * self.elem + 1024 > 150 * 1024 and w > 1:
+            w //= 2
+        span = c_end - c_begin
+        for t in range(0, int(span.max()), w):
+            act = np.nonzero((span > t) & (rows > 0))[0]
+            if act.size == 0:
+                break
+            j = c_begin[act] + t
+            wj = np.minimum(w, c_end[act] - j)
+            colp = base[act] + j * ld[act] * self.elem
+            for _ in range(2):
+                self.gemm(1, 1.0, 0.0, base[act], colp, scratch_ptr[act], j, wj, rows[act], ld[act], ld[act],
+                          np.maximum(j, 1))
+                self.gemm(0, -1.0, 1.0, base[act], scratch_ptr[act], colp, rows[act], wj, j, ld[act],
+                          np.maximum(j, 1), ld[act])
+            d = np.zeros(act.size, nat.panel_desc)
+            d["A"], d["n"], d["w"], d["lda"] = colp, rows[act], wj, ld[act]
+            dd = self._up(d)
+            nat.check(self.lib.tmf_orth_panel_batched(self.dtype, dd.data_ptr(), act.size, max_rows, w, self.stream),
+                      "tmf_orth_panel_batched")
+
+    def jacobi(self, X, V, s, count, thresh2, p, ldx, ldv):
+        p = np.asarray(p, np.int64)
+        sel = np.nonzero(p > 0)[0]
+        if sel.size == 0:
+            return
+        d = np.zeros(sel.size, nat.jacobi_desc)
+        for f, v in (("X", X), ("V", V), ("s", s), ("count", count), ("p", p), ("ldx", ldx), ("ldv", ldv)):
+            d[f] = np.broadcast_to(np.asarray(v), p.shape)[sel]
+        d["thresh2"] = thresh2
+        d["ldu"] = 1
+        dd = self._up(d)
+        nat.check(self.lib.tmf_jacobi_batched(self.dtype, dd.data_ptr(), sel.size, int(p.max()), None, self.stream),
+                  "tmf_jacobi_batched")
+
+    def colcopy(self, src, dst, n, c, lds_, ldd, reverse=0, flip_odd=0):
+        n, c = np.asarray(n, np.int64), np.asarray(c, np.int64)
+        sel = np.nonzero((n > 0) & (c > 0))[0]
+        if sel.size == 0:
+            return
+        d = np.zeros(sel.size, nat.colnorm_desc)
+        for f, v in (("src", src), ("dst", dst), ("n", n), ("c", c), ("lds_", lds_), ("ldd", ldd)):
+            d[f] = np.broadcast_to(np.asarray(v), n.shape)[sel]
+        d["reverse"], d["flip_odd"] = reverse, flip_odd
+        dd = self._up(d)
+        nat.check(self.lib.tmf_normalise_columns_batched(self.dtype, dd.data_ptr(), sel.size, self.stream),
+                  "tmf_normalise_columns_batched")
+
+    # ------------------------------------------------------------------ the sweep
+    def run(self, C, trunc, ortho_center, unit_cell_width, threads=None):
+        torch = self.torch
+        t_all = time.perf_counter()
+        self.timings = {}
+        C = np.asarray(C)
+        cplx = np.iscomplexobj(C)
+        self.dtype = nat.TMF_C128 if cplx else nat.TMF_F64
+        self.elem = 16 if cplx else 8
+        npdt = np.complex128 if cplx else np.float64
+        C = np.ascontiguousarray(C, npdt)
+        L = len(C)
+        oc = ortho_center
+        el = self.elem
+        cutoff = trunc.svd_min**2  # slater.py:318
+        thr2 = cutoff * (1.0 - cutoff)
+        threads = threads or min(16, os.cpu_count() or 1)
+
+        t0 = time.perf_counter()
+        d_Crm = torch.from_numpy(C.reshape(-1)).to(self.device)
+        d_C = self._alloc(L * L)
+        nat.check(self.lib.tmf_transpose(self.dtype, d_Crm.data_ptr(), d_C.data_ptr(), L, self.stream), "tmf_transpose")
+        Cp = d_C.data_ptr()
+        P = P_RANGE
+        d_Om = self._alloc(L * P)
+        nat.check(self.lib.tmf_fill_normal(self.dtype, d_Om.data_ptr(), L * P, 0x5EED1, self.stream), "fill")
+        self._tick("upload", t0)
+
+        # ---- cut-side problems --------------------------------------------------------------
+        cs_b, cs_side = [], []
+        for b in range(L + 1):
+            if b <= oc:
+                cs_b.append(b), cs_side.append(0)
+            if b >= oc:
+                cs_b.append(b), cs_side.append(1)
+        cs_b, cs_side = np.array(cs_b), np.array(cs_side)
+        ncs = len(cs_b)
+        n = np.where(cs_side == 0, cs_b, L - cs_b)
+        m = L - n
+        blk = Cp + np.where(cs_side == 0, 0, (cs_b + cs_b * L)) * el      # A = C_LL or C_RR
+        off = Cp + np.where(cs_side == 0, cs_b * L, cs_b) * el            # F (n x m)
+        omp = d_Om.data_ptr() + np.where(cs_side == 0, cs_b, 0) * el      # rows of Omega on the other side
+        centre_R = np.nonzero((cs_b == oc) & (cs_side == 1))[0][0]
+        centre_L = np.nonzero((cs_b == oc) & (cs_side == 0))[0][0]
+        # the right side of the centre cut is paired with the left side through C_RL (block_svd, slater.py:407)
+        doE = (n > 0) & (m > 0)
+        doE[centre_R] = False
+        p = np.where(doE, np.minimum(P, np.minimum(n, m)), 0)
+
+        def offsets(sizes):
+            o = np.concatenate(([0], np.cumsum(sizes)))
+            return o[:-1], int(o[-1])
+
+        t0 = time.perf_counter()
+        oY, tY = offsets(n * p)
+        oB, tB = offsets(m * p)
+        oR, tR = offsets(p * p)
+        oS, tS = offsets(p)
+        d_Y, d_U0, d_W1 = self._alloc(tY), self._alloc(tY), self._alloc(tY)
+        d_Bt, d_Q2 = self._alloc(tB), self._alloc(tB)
+        d_R, d_Z, d_T, d_X = self._alloc(tR), self._alloc(tR), self._alloc(tR), self._alloc(tR)
+        d_sig = self._alloc(tS, real=True, zero=True)
+        d_e = self._alloc(tS, real=True, zero=True)
+        d_cnt = torch.zeros(ncs, dtype=torch.int32, device=self.device)
+        d_scr = self._alloc(ncs * P * PANEL_W)
+        Yp, U0p, W1p = (t.data_ptr() + oY * el for t in (d_Y, d_U0, d_W1))
+        Btp, Q2p = (t.data_ptr() + oB * el for t in (d_Bt, d_Q2))
+        Rp, Zp, Tp, Xp = (t.data_ptr() + oR * el for t in (d_R, d_Z, d_T, d_X))
+        sigp, ep = d_sig.data_ptr() + oS * 8, d_e.data_ptr() + oS * 8
+        cntp = d_cnt.data_ptr() + np.arange(ncs) * 4
+        scrp = d_scr.data_ptr() + np.arange(ncs) * P * PANEL_W * el
+        zero = np.zeros(ncs, np.int64)
+        ld1 = np.maximum(n, 1)
+
+        # E1: Y = F Omega
+        self.gemm(0, 1.0, 0.0, off, omp, Yp, n, p, m, L, L, ld1)
+        # E2: Q = qr(Y)
+        self.bcgs2(Yp[doE], n[doE], n[doE], zero[doE], p[doE], scrp[doE])
+        # E3: B^H = F^H Q  (m x p), R = Q2^H B^H
+        self.gemm(1, 1.0, 0.0, off, Yp, Btp, m, p, n, L, ld1, np.maximum(m, 1))
+        torch.cuda.current_stream(self.device)  # (same stream; copy below is stream-ordered)
+        d_Q2.copy_(d_Bt)
+        self.bcgs2(Q2p[doE], m[doE], m[doE], zero[doE], p[doE], scrp[doE])
+        self.gemm(1, 1.0, 0.0, Q2p, Btp, Rp, p, p, m, np.maximum(m, 1), np.maximum(m, 1), np.maximum(p, 1))
+        # E4: Jacobi SVD of R: right singular vectors Z, sigma; columns below the threshold zeroed
+        self.jacobi(Rp, Zp, sigp, cntp, thr2, p, np.maximum(p, 1), np.maximum(p, 1))
+        # E5: U0 = Q Z
+        self.gemm(0, 1.0, 0.0, Yp, Zp, U0p, n, p, p, ld1, np.maximum(p, 1), ld1)
+        # E6: T = U0^H (A U0), Jacobi eigen-decomposition
+        self.gemm(0, 1.0, 0.0, blk, U0p, W1p, n, p, n, L, ld1, ld1)
+        self.gemm(1, 1.0, 0.0, U0p, W1p, Tp, p, p, n, ld1, ld1, np.maximum(p, 1))
+        self.jacobi(Tp, Xp, ep, 0, 0.0, p, np.maximum(p, 1), np.maximum(p, 1))
+        # E7: U_E = U0 X  (reuses the Y buffer; Q is no longer needed)
+        self.gemm(0, 1.0, 0.0, U0p, Xp, Yp, n, p, p, ld1, np.maximum(p, 1), ld1)
+        UEp = Yp
+        self._tick("E_entangled", t0)
+
+        # ---- host round trip 1: eigenvalues -> classification, filled counts ------------------
+        t0 = time.perf_counter()
+        h_e = d_e.cpu().numpy()
+        h_cnt = d_cnt.cpu().numpy()
+        diag = np.real(np.diagonal(C)).copy()
+        csum = np.concatenate(([0.0], np.cumsum(diag)))
+        n_fermion = int(np.round(csum[-1]))  # slater.py:414
+        tr = np.where(cs_side == 0, csum[cs_b], csum[-1] - csum[cs_b])
+        k = np.zeros(ncs, np.int64)
+        ent0 = np.zeros(ncs, np.int64)  # first entangled column inside U_E
+        e_side = [np.zeros(0)] * ncs
+        for i in range(ncs):
+            if not doE[i]:
+                continue
+            if h_cnt[i] >= p[i] and p[i] == P and P < min(n[i], m[i]):
+                raise NotImplementedError(
+                    f"cut {cs_b[i]}: more than {P - 1} orbitals above the range-finder threshold; "
+                    f"entanglement rank beyond the compiled limit of the LDS Jacobi kernel")
+            ev = h_e[oS[i]: oS[i] + h_cnt[i]]
+            x_hi = int(np.sum(ev >= 1 - cutoff))          # kept but 'filled' by slater.py:350
+            x_lo = int(np.sum(ev < cutoff))
+            ent0[i] = x_hi
+            k[i] = len(ev) - x_hi - x_lo
+            e_side[i] = ev[x_hi: x_hi + k[i]].copy()
+        # centre: right-side eigenvalues are 1 - e_L reversed (slater.py:386 convention)
+        k[centre_R] = k[centre_L]
+        e_side[centre_R] = (1.0 - e_side[centre_L])[::-1].copy()
+        nf = np.array([int(np.round(tr[i] - e_side[i].sum())) for i in range(ncs)])
+        nf = np.clip(nf, 0, n - k)
+        self._tick("host_classify", t0)
+
+        # ---- F: orbital matrices V = [U_E (k) | Q_f (nf)] -------------------------------------
+        t0 = time.perf_counter()
+        ncolV = k + nf
+        oV, tV = offsets(n * ncolV)
+        d_V = self._alloc(tV)
+        Vp = d_V.data_ptr() + oV * el
+        # entangled columns (renormalised copy); centre-right: C_RL U_E(left), reversed, odd columns flipped
+        cp = doE.copy()
+        self.colcopy((UEp + ent0 * ld1 * el)[cp], Vp[cp], n[cp], k[cp], ld1[cp], ld1[cp])
+        if k[centre_L] > 0 and n[centre_R] > 0:
+            d_pair = self._alloc(n[centre_R] * k[centre_L])
+            self.gemm(0, 1.0, 0.0, [off[centre_R]], [Vp[centre_L]], [d_pair.data_ptr()], [n[centre_R]], [k[centre_L]],
+                      [m[centre_R]], [L], [ld1[centre_L]], [ld1[centre_R]])
+            self.colcopy([d_pair.data_ptr()], [Vp[centre_R]], [n[centre_R]], [k[centre_R]], [ld1[centre_R]],
+                         [ld1[centre_R]], reverse=1, flip_odd=1)
+        # filled: Y2 = A (A Omega_f)
+        maxnf = int(nf.max()) if ncs else 0
+        if maxnf > 0:
+            d_OmF = self._alloc(L * maxnf)
+            nat.check(self.lib.tmf_fill_normal(self.dtype, d_OmF.data_ptr(), L * maxnf, 0xF111ED, self.stream), "fill")
+            oY1, tY1 = offsets(n * nf)
+            d_Y1 = self._alloc(tY1)
+            Y1p = d_Y1.data_ptr() + oY1 * el
+            Vf = Vp + k * ld1 * el
+            self.gemm(0, 1.0, 0.0, blk, d_OmF.data_ptr(), Y1p, n, nf, n, L, L, ld1)
+            self.gemm(0, 1.0, 0.0, blk, Y1p, Vf, n, nf, n, L, ld1, ld1)
+            d_scr2 = self._alloc(int((ncolV.max() + 1) * PANEL_W) * ncs)
+            scr2 = d_scr2.data_ptr() + np.arange(ncs) * int((ncolV.max() + 1) * PANEL_W) * el
+            has = nf > 0
+            self.bcgs2(Vp[has], n[has], ld1[has], k[has], ncolV[has], scr2[has])
+        self._tick("F_filled", t0)
+
+        # ---- host: best-first enumeration for every cut (C++, threaded) ------------------------
+        t0 = time.perf_counter()
+        sectors = _sector_list(trunc, L)
+        cut_idx = {}
+        for i in range(ncs):
+            cut_idx[(int(cs_b[i]), int(cs_side[i]))] = i
+        e_left, nfl, nfr = [None] * (L + 1), [0] * (L + 1), [0] * (L + 1)
+        for b in range(L + 1):
+            iL, iR = cut_idx.get((b, 0)), cut_idx.get((b, 1))
+            if iL is not None:
+                e_left[b] = e_side[iL]
+                nfl[b] = int(nf[iL])
+                nfr[b] = int(nf[iR]) if iR is not None else n_fermion - len(e_left[b]) - nfl[b]  # slater.py:167
+            else:
+                e_left[b] = (1.0 - e_side[iR])[::-1].copy()  # slater.py:386
+                nfr[b] = int(nf[iR])
+                nfl[b] = n_fermion - len(e_left[b]) - nfr[b]  # slater.py:172
+
+        def enum(b):
+            return nat.cut_vectors(e_left[b], nfl[b], trunc.chi_max or 0, trunc.svd_min, trunc.degeneracy_tol, sectors)
+
+        with ThreadPoolExecutor(threads) as ex:
+            enum_out = list(ex.map(enum, range(L + 1)))
+        bonds = []
+        for b in range(L + 1):
+            sets, lam_raw, q, nchk = enum_out[b]
+            if len(lam_raw) == 0:
+                raise ValueError("No Schmidt vectors left after filtering by `trunc_par.sectors`!")  # slater.py:668
+            kk = len(e_left[b])
+            sb_ = np.zeros((len(sets), kk), bool)
+            for i in range(kk):
+                sb_[:, i] = (sets[:, i // 64] >> np.uint64(i % 64)) & np.uint64(1)
+            nrm = np.linalg.norm(lam_raw)
+            logger.info("bond %d: %d Schmidt modes, checked %d subsets, kept %d, norm %.12g", b, kk, nchk,
+                        len(lam_raw), nrm)
+            bd = BondData(x=b, e=e_left[b], n_filled_left=nfl[b], n_filled_right=nfr[b], sets=sb_, lam_raw=lam_raw,
+                          lam=lam_raw / nrm, q_left=q, n_checked=nchk)
+            bd._masks = sets
+            bonds.append(bd)
+        self._tick("host_enumerate", t0)
+
+        # ---- host: per-site integer preparation -------------------------------------------------
+        t0 = time.perf_counter()
+
+        def prep(i):
+            mode = 0 if i < oc else 1
+            bb, kb = (i, i + 1) if mode == 0 else (i + 1, i)
+            ib, ik = cut_idx[(bb, mode)], cut_idx[(kb, mode)]
+            B, K = bonds[bb], bonds[kb]
+            r = nat.site_prepare(mode, int(k[ib]), int(nf[ib]), B._masks, B.q_left, int(k[ik]), int(nf[ik]), K._masks,
+                                 K.q_left)
+            r["ib"], r["ik"], r["mode"] = ib, ik, mode
+            return r
+
+        with ThreadPoolExecutor(threads) as ex:
+            prep_out = list(ex.map(prep, range(L)))
+        self._tick("host_site_prepare", t0)
+
+        # ---- S1/S2: overlaps and W assembly ---------------------------------------------------
+        t0 = time.perf_counter()
+        ib = np.array([r["ib"] for r in prep_out])
+        ik = np.array([r["ik"] for r in prep_out])
+        mode = np.array([r["mode"] for r in prep_out])
+        mb = np.array([r["mb"] for r in prep_out])
+        mk = np.array([r["mk"] for r in prep_out])
+        ka = np.array([r["k"] for r in prep_out])
+        sbv = np.array([r["sb"] for r in prep_out])
+        skv = np.array([r["sk"] for r in prep_out])
+        if int((sbv * skv).max()) * el > 64 * 1024:
+            raise NotImplementedError("sometimes-matrix larger than the 64 KiB LDS stage of the determinant kernel")
+        cb, ck = ncolV[ib], ncolV[ik]           # columns of V_bra / V_ket
+        nb_rows = n[ib]                          # contraction length = bra orbitals
+        oO, tO = offsets(cb * ck)
+        oW, tW = offsets(mb * mk)
+        d_O, d_W = self._alloc(tO), self._alloc(tW)
+        d_det = self._alloc(L)
+        Op, Wp = d_O.data_ptr() + oO * el, d_W.data_ptr() + oW * el
+        detp = d_det.data_ptr() + np.arange(L) * el
+        Vk_sub = Vp[ik] + np.where(mode == 1, 1, 0) * el     # right mode: physical orbital is row 0 of the ket block
+        physp = Vp[ik] + np.where(mode == 1, 0, nb_rows) * el
+        self.gemm(1, 1.0, 0.0, Vp[ib], Vk_sub, Op, cb, ck, nb_rows, ld1[ib], ld1[ik], np.maximum(cb, 1))
+        # selection arrays
+        rs_off, rs_tot = offsets(mb)
+        cs_off, cs_tot = offsets(mk)
+        row_sel = np.concatenate([r["row_sel"] for r in prep_out]).astype(np.int32)
+        col_sel = np.concatenate([r["col_sel"] for r in prep_out]).astype(np.int32)
+        row_sign = np.concatenate([r["row_sign"] for r in prep_out]).astype(np.int8)
+        col_sign = np.concatenate([r["col_sign"] for r in prep_out]).astype(np.int8)
+        t_rs, t_cs, t_rg, t_cg = self._up(row_sel), self._up(col_sel), self._up(row_sign), self._up(col_sign)
+        gd = np.zeros(L, nat.gather_desc)
+        gd["src"], gd["dst"] = Op, Wp
+        gd["row_sel"], gd["col_sel"] = t_rs.data_ptr() + rs_off * 4, t_cs.data_ptr() + cs_off * 4
+        gd["row_sign"], gd["col_sign"] = t_rg.data_ptr() + rs_off, t_cg.data_ptr() + cs_off
+        gd["phys"] = physp
+        gd["rows"], gd["cols"] = mb, mk
+        gd["lds_"], gd["ldd"], gd["ldp"] = np.maximum(cb, 1), np.maximum(mb, 1), ld1[ik]
+        t_gd = self._up(gd)
+        nat.check(self.lib.tmf_gather_signed_batched(self.dtype, t_gd.data_ptr(), L, self.stream), "gather")
+        # S3: det_always + Schur complement
+        sd = np.zeros(L, nat.schur_desc)
+        sd["W"], sd["S"], sd["det"] = Wp, 0, detp
+        sd["mb"], sd["mk"], sd["k"], sd["ldw"], sd["lds"] = mb, mk, ka, np.maximum(mb, 1), 1
+        t_sd = self._up(sd)
+        nat.check(self.lib.tmf_lu_schur_batched(self.dtype, t_sd.data_ptr(), L, int(mb.max()), self.stream), "lu_schur")
+        self._tick("S_overlap_schur", t0)
+
+        # ---- S4: all minors ----------------------------------------------------------------------
+        t0 = time.perf_counter()
+        out_off, out_tot = offsets(np.array([r["out_elems"] for r in prep_out]))
+        pool_off, pool_tot = offsets(np.array([len(r["idx_pool"]) for r in prep_out]))
+        pool = np.concatenate([r["idx_pool"] for r in prep_out]) if pool_tot else np.zeros(1, np.uint8)
+        t_pool = self._up(pool)
+        d_out = self._alloc(out_tot)
+        Sp = Wp + (ka + ka * np.maximum(mb, 1)) * el
+        tiles = {8: [], 16: [], 32: [], 64: []}
+        lds_need = {8: 0, 16: 0, 32: 0, 64: 0}
+        a16 = lambda x: (x + 15) & ~15  # noqa: E731
+        for i, r in enumerate(prep_out):
+            for sec in r["sectors"]:
+                nq = int(sec["n"])
+                cls = 8 if nq <= 8 else 16 if nq <= 16 else 32 if nq <= 32 else 64
+                nsb, nsk = int(sec["r1"] - sec["r0"]), int(sec["c1"] - sec["c0"])
+                ta = max(1, min(nsb, _cdiv(4096, nsk)))
+                base = (Sp[i], detp[i], t_pool.data_ptr() + pool_off[i] + int(sec["bra_off"]),
+                        t_pool.data_ptr() + pool_off[i] + int(sec["ket_off"]),
+                        d_out.data_ptr() + (out_off[i] + int(sec["out_off"])) * el, int(sbv[i]), int(skv[i]),
+                        int(max(mb[i], 1)), nq, nsb, nsk)
+                need = a16(int(sbv[i]) * int(skv[i]) * el) + a16(nsk * nq) + a16(ta * nq) + (nq * nq * el if cls == 64 else 0)
+                lds_need[cls] = max(lds_need[cls], need)
+                for a0 in range(0, nsb, ta):
+                    tiles[cls].append(base + (a0, min(nsb, a0 + ta)))
+        n_det = 0
+        for cls, tl in tiles.items():
+            if not tl:
+                continue
+            dd = np.zeros(len(tl), nat.det_desc)
+            arr = np.array(tl, dtype=np.int64)
+            for j, f in enumerate(("S", "scale", "bra_idx", "ket_idx", "out", "sb", "sk", "lds", "n", "nsb", "nsk", "a0", "a1")):
+                dd[f] = arr[:, j]
+            n_det += int(((dd["a1"] - dd["a0"]).astype(np.int64) * dd["nsk"]).sum())
+            # biggest tiles first
+            dd = dd[np.argsort(-((dd["a1"] - dd["a0"]).astype(np.int64) * dd["nsk"] * (dd["n"].astype(np.int64) + 1) ** 2), kind="stable")]
+            t_dd = self._up(dd)
+            nat.check(self.lib.tmf_det_gather_batched(self.dtype, cls, t_dd.data_ptr(), len(tl), int(lds_need[cls]) + 16,
+                                                      self.stream), "tmf_det_gather_batched")
+        self.n_det = n_det
+        self._tick("S_determinants", t0)
+        self.d_out = d_out  # device-resident result
+
+        # ---- host round trip 2: tensors back -----------------------------------------------------
+        t0 = time.perf_counter()
+        h_out = d_out.cpu().numpy()
+        h_det = d_det.cpu().numpy()
+        sites = []
+        for i, r in enumerate(prep_out):
+            m_ = "left" if r["mode"] == 0 else "right"
+            bb, kb = (i, i + 1) if r["mode"] == 0 else (i + 1, i)
+            blocks = []
+            for sec in r["sectors"]:
+                r0, r1, c0, c1 = (int(sec[f]) for f in ("r0", "r1", "c0", "c1"))
+                o = out_off[i] + int(sec["out_off"])
+                blocks.append((int(sec["q"]), r0, r1, c0, c1, h_out[o: o + (r1 - r0) * (c1 - c0)].reshape(r1 - r0, c1 - c0)))
+            sites.append(SiteData(mode=m_, det_always=h_det[i], qtotal=0, bra_p=r["bra_p"], bra_alpha=r["bra_alpha"],
+                                  blocks=blocks, chi_bra=bonds[bb].chi, chi_ket=bonds[kb].chi))
+        self._tick("download", t0)
+        self.timings["total"] = time.perf_counter() - t_all
+        self._keep.clear()
+        return MPSData(bonds, sites, oc, unit_cell_width, dict(self.timings))
+
+
+def _sector_list(trunc, L):
+    """StoppingCondition.sectors (schmidt_utils.py:67-77) as an explicit list of allowed charges."""
+    s = trunc.sectors
+    if s is None:
+        return None
+    return [q for q in range(0, 2 * L + 2) if trunc.is_sector(q)]

@@ -1,0 +1,289 @@
+"""GPU parity tests of every device entry point of the C ABI against NumPy (fp64).
+Tolerances are stated per test; everything is called through libtemfpy_hip.so."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from temfpy_amd import _native as nat
+    from temfpy_amd.engine import Engine
+
+    e = Engine("cuda:0")
+    e.nat = nat
+    return e
+
+
+def setup(eng, cplx):
+    eng.dtype = eng.nat.TMF_C128 if cplx else eng.nat.TMF_F64
+    eng.elem = 16 if cplx else 8
+    eng._keep.clear()
+
+
+def rnd(rng, shape, cplx):
+    a = rng.standard_normal(shape)
+    return a + 1j * rng.standard_normal(shape) if cplx else a
+
+
+def dev(eng, a):
+    """column-major upload; returns (tensor, ptr)"""
+    t = torch.from_numpy(np.asfortranarray(a).T.copy().reshape(-1)).to("cuda:0")
+    return t, t.data_ptr()
+
+
+def back(t, shape):
+    return t.cpu().numpy().reshape(shape[::-1]).T
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("opA", [0, 1])
+def test_gemm_batched(eng, cplx, opA):
+    setup(eng, cplx)
+    rng = np.random.default_rng(1)
+    shapes = [(1, 1, 1), (64, 64, 16), (65, 17, 33), (130, 64, 257), (200, 16, 70), (33, 3, 5), (512, 70, 300), (7, 100, 0)]
+    for only16 in (False, True):
+        As, Bs, Cs, keep = [], [], [], []
+        sh = [(M, min(N, 16) if only16 else N, K) for M, N, K in shapes]
+        for M, N, K in sh:
+            A = rnd(rng, (K, M) if opA else (M, K), cplx)
+            B = rnd(rng, (K, N), cplx)
+            C0 = rnd(rng, (M, N), cplx)
+            As.append(A), Bs.append(B), Cs.append(C0)
+        for alpha, beta in ((1.0, 0.0), (-1.0, 1.0)):
+            dA = [dev(eng, a) for a in As]
+            dB = [dev(eng, b) for b in Bs]
+            dC = [dev(eng, c) for c in Cs]
+            eng.gemm(opA, alpha, beta, [x[1] for x in dA], [x[1] for x in dB], [x[1] for x in dC],
+                     [s[0] for s in sh], [s[1] for s in sh], [s[2] for s in sh],
+                     [max(a.shape[0], 1) for a in As], [max(b.shape[0], 1) for b in Bs], [s[0] for s in sh])
+            torch.cuda.synchronize()
+            for (M, N, K), A, B, C0, dc in zip(sh, As, Bs, Cs, dC):
+                ref = alpha * ((A.conj().T if opA else A) @ B) + beta * C0
+                got = back(dc[0], (M, N))
+                np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * max(1, K))
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_bcgs2_orthonormalises_and_keeps_span(eng, cplx):
+    setup(eng, cplx)
+    rng = np.random.default_rng(2)
+    cases = [(40, 0, 40), (300, 0, 64), (513, 5, 70), (100, 10, 11), (1000, 0, 33), (17, 0, 1)]
+    mats, dm = [], []
+    for n, c0, c1 in cases:
+        A = rnd(rng, (n, c1), cplx)
+        if c0:
+            A[:, :c0] = np.linalg.qr(A[:, :c0])[0]
+        mats.append(A)
+        dm.append(dev(eng, A))
+    scr = eng._alloc(len(cases) * 80 * 16)
+    eng.bcgs2([d[1] for d in dm], [c[0] for c in cases], [c[0] for c in cases], [c[1] for c in cases],
+              [c[2] for c in cases], scr.data_ptr() + np.arange(len(cases)) * 80 * 16 * eng.elem)
+    torch.cuda.synchronize()
+    for (n, c0, c1), A, d in zip(cases, mats, dm):
+        Q = back(d[0], (n, c1))
+        np.testing.assert_allclose(Q.conj().T @ Q, np.eye(c1), rtol=0, atol=5e-14)
+        # same column space: projector onto span(A) equals Q Q^H
+        Qa = np.linalg.qr(A)[0]
+        np.testing.assert_allclose(Q @ Q.conj().T, Qa @ Qa.conj().T, rtol=0, atol=1e-11)
+        if c0:
+            np.testing.assert_allclose(Q[:, :c0], A[:, :c0], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_bcgs2_exactly_rank_deficient_gives_zero_columns(eng, cplx):
+    setup(eng, cplx)
+    rng = np.random.default_rng(3)
+    A = np.zeros((50, 8), complex if cplx else float)
+    A[:, :3] = rnd(rng, (50, 3), cplx)
+    d = dev(eng, A)
+    scr = eng._alloc(8 * 16)
+    eng.bcgs2([d[1]], [50], [50], [0], [8], np.array([scr.data_ptr()]))
+    torch.cuda.synchronize()
+    Q = back(d[0], (50, 8))
+    G = Q.conj().T @ Q
+    np.testing.assert_allclose(G[:3, :3], np.eye(3), atol=1e-14)
+    assert np.all(Q[:, 3:] == 0)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_jacobi_svd_and_threshold(eng, cplx):
+    setup(eng, cplx)
+    rng = np.random.default_rng(4)
+    ps = [1, 2, 3, 17, 32, 64]
+    Xs = []
+    for p in ps:
+        X = rnd(rng, (p, p), cplx)
+        if p >= 17:  # column-graded: singular values down to 1e-9
+            X = np.linalg.qr(X)[0] * np.logspace(0, -9, p) @ np.linalg.qr(rnd(rng, (p, p), cplx))[0]
+        Xs.append(X)
+    dX = [dev(eng, x) for x in Xs]
+    dV = [dev(eng, np.zeros_like(x)) for x in Xs]
+    ds = [torch.zeros(p, dtype=torch.float64, device="cuda:0") for p in ps]
+    dc = torch.zeros(len(ps), dtype=torch.int32, device="cuda:0")
+    thr2 = 1e-12
+    eng.jacobi([d[1] for d in dX], [d[1] for d in dV], [s.data_ptr() for s in ds],
+               dc.data_ptr() + 4 * np.arange(len(ps)), thr2, ps, ps, ps)
+    torch.cuda.synchronize()
+    cnt = dc.cpu().numpy()
+    for p, X, dv, s_, c in zip(ps, Xs, dV, ds, cnt):
+        V = back(dv[0], (p, p))
+        s = s_.cpu().numpy()
+        sref = np.linalg.svd(X, compute_uv=False)
+        np.testing.assert_allclose(s, sref, rtol=1e-10, atol=1e-15)  # relative accuracy on graded spectra
+        assert c == np.sum(sref**2 >= thr2)
+        Vk = V[:, :c]
+        np.testing.assert_allclose(Vk.conj().T @ Vk, np.eye(c), atol=1e-13)
+        assert np.all(V[:, c:] == 0)
+        XV = X @ Vk
+        np.testing.assert_allclose(np.linalg.norm(XV, axis=0), s[:c], rtol=1e-10)
+        G = XV.conj().T @ XV
+        off = G - np.diag(np.diag(G))
+        assert np.abs(off).max() <= 1e-13 * s[0] ** 2
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_jacobi_hermitian_eigenproblem(eng, cplx):
+    setup(eng, cplx)
+    rng = np.random.default_rng(5)
+    p = 40
+    U = np.linalg.qr(rnd(rng, (p, p), cplx))[0]
+    e = np.sort(np.concatenate((1 - np.logspace(-12, -1, 15), np.logspace(-12, -1, 15), rng.uniform(0.2, 0.8, 10))))[::-1]
+    T = (U * e) @ U.conj().T
+    dX, dV = dev(eng, T), dev(eng, np.zeros_like(T))
+    ds = torch.zeros(p, dtype=torch.float64, device="cuda:0")
+    eng.jacobi([dX[1]], [dV[1]], [ds.data_ptr()], 0, 0.0, [p], [p], [p])
+    torch.cuda.synchronize()
+    V, s = back(dV[0], (p, p)), ds.cpu().numpy()
+    np.testing.assert_allclose(s, e, rtol=0, atol=2e-15)
+    np.testing.assert_allclose(V.conj().T @ V, np.eye(p), atol=1e-13)
+    np.testing.assert_allclose(T @ V, V * s, atol=5e-15)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_lu_schur(eng, cplx):
+    setup(eng, cplx)
+    nat = eng.nat
+    rng = np.random.default_rng(6)
+    cases = [(5, 4, 0), (1, 3, 1), (20, 23, 7), (70, 66, 40), (300, 290, 257), (33, 33, 33), (48, 50, 16)]
+    Ws, dW, dS = [], [], []
+    for mb, mk, k in cases:
+        W = rnd(rng, (mb, mk), cplx)
+        Ws.append(W), dW.append(dev(eng, W))
+        dS.append(dev(eng, np.zeros((max(mb - k, 1), max(mk - k, 1)), W.dtype)))
+    ddet = eng._alloc(len(cases))
+    sd = np.zeros(len(cases), nat.schur_desc)
+    sd["W"] = [d[1] for d in dW]
+    sd["S"] = [d[1] for d in dS]
+    sd["det"] = ddet.data_ptr() + np.arange(len(cases)) * eng.elem
+    sd["mb"], sd["mk"], sd["k"] = [c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases]
+    sd["ldw"] = sd["mb"]
+    sd["lds"] = np.maximum(sd["mb"] - sd["k"], 1)
+    t = eng._up(sd)
+    nat.check(eng.lib.tmf_lu_schur_batched(eng.dtype, t.data_ptr(), len(cases), 300, eng.stream), "lu")
+    torch.cuda.synchronize()
+    det = ddet.cpu().numpy()
+    for i, ((mb, mk, k), W) in enumerate(zip(cases, Ws)):
+        if k:
+            dref = np.linalg.det(W[:k, :k])
+            Sref = W[k:, k:] - W[k:, :k] @ np.linalg.solve(W[:k, :k], W[:k, k:])
+        else:
+            dref, Sref = 1.0, W
+        np.testing.assert_allclose(det[i], dref, rtol=1e-10)
+        if mb > k and mk > k:
+            S = back(dS[i][0], (mb - k, mk - k))
+            scale = max(1.0, np.abs(Sref).max())
+            np.testing.assert_allclose(S, Sref, rtol=0, atol=1e-10 * scale)
+            # in-place Schur complement is what the sweep reads
+            Wd = back(dW[i][0], (mb, mk))
+            np.testing.assert_allclose(Wd[k:, k:], Sref, rtol=0, atol=1e-10 * scale)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("n,cls", [(0, 8), (1, 8), (5, 8), (8, 8), (9, 16), (13, 16), (16, 16), (19, 32), (32, 32), (40, 64)])
+def test_det_gather(eng, cplx, n, cls):
+    setup(eng, cplx)
+    nat = eng.nat
+    rng = np.random.default_rng(7 + n)
+    sb, sk = max(n + 6, 3), max(n + 4, 2)
+    if sb * sk * eng.elem > 60000:
+        sb = sk = n + 2
+    S = rnd(rng, (sb, sk), cplx)
+    nsb, nsk = 37, 21 if n < 33 else 5
+    bra = np.stack([np.sort(rng.choice(sb, n, replace=False)) for _ in range(nsb)]).astype(np.uint8).reshape(nsb, n)
+    ket = np.stack([np.sort(rng.choice(sk, n, replace=False)) for _ in range(nsk)]).astype(np.uint8).reshape(nsk, n)
+    scale = rnd(rng, (1,), cplx)
+    dS_, dsc = dev(eng, S), dev(eng, scale)
+    tb, tk = eng._up(bra if n else np.zeros(1, np.uint8)), eng._up(ket if n else np.zeros(1, np.uint8))
+    out = eng._alloc(nsb * nsk, zero=True)
+    ta = 16
+    dd = np.zeros(_cdiv(nsb, ta), nat.det_desc)
+    for j in range(len(dd)):
+        dd[j] = (dS_[1], dsc[1], tb.data_ptr(), tk.data_ptr(), out.data_ptr(), sb, sk, sb, n, nsb, nsk, j * ta,
+                 min(nsb, (j + 1) * ta))
+    a16 = lambda x: (x + 15) & ~15  # noqa: E731
+    lds = a16(sb * sk * eng.elem) + a16(nsk * n) + a16(ta * n) + (n * n * eng.elem if cls == 64 else 0) + 16
+    t = eng._up(dd)
+    nat.check(eng.lib.tmf_det_gather_batched(eng.dtype, cls, t.data_ptr(), len(dd), lds, eng.stream), "det")
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(nsb, nsk)
+    ref = np.empty((nsb, nsk), S.dtype)
+    for a in range(nsb):
+        for b in range(nsk):
+            ref[a, b] = scale[0] * (np.linalg.det(S[np.ix_(bra[a], ket[b])]) if n else 1.0)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
+
+
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
+def test_det_gather_singular_minor_is_zero(eng):
+    setup(eng, True)
+    nat = eng.nat
+    S = np.ones((4, 4), complex)  # every 2x2 minor is singular
+    bra = np.array([[0, 1], [2, 3]], np.uint8)
+    ket = np.array([[0, 2], [1, 3]], np.uint8)
+    dS_, dsc = dev(eng, S), dev(eng, np.array([2.0 + 0j]))
+    tb, tk = eng._up(bra), eng._up(ket)
+    out = eng._alloc(4)
+    dd = np.zeros(1, nat.det_desc)
+    dd[0] = (dS_[1], dsc[1], tb.data_ptr(), tk.data_ptr(), out.data_ptr(), 4, 4, 4, 2, 2, 2, 0, 2)
+    t = eng._up(dd)
+    nat.check(eng.lib.tmf_det_gather_batched(eng.dtype, 8, t.data_ptr(), 1, 1024, eng.stream), "det")
+    torch.cuda.synchronize()
+    assert np.all(out.cpu().numpy() == 0)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_utilities(eng, cplx):
+    setup(eng, cplx)
+    nat = eng.nat
+    rng = np.random.default_rng(8)
+    n = 77
+    A = rnd(rng, (n, n), cplx)
+    t_in = torch.from_numpy(A.reshape(-1).copy()).to("cuda:0")
+    t_out = eng._alloc(n * n)
+    nat.check(eng.lib.tmf_transpose(eng.dtype, t_in.data_ptr(), t_out.data_ptr(), n, eng.stream), "tr")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(back(t_out, (n, n)), A)
+    # normal fill: deterministic, unit variance
+    r1, r2 = eng._alloc(100001), eng._alloc(100001)
+    for r in (r1, r2):
+        nat.check(eng.lib.tmf_fill_normal(eng.dtype, r.data_ptr(), 100001, 42, eng.stream), "fill")
+    torch.cuda.synchronize()
+    x = r1.cpu().numpy()
+    assert np.array_equal(x, r2.cpu().numpy())
+    xr = x.view(np.float64)
+    assert abs(xr.mean()) < 0.01 and abs(xr.std() - 1) < 0.01
+    # column normalise with reversal and odd flip (slater.py:410)
+    B = rnd(rng, (50, 6), cplx)
+    dB, dD = dev(eng, B), dev(eng, np.zeros_like(B))
+    eng.colcopy([dB[1]], [dD[1]], [50], [6], [50], [50], reverse=1, flip_odd=1)
+    torch.cuda.synchronize()
+    ref = (B / np.linalg.norm(B, axis=0))[:, ::-1].copy()
+    ref[:, 1::2] *= -1
+    np.testing.assert_allclose(back(dD[0], (50, 6)), ref, atol=1e-15)
