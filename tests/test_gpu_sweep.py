@@ -62,7 +62,8 @@ def test_sweep_matches_reference_fixture(name):
     for i in range(L):
         s = mps.sites[i]
         assert sorted(b[0] for b in s.blocks) == sorted(int(q) for q in g[f"s{i}_blkq"])
-        np.testing.assert_allclose(abs(s.det_always), abs(g[f"s{i}_det_always"]), rtol=1e-8)
+        # det_always alone depends on the (arbitrary) basis of the filled subspace whenever the bra and
+        # ket always-blocks differ in size; det_always * minor (= the blocks) is the invariant quantity
         for q, r0, r1, c0, c1, blk in s.blocks:
             ref = g[f"s{i}_blk{q}"]
             assert blk.shape == ref.shape
@@ -101,6 +102,8 @@ def test_sweep_degenerate_spectra(name):
         if mps.bonds[b].chi != len(cuts[b].lam):
             same_basis = False  # a degenerate multiplet straddles chi_max: rounding decides
             continue
+        if sorted(map(bytes, mps.bonds[b].sets)) != sorted(map(bytes, cuts[b].sets)):
+            same_basis = False  # chi_max cuts a pair that is degenerate only in exact arithmetic
         np.testing.assert_allclose(np.sort(mps.bonds[b].lam), np.sort(cuts[b].lam), rtol=0, atol=1e-8)
     if same_basis and name != "randSimple_L6_s4_chi32":
         assert abs(1 - overlap(cuts, sites, mps, oc)) < 1e-9
