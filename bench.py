@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: sites/sec of the Slater -> MPS conversion (BASELINE.json metric).
+
+A step = one full C -> MPS conversion of the workload (all L sites): per-cut block
+diagonalisation, enumeration, overlap/Schur complement and all tensor-block determinants.
+The timed region starts with C resident in HBM and ends with every tensor block resident in
+HBM (the PCIe-inclusive rate is printed as `value_pcie` and discussed in DESIGN.md).
+
+N = 1  : workload = BASELINE config 3 sizes on one GPU, L=1024, chi_max=512, random complex
+         hopping seed 0 (the configuration the metric is quoted on; it fits one GPU).
+N > 1  : the same chain, sites sharded over the ranks (contiguous, cost-balanced ranges);
+         cuts on a shard boundary are recomputed by both neighbours (the kernels are
+         deterministic), so there is no data-path collective.  scaling = "strong".
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task description).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak (spec; half the 157.3 TF fp32 vector peak)
+
+
+def shard_sites(L, oc, world):
+    """Contiguous site ranges with balanced cost  w(i) = 1 + 3 (n_i / (L/2))^3
+    (determinant stage ~ constant in the chi-saturated bulk, eigen/overlap stages ~ n^3)."""
+    i = np.arange(L)
+    n = np.where(i < oc, i + 1, L - i)
+    w = 1.0 + 3.0 * (n / max(L / 2, 1)) ** 3
+    c = np.concatenate(([0.0], np.cumsum(w)))
+    bounds = [int(np.searchsorted(c, c[-1] * r / world)) for r in range(world + 1)]
+    bounds[0], bounds[-1] = 0, L
+    for r in range(1, world + 1):
+        bounds[r] = max(bounds[r], bounds[r - 1])
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+def cpu_baseline(C, chi, L, oc, n_sample):
+    """Oracle (NumPy restatement of the reference, `kind: port`) on a bounded sample of sites."""
+    from oracle import slater_oracle as orc
+
+    trunc = orc.as_trunc({"chi_max": chi})
+    sites = sorted(set(np.linspace(0, L - 1, n_sample).astype(int).tolist()))
+    t0 = time.perf_counter()
+    S = {}
+    for i in sites:
+        if i >= oc:
+            bra = orc.cut_vectors(C, i + 1, trunc, "R")
+            ket = orc.cut_vectors(C, i, trunc, "R" if i > oc else "LR")
+            orc.site_tensor(bra, ket, "right")
+        else:
+            bra = orc.cut_vectors(C, i, trunc, "L")
+            ket = orc.cut_vectors(C, i + 1, trunc, "L" if i + 1 < oc else "LR")
+            orc.site_tensor(bra, ket, "left")
+        for c in (bra, ket):
+            p = c.lam**2
+            S[c.x] = -(p[p > 0] * np.log(p[p > 0])).sum()
+    dt = time.perf_counter() - t0
+    # each sampled site costs two cut decompositions; the sweep amortises one per site
+    return len(sites) / dt, sites, S, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--L", type=int, default=1024)
+    ap.add_argument("--chi", type=int, default=512)
+    ap.add_argument("--cpu-sample", type=int, default=40, help="sites timed with the CPU oracle (0 = skip)")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = f"cuda:{local}"
+    torch.cuda.set_device(local)
+
+    from tests_inputs import random_hopping
+    from temfpy_amd import slater
+    from temfpy_amd.engine import Engine
+    from temfpy_amd.schmidt_utils import to_stopping_condition
+
+    L, chi = a.L, a.chi
+    C, N = slater.correlation_matrix(random_hopping(L, 0))  # H -> C is outside the metric
+    oc = L // 2
+    trunc = to_stopping_condition({"chi_max": chi})
+    eng = Engine(dev, profile=False)
+    d_C = torch.from_numpy(np.ascontiguousarray(C).reshape(-1)).to(dev)
+    rng_sites = shard_sites(L, oc, world)[rank]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def step():
+        return eng.run(d_C, trunc, oc, L, download=False, site_range=rng_sites if world > 1 else None)
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    det_ms, det_flops, det_n = {}, {}, {}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        mps = step()
+        torch.cuda.synchronize()
+        for cls, e0, e1, fl, nd in eng.det_events:
+            det_ms.setdefault(cls, []).append(e0.elapsed_time(e1))
+            det_flops[cls], det_n[cls] = fl, nd
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # PCIe-inclusive variant (host C in, host tensors out), N = 1 only, one repetition
+    value_pcie = None
+    if world == 1:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        full = eng.run(C, trunc, oc, L, download=True)
+        value_pcie = L / (time.perf_counter() - t1)
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        dom = max(det_ms, key=lambda c: np.mean(det_ms[c])) if det_ms else None
+        roof = None
+        if dom is not None:
+            avg_ms = float(np.mean(det_ms[dom]))
+            ach = det_flops[dom] / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": f"det_kernel<complex128, n<={dom}>", "achieved": round(ach, 4),
+                    "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_PEAK_TFLOPS, 5),
+                    "traffic": None, "avg_launch_ms": round(avg_ms, 3), "dets_per_launch": det_n[dom],
+                    "flops_per_launch": det_flops[dom],
+                    "all_det_launch_ms": {str(c): round(float(np.mean(v)), 3) for c, v in det_ms.items()}}
+        out = {
+            "metric": "sites/sec (Slater->MPS, L=%d chi=%d fp64)" % (L, chi), "value": round(L / (dt / a.steps), 2),
+            "unit": "sites/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "c128 (fp64 complex)",
+            "data": "synthetic",
+            "config": {"workload": f"L={L} random complex hopping (seed 0, range 3) Slater->MPS, chi_max={chi}, "
+                                   f"svd_min=1e-6; sites sharded over {world} rank(s)", "N_fermions": N,
+                       "stage_ms": {k: round(v * 1e3, 1) for k, v in mps.timings.items()}},
+            "roofline": roof, "value_pcie": None if value_pcie is None else round(value_pcie, 2),
+        }
+        if world == 1 and a.cpu_sample > 0:
+            v, sites, S_ref, t_cpu = cpu_baseline(C, chi, L, oc, a.cpu_sample)
+            S_hip = full.entanglement_entropy(all_bonds=True)
+            dS = max(abs(S_hip[b] - s) for b, s in S_ref.items())
+            out["cpu_baseline"] = {"value": round(v, 3), "unit": "sites/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"{len(sites)} of {L} sites evenly spaced along the chain, "
+                                             f"{t_cpu:.1f} s of oracle time (NumPy/OpenBLAS threads = all cores)"}
+            out["max_abs_dS_vs_oracle"] = float(dS)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

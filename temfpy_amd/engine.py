@@ -165,25 +165,41 @@ class Engine:
                   "tmf_normalise_columns_batched")
 
     # ------------------------------------------------------------------ the sweep
-    def run(self, C, trunc, ortho_center, unit_cell_width, threads=None):
+    def run(self, C, trunc, ortho_center, unit_cell_width, threads=None, download=True, site_range=None):
+        """One C -> MPS conversion.
+
+        C            (L, L) NumPy array, or a row-major torch tensor already resident in HBM
+        download     False keeps the tensors in HBM (``self.d_out``) and returns no site blocks
+        site_range   (a, b): only sites a <= i < b and the cuts next to them (one rank's shard)
+        """
         torch = self.torch
         t_all = time.perf_counter()
         self.timings = {}
-        C = np.asarray(C)
-        cplx = np.iscomplexobj(C)
+        self.det_events = []
+        if isinstance(C, torch.Tensor):
+            d_Crm = C.reshape(-1)
+            cplx = d_Crm.is_complex()
+            L = int(round(d_Crm.numel() ** 0.5))
+            diag = torch.real(d_Crm[:: L + 1]).cpu().numpy().astype(np.float64)
+        else:
+            C = np.asarray(C)
+            cplx = np.iscomplexobj(C)
+            C = np.ascontiguousarray(C, np.complex128 if cplx else np.float64)
+            L = len(C)
+            diag = np.real(np.diagonal(C)).astype(np.float64)
+            d_Crm = None
         self.dtype = nat.TMF_C128 if cplx else nat.TMF_F64
         self.elem = 16 if cplx else 8
-        npdt = np.complex128 if cplx else np.float64
-        C = np.ascontiguousarray(C, npdt)
-        L = len(C)
         oc = ortho_center
         el = self.elem
         cutoff = trunc.svd_min**2  # slater.py:318
         thr2 = cutoff * (1.0 - cutoff)
         threads = threads or min(16, os.cpu_count() or 1)
+        s_lo, s_hi = site_range if site_range is not None else (0, L)
 
         t0 = time.perf_counter()
-        d_Crm = torch.from_numpy(C.reshape(-1)).to(self.device)
+        if d_Crm is None:
+            d_Crm = torch.from_numpy(C.reshape(-1)).to(self.device)
         d_C = self._alloc(L * L)
         nat.check(self.lib.tmf_transpose(self.dtype, d_Crm.data_ptr(), d_C.data_ptr(), L, self.stream), "tmf_transpose")
         Cp = d_C.data_ptr()
@@ -193,12 +209,17 @@ class Engine:
         self._tick("upload", t0)
 
         # ---- cut-side problems --------------------------------------------------------------
+        need = set()
+        for i in range(s_lo, s_hi):
+            sd_ = 0 if i < oc else 1
+            need.add((i, sd_)), need.add((i + 1, sd_))
+        if (oc, 1) in need or (s_lo <= oc <= s_hi):
+            need.add((oc, 0)), need.add((oc, 1))  # the centre's right orbitals are paired with its left ones
         cs_b, cs_side = [], []
         for b in range(L + 1):
-            if b <= oc:
-                cs_b.append(b), cs_side.append(0)
-            if b >= oc:
-                cs_b.append(b), cs_side.append(1)
+            for sd_ in (0, 1):
+                if (b, sd_) in need:
+                    cs_b.append(b), cs_side.append(sd_)
         cs_b, cs_side = np.array(cs_b), np.array(cs_side)
         ncs = len(cs_b)
         n = np.where(cs_side == 0, cs_b, L - cs_b)
@@ -206,11 +227,13 @@ class Engine:
         blk = Cp + np.where(cs_side == 0, 0, (cs_b + cs_b * L)) * el      # A = C_LL or C_RR
         off = Cp + np.where(cs_side == 0, cs_b * L, cs_b) * el            # F (n x m)
         omp = d_Om.data_ptr() + np.where(cs_side == 0, cs_b, 0) * el      # rows of Omega on the other side
-        centre_R = np.nonzero((cs_b == oc) & (cs_side == 1))[0][0]
-        centre_L = np.nonzero((cs_b == oc) & (cs_side == 0))[0][0]
+        has_centre = (oc, 0) in need
+        centre_R = np.nonzero((cs_b == oc) & (cs_side == 1))[0][0] if has_centre else -1
+        centre_L = np.nonzero((cs_b == oc) & (cs_side == 0))[0][0] if has_centre else -1
         # the right side of the centre cut is paired with the left side through C_RL (block_svd, slater.py:407)
         doE = (n > 0) & (m > 0)
-        doE[centre_R] = False
+        if has_centre:
+            doE[centre_R] = False
         p = np.where(doE, np.minimum(P, np.minimum(n, m)), 0)
 
         def offsets(sizes):
@@ -265,7 +288,6 @@ class Engine:
         t0 = time.perf_counter()
         h_e = d_e.cpu().numpy()
         h_cnt = d_cnt.cpu().numpy()
-        diag = np.real(np.diagonal(C)).copy()
         csum = np.concatenate(([0.0], np.cumsum(diag)))
         n_fermion = int(np.round(csum[-1]))  # slater.py:414
         tr = np.where(cs_side == 0, csum[cs_b], csum[-1] - csum[cs_b])
@@ -286,8 +308,9 @@ class Engine:
             k[i] = len(ev) - x_hi - x_lo
             e_side[i] = ev[x_hi: x_hi + k[i]].copy()
         # centre: right-side eigenvalues are 1 - e_L reversed (slater.py:386 convention)
-        k[centre_R] = k[centre_L]
-        e_side[centre_R] = (1.0 - e_side[centre_L])[::-1].copy()
+        if has_centre:
+            k[centre_R] = k[centre_L]
+            e_side[centre_R] = (1.0 - e_side[centre_L])[::-1].copy()
         nf = np.array([int(np.round(tr[i] - e_side[i].sum())) for i in range(ncs)])
         nf = np.clip(nf, 0, n - k)
         self._tick("host_classify", t0)
@@ -301,7 +324,7 @@ class Engine:
         # entangled columns (renormalised copy); centre-right: C_RL U_E(left), reversed, odd columns flipped
         cp = doE.copy()
         self.colcopy((UEp + ent0 * ld1 * el)[cp], Vp[cp], n[cp], k[cp], ld1[cp], ld1[cp])
-        if k[centre_L] > 0 and n[centre_R] > 0:
+        if has_centre and k[centre_L] > 0 and n[centre_R] > 0:
             d_pair = self._alloc(n[centre_R] * k[centre_L])
             self.gemm(0, 1.0, 0.0, [off[centre_R]], [Vp[centre_L]], [d_pair.data_ptr()], [n[centre_R]], [k[centre_L]],
                       [m[centre_R]], [L], [ld1[centre_L]], [ld1[centre_R]])
@@ -331,7 +354,8 @@ class Engine:
         for i in range(ncs):
             cut_idx[(int(cs_b[i]), int(cs_side[i]))] = i
         e_left, nfl, nfr = [None] * (L + 1), [0] * (L + 1), [0] * (L + 1)
-        for b in range(L + 1):
+        my_cuts = sorted({b for b, _ in need})
+        for b in my_cuts:
             iL, iR = cut_idx.get((b, 0)), cut_idx.get((b, 1))
             if iL is not None:
                 e_left[b] = e_side[iL]
@@ -346,9 +370,9 @@ class Engine:
             return nat.cut_vectors(e_left[b], nfl[b], trunc.chi_max or 0, trunc.svd_min, trunc.degeneracy_tol, sectors)
 
         with ThreadPoolExecutor(threads) as ex:
-            enum_out = list(ex.map(enum, range(L + 1)))
-        bonds = []
-        for b in range(L + 1):
+            enum_out = dict(zip(my_cuts, ex.map(enum, my_cuts)))
+        bonds = [None] * (L + 1)
+        for b in my_cuts:
             sets, lam_raw, q, nchk = enum_out[b]
             if len(lam_raw) == 0:
                 raise ValueError("No Schmidt vectors left after filtering by `trunc_par.sectors`!")  # slater.py:668
@@ -362,7 +386,7 @@ class Engine:
             bd = BondData(x=b, e=e_left[b], n_filled_left=nfl[b], n_filled_right=nfr[b], sets=sb_, lam_raw=lam_raw,
                           lam=lam_raw / nrm, q_left=q, n_checked=nchk)
             bd._masks = sets
-            bonds.append(bd)
+            bonds[b] = bd
         self._tick("host_enumerate", t0)
 
         # ---- host: per-site integer preparation -------------------------------------------------
@@ -378,8 +402,10 @@ class Engine:
             r["ib"], r["ik"], r["mode"] = ib, ik, mode
             return r
 
+        my_sites = list(range(s_lo, s_hi))
         with ThreadPoolExecutor(threads) as ex:
-            prep_out = list(ex.map(prep, range(L)))
+            prep_out = list(ex.map(prep, my_sites))
+        L_all, L = L, len(my_sites)  # from here on "L" counts the sites of this shard
         self._tick("host_site_prepare", t0)
 
         # ---- S1/S2: overlaps and W assembly ---------------------------------------------------
@@ -451,8 +477,8 @@ class Engine:
                         t_pool.data_ptr() + pool_off[i] + int(sec["ket_off"]),
                         d_out.data_ptr() + (out_off[i] + int(sec["out_off"])) * el, int(sbv[i]), int(skv[i]),
                         int(max(mb[i], 1)), nq, nsb, nsk)
-                need = a16(int(sbv[i]) * int(skv[i]) * el) + a16(nsk * nq) + a16(ta * nq) + (nq * nq * el if cls == 64 else 0)
-                lds_need[cls] = max(lds_need[cls], need)
+                lneed = a16(int(sbv[i]) * int(skv[i]) * el) + a16(nsk * nq) + a16(ta * nq) + (nq * nq * el if cls == 64 else 0)
+                lds_need[cls] = max(lds_need[cls], lneed)
                 for a0 in range(0, nsb, ta):
                     tiles[cls].append(base + (a0, min(nsb, a0 + ta)))
         n_det = 0
@@ -467,27 +493,41 @@ class Engine:
             # biggest tiles first
             dd = dd[np.argsort(-((dd["a1"] - dd["a0"]).astype(np.int64) * dd["nsk"] * (dd["n"].astype(np.int64) + 1) ** 2), kind="stable")]
             t_dd = self._up(dd)
+            flops = float((((dd["a1"] - dd["a0"]).astype(np.float64) * dd["nsk"]) * dd["n"].astype(np.float64) ** 3).sum())
+            flops *= (8.0 / 3.0) if cplx else (2.0 / 3.0)  # LU of an n x n complex / real matrix
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream(self.device))
             nat.check(self.lib.tmf_det_gather_batched(self.dtype, cls, t_dd.data_ptr(), len(tl), int(lds_need[cls]) + 16,
                                                       self.stream), "tmf_det_gather_batched")
+            ev1.record(torch.cuda.current_stream(self.device))
+            ndet_cls = int(((dd["a1"] - dd["a0"]).astype(np.int64) * dd["nsk"]).sum())
+            self.det_events.append((cls, ev0, ev1, flops, ndet_cls))
         self.n_det = n_det
         self._tick("S_determinants", t0)
         self.d_out = d_out  # device-resident result
 
         # ---- host round trip 2: tensors back -----------------------------------------------------
+        if not download:
+            torch.cuda.current_stream(self.device).synchronize()
+            self.timings["total"] = time.perf_counter() - t_all
+            self._keep.clear()
+            return MPSData(bonds, [], oc, unit_cell_width, dict(self.timings))
         t0 = time.perf_counter()
         h_out = d_out.cpu().numpy()
         h_det = d_det.cpu().numpy()
-        sites = []
-        for i, r in enumerate(prep_out):
+        sites = [None] * s_lo
+        for j, r in enumerate(prep_out):
+            i = my_sites[j]
             m_ = "left" if r["mode"] == 0 else "right"
             bb, kb = (i, i + 1) if r["mode"] == 0 else (i + 1, i)
             blocks = []
             for sec in r["sectors"]:
                 r0, r1, c0, c1 = (int(sec[f]) for f in ("r0", "r1", "c0", "c1"))
-                o = out_off[i] + int(sec["out_off"])
+                o = out_off[j] + int(sec["out_off"])
                 blocks.append((int(sec["q"]), r0, r1, c0, c1, h_out[o: o + (r1 - r0) * (c1 - c0)].reshape(r1 - r0, c1 - c0)))
-            sites.append(SiteData(mode=m_, det_always=h_det[i], qtotal=0, bra_p=r["bra_p"], bra_alpha=r["bra_alpha"],
+            sites.append(SiteData(mode=m_, det_always=h_det[j], qtotal=0, bra_p=r["bra_p"], bra_alpha=r["bra_alpha"],
                                   blocks=blocks, chi_bra=bonds[bb].chi, chi_ket=bonds[kb].chi))
+        sites += [None] * (L_all - s_hi)
         self._tick("download", t0)
         self.timings["total"] = time.perf_counter() - t_all
         self._keep.clear()

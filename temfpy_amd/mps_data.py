@@ -66,7 +66,7 @@ class MPSData:
     def __init__(self, bonds, sites, ortho_center, unit_cell_width, timings=None):
         self.bonds = bonds
         self.sites = sites
-        self.L = len(sites)
+        self.L = len(bonds) - 1
         self.ortho_center = ortho_center
         self.unit_cell_width = unit_cell_width
         self.form = ["A"] * ortho_center + ["B"] * (self.L - ortho_center)  # slater.py:1348
