@@ -209,6 +209,24 @@ int tmf_site_prepare(const tmf_site_in* in, const uint64_t* sets_b, const int32_
                      tmf_sector* sectors, int32_t sector_cap, uint8_t* idx_pool, int64_t idx_cap,
                      tmf_site_out* out);
 
+/* Batched, multi-threaded forms (one call per sweep).  Per-cut outputs live at stride `cap`
+ * (sets: cap*2 words) in the caller's arrays; `chi[i]` receives the number of kept vectors. */
+int tmf_cut_vectors_batch(int ncuts, const double* e_pool, const int64_t* e_off, const int32_t* k,
+                          const int32_t* filled_left, int64_t chi_max, double svd_min, double degeneracy_tol,
+                          const int64_t* sectors, int n_sectors, int64_t cap, uint64_t* sets, double* lam_raw,
+                          int32_t* q_left, int64_t* chi, int64_t* n_checked, int nthreads);
+
+typedef struct {
+  int32_t mode, cut_b, cut_k;        /* cut indices into the arrays of tmf_cut_vectors_batch */
+  int32_t k_b, nf_b, k_k, nf_k, sec_cap;
+  int64_t row_off, col_off, bra_off, sec_off, idx_off, idx_cap;  /* where this site's outputs go */
+} tmf_site_job;                      /* 80 bytes */
+
+int tmf_site_prepare_batch(int nsites, const tmf_site_job* jobs, const uint64_t* sets, const int32_t* q_left,
+                           const int64_t* chi, int64_t cap, int32_t* row_sel, int8_t* row_sign, int32_t* col_sel,
+                           int8_t* col_sign, int32_t* bra_p, int32_t* bra_alpha, tmf_sector* sectors,
+                           uint8_t* idx_pool, tmf_site_out* outs, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

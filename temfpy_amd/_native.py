@@ -38,6 +38,10 @@ site_out = np.dtype([("mb", "<i4"), ("mk", "<i4"), ("k_always", "<i4"), ("sb", "
 sector = np.dtype([("q", "<i4"), ("r0", "<i4"), ("r1", "<i4"), ("c0", "<i4"), ("c1", "<i4"), ("n", "<i4"),
                    ("bra_off", "<i8"), ("ket_off", "<i8"), ("out_off", "<i8")])
 
+site_job = np.dtype([("mode", "<i4"), ("cut_b", "<i4"), ("cut_k", "<i4"), ("k_b", "<i4"), ("nf_b", "<i4"),
+                     ("k_k", "<i4"), ("nf_k", "<i4"), ("sec_cap", "<i4"), ("row_off", "<i8"), ("col_off", "<i8"),
+                     ("bra_off", "<i8"), ("sec_off", "<i8"), ("idx_off", "<i8"), ("idx_cap", "<i8")])
+assert site_job.itemsize == 80
 assert gemm_desc.itemsize == 48 and panel_desc.itemsize == 24 and jacobi_desc.itemsize == 64
 assert schur_desc.itemsize == 48 and det_desc.itemsize == 72 and gather_desc.itemsize == 80
 assert colnorm_desc.itemsize == 40 and sector.itemsize == 48 and site_out.itemsize == 40
@@ -46,6 +50,7 @@ SYMBOLS = [
     "tmf_last_error", "tmf_version", "tmf_device_count", "tmf_gemm_batched", "tmf_orth_panel_batched",
     "tmf_jacobi_batched", "tmf_lu_schur_batched", "tmf_det_gather_batched", "tmf_transpose", "tmf_fill_normal",
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_cut_vectors", "tmf_site_prepare",
+    "tmf_cut_vectors_batch", "tmf_site_prepare_batch",
 ]
 
 
@@ -80,6 +85,8 @@ def load():
     lib.tmf_cut_vectors.argtypes = [vp, i32, i32, i64, f64, f64, vp, i32, i64, vp, vp, vp, vp, vp]
     lib.tmf_site_prepare.argtypes = [vp] * 13 + [i32, vp, i64, vp]
     lib.tmf_site_prepare.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i64, vp]
+    lib.tmf_cut_vectors_batch.argtypes = [i32, vp, vp, vp, vp, i64, f64, f64, vp, i32, i64, vp, vp, vp, vp, vp, i32]
+    lib.tmf_site_prepare_batch.argtypes = [i32, vp, vp, vp, vp, i64] + [vp] * 9 + [i32]
     _LIB = lib
     return lib
 

@@ -403,3 +403,66 @@ extern "C" int tmf_site_prepare(const tmf_site_in* in, const uint64_t* sets_b, c
   out->out_elems = out_elems;
   return TMF_OK;
 }
+
+// -------------------------------------------------------------------------------------------
+// Batched, multi-threaded variants: one call for all cuts / all sites of a sweep.
+// -------------------------------------------------------------------------------------------
+#include <atomic>
+#include <thread>
+
+namespace {
+template <typename F>
+int parallel_for(int n, int nthreads, F&& fn) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > n) nthreads = n > 0 ? n : 1;
+  std::atomic<int> next(0), err(0);
+  auto work = [&]() {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n) break;
+      const int st = fn(i);
+      if (st != 0) {
+        int z = 0;
+        err.compare_exchange_strong(z, st);
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads; ++t) th.emplace_back(work);
+  work();
+  for (auto& t : th) t.join();
+  return err.load();
+}
+}  // namespace
+
+extern "C" int tmf_cut_vectors_batch(int ncuts, const double* e_pool, const int64_t* e_off, const int32_t* k,
+                                     const int32_t* filled_left, int64_t chi_max, double svd_min,
+                                     double degeneracy_tol, const int64_t* sectors, int n_sectors, int64_t cap,
+                                     uint64_t* sets, double* lam_raw, int32_t* q_left, int64_t* chi,
+                                     int64_t* n_checked, int nthreads) {
+  return parallel_for(ncuts, nthreads, [&](int i) {
+    return tmf_cut_vectors(e_pool + e_off[i], k[i], filled_left[i], chi_max, svd_min, degeneracy_tol, sectors,
+                           n_sectors, cap, sets + (size_t)i * cap * 2, lam_raw + (size_t)i * cap,
+                           q_left + (size_t)i * cap, chi + i, n_checked + i);
+  });
+}
+
+extern "C" int tmf_site_prepare_batch(int nsites, const tmf_site_job* jobs, const uint64_t* sets,
+                                      const int32_t* q_left, const int64_t* chi, int64_t cap, int32_t* row_sel,
+                                      int8_t* row_sign, int32_t* col_sel, int8_t* col_sign, int32_t* bra_p,
+                                      int32_t* bra_alpha, tmf_sector* sectors, uint8_t* idx_pool,
+                                      tmf_site_out* outs, int nthreads) {
+  return parallel_for(nsites, nthreads, [&](int i) {
+    const tmf_site_job& j = jobs[i];
+    tmf_site_in in;
+    in.mode = j.mode;
+    in.k_b = j.k_b, in.nf_b = j.nf_b, in.chi_b = (int32_t)chi[j.cut_b];
+    in.k_k = j.k_k, in.nf_k = j.nf_k, in.chi_k = (int32_t)chi[j.cut_k];
+    in.pad = 0;
+    return tmf_site_prepare(&in, sets + (size_t)j.cut_b * cap * 2, q_left + (size_t)j.cut_b * cap,
+                            sets + (size_t)j.cut_k * cap * 2, q_left + (size_t)j.cut_k * cap, row_sel + j.row_off,
+                            row_sign + j.row_off, col_sel + j.col_off, col_sign + j.col_off, bra_p + j.bra_off,
+                            bra_alpha + j.bra_off, sectors + j.sec_off, j.sec_cap, idx_pool + j.idx_off, j.idx_cap,
+                            outs + i);
+  });
+}

@@ -347,77 +347,105 @@ class Engine:
             self.bcgs2(Vp[has], n[has], ld1[has], k[has], ncolV[has], scr2[has])
         self._tick("F_filled", t0)
 
-        # ---- host: best-first enumeration for every cut (C++, threaded) ------------------------
+        # ---- host: best-first enumeration for every cut (one threaded C++ call) ----------------
         t0 = time.perf_counter()
         sectors = _sector_list(trunc, L)
         cut_idx = {}
         for i in range(ncs):
             cut_idx[(int(cs_b[i]), int(cs_side[i]))] = i
-        e_left, nfl, nfr = [None] * (L + 1), [0] * (L + 1), [0] * (L + 1)
         my_cuts = sorted({b for b, _ in need})
-        for b in my_cuts:
+        ncut = len(my_cuts)
+        cpos = {b: j for j, b in enumerate(my_cuts)}
+        e_left, nfl, nfr = [None] * ncut, np.zeros(ncut, np.int32), np.zeros(ncut, np.int32)
+        for j, b in enumerate(my_cuts):
             iL, iR = cut_idx.get((b, 0)), cut_idx.get((b, 1))
             if iL is not None:
-                e_left[b] = e_side[iL]
-                nfl[b] = int(nf[iL])
-                nfr[b] = int(nf[iR]) if iR is not None else n_fermion - len(e_left[b]) - nfl[b]  # slater.py:167
+                e_left[j] = e_side[iL]
+                nfl[j] = nf[iL]
+                nfr[j] = nf[iR] if iR is not None else n_fermion - len(e_left[j]) - nfl[j]  # slater.py:167
             else:
-                e_left[b] = (1.0 - e_side[iR])[::-1].copy()  # slater.py:386
-                nfr[b] = int(nf[iR])
-                nfl[b] = n_fermion - len(e_left[b]) - nfr[b]  # slater.py:172
-
-        def enum(b):
-            return nat.cut_vectors(e_left[b], nfl[b], trunc.chi_max or 0, trunc.svd_min, trunc.degeneracy_tol, sectors)
-
-        with ThreadPoolExecutor(threads) as ex:
-            enum_out = dict(zip(my_cuts, ex.map(enum, my_cuts)))
+                e_left[j] = (1.0 - e_side[iR])[::-1].copy()  # slater.py:386
+                nfr[j] = nf[iR]
+                nfl[j] = n_fermion - len(e_left[j]) - nfr[j]  # slater.py:172
+        kk_cut = np.array([len(x) for x in e_left], np.int32)
+        e_off = np.concatenate(([0], np.cumsum(kk_cut)))[:-1].astype(np.int64)
+        e_pool = np.concatenate(e_left + [np.zeros(1)])
+        sec_arr = None if sectors is None else np.ascontiguousarray(sectors, np.int64)
+        cap = int(trunc.chi_max) + 1 if trunc.chi_max else 4096
+        while True:
+            c_sets = np.zeros((ncut, cap, 2), np.uint64)
+            c_lam = np.zeros((ncut, cap))
+            c_q = np.zeros((ncut, cap), np.int32)
+            c_chi, c_chk = np.zeros(ncut, np.int64), np.zeros(ncut, np.int64)
+            st = self.lib.tmf_cut_vectors_batch(
+                ncut, nat._p(e_pool), nat._p(e_off), nat._p(kk_cut), nat._p(nfl), int(trunc.chi_max or 0),
+                float(trunc.svd_min), float(trunc.degeneracy_tol), None if sec_arr is None else nat._p(sec_arr),
+                0 if sec_arr is None else sec_arr.size, cap, nat._p(c_sets), nat._p(c_lam), nat._p(c_q), nat._p(c_chi),
+                nat._p(c_chk), threads)
+            if st == -3 and not trunc.chi_max and int(c_chi.max()) > cap:
+                cap = int(c_chi.max()) + 1  # unlimited chi: grow the per-cut capacity and redo
+                continue
+            nat.check(st, "tmf_cut_vectors_batch")
+            break
+        if np.any(c_chi == 0):
+            raise ValueError("No Schmidt vectors left after filtering by `trunc_par.sectors`!")  # slater.py:668
         bonds = [None] * (L + 1)
-        for b in my_cuts:
-            sets, lam_raw, q, nchk = enum_out[b]
-            if len(lam_raw) == 0:
-                raise ValueError("No Schmidt vectors left after filtering by `trunc_par.sectors`!")  # slater.py:668
-            kk = len(e_left[b])
-            sb_ = np.zeros((len(sets), kk), bool)
-            for i in range(kk):
-                sb_[:, i] = (sets[:, i // 64] >> np.uint64(i % 64)) & np.uint64(1)
-            nrm = np.linalg.norm(lam_raw)
-            logger.info("bond %d: %d Schmidt modes, checked %d subsets, kept %d, norm %.12g", b, kk, nchk,
-                        len(lam_raw), nrm)
-            bd = BondData(x=b, e=e_left[b], n_filled_left=nfl[b], n_filled_right=nfr[b], sets=sb_, lam_raw=lam_raw,
-                          lam=lam_raw / nrm, q_left=q, n_checked=nchk)
-            bd._masks = sets
-            bonds[b] = bd
+        for j, b in enumerate(my_cuts):
+            ch = int(c_chi[j])
+            lam_raw = c_lam[j, :ch]
+            nrm = float(np.sqrt(np.dot(lam_raw, lam_raw)))
+            if logger.isEnabledFor(logging.INFO):
+                logger.info("bond %d: %d Schmidt modes, checked %d subsets, kept %d, norm %.12g", b, kk_cut[j],
+                            c_chk[j], ch, nrm)
+            bonds[b] = BondData(x=b, e=e_left[j], n_filled_left=int(nfl[j]), n_filled_right=int(nfr[j]),
+                                masks=c_sets[j, :ch], lam_raw=lam_raw, lam=lam_raw / nrm, q_left=c_q[j, :ch],
+                                n_checked=int(c_chk[j]))
         self._tick("host_enumerate", t0)
 
-        # ---- host: per-site integer preparation -------------------------------------------------
+        # ---- host: per-site integer preparation (one threaded C++ call) --------------------------
         t0 = time.perf_counter()
-
-        def prep(i):
-            mode = 0 if i < oc else 1
-            bb, kb = (i, i + 1) if mode == 0 else (i + 1, i)
-            ib, ik = cut_idx[(bb, mode)], cut_idx[(kb, mode)]
-            B, K = bonds[bb], bonds[kb]
-            r = nat.site_prepare(mode, int(k[ib]), int(nf[ib]), B._masks, B.q_left, int(k[ik]), int(nf[ik]), K._masks,
-                                 K.q_left)
-            r["ib"], r["ik"], r["mode"] = ib, ik, mode
-            return r
-
-        my_sites = list(range(s_lo, s_hi))
-        with ThreadPoolExecutor(threads) as ex:
-            prep_out = list(ex.map(prep, my_sites))
-        L_all, L = L, len(my_sites)  # from here on "L" counts the sites of this shard
+        my_sites = np.arange(s_lo, s_hi)
+        ns = len(my_sites)
+        mode = (my_sites >= oc).astype(np.int32)
+        bb = np.where(mode == 0, my_sites, my_sites + 1)
+        kb_ = np.where(mode == 0, my_sites + 1, my_sites)
+        ib = np.array([cut_idx[(int(b_), int(m_))] for b_, m_ in zip(bb, mode)])
+        ik = np.array([cut_idx[(int(b_), int(m_))] for b_, m_ in zip(kb_, mode)])
+        cb_i = np.array([cpos[int(b_)] for b_ in bb])
+        ck_i = np.array([cpos[int(b_)] for b_ in kb_])
+        chi_b, chi_k = c_chi[cb_i], c_chi[ck_i]
+        jobs = np.zeros(ns, nat.site_job)
+        jobs["mode"], jobs["cut_b"], jobs["cut_k"] = mode, cb_i, ck_i
+        jobs["k_b"], jobs["nf_b"], jobs["k_k"], jobs["nf_k"] = k[ib], nf[ib], k[ik], nf[ik]
+        mb_cap = k[ib] + nf[ib] + 1
+        mk_cap = np.maximum(k[ik] + nf[ik], 1)
+        sec_cap = k[ik] + 2
+        n_bound = np.minimum(255, k[ik] + np.maximum(0, nf[ik] + k[ik] - nf[ib]) + 1)
+        idx_cap = (2 * chi_b + chi_k) * n_bound + 16
+        jobs["sec_cap"] = sec_cap
+        jobs["row_off"], rs_tot = offsets(mb_cap)
+        jobs["col_off"], cs_tot = offsets(mk_cap)
+        jobs["bra_off"], br_tot = offsets(2 * chi_b)
+        jobs["sec_off"], sc_tot = offsets(sec_cap)
+        jobs["idx_off"], ix_tot = offsets(idx_cap)
+        jobs["idx_cap"] = idx_cap
+        row_sel, row_sign = np.zeros(rs_tot + 1, np.int32), np.zeros(rs_tot + 1, np.int8)
+        col_sel, col_sign = np.zeros(cs_tot + 1, np.int32), np.zeros(cs_tot + 1, np.int8)
+        bra_p, bra_alpha = np.zeros(br_tot + 1, np.int32), np.zeros(br_tot + 1, np.int32)
+        sec_buf = np.zeros(sc_tot + 1, nat.sector)
+        pool = np.zeros(ix_tot + 1, np.uint8)
+        souts = np.zeros(ns, nat.site_out)
+        nat.check(self.lib.tmf_site_prepare_batch(
+            ns, nat._p(jobs), nat._p(c_sets), nat._p(c_q), nat._p(c_chi), cap, nat._p(row_sel), nat._p(row_sign),
+            nat._p(col_sel), nat._p(col_sign), nat._p(bra_p), nat._p(bra_alpha), nat._p(sec_buf), nat._p(pool),
+            nat._p(souts), threads), "tmf_site_prepare_batch")
         self._tick("host_site_prepare", t0)
+        L_all, L = L, ns  # from here on "L" counts the sites of this shard
 
         # ---- S1/S2: overlaps and W assembly ---------------------------------------------------
         t0 = time.perf_counter()
-        ib = np.array([r["ib"] for r in prep_out])
-        ik = np.array([r["ik"] for r in prep_out])
-        mode = np.array([r["mode"] for r in prep_out])
-        mb = np.array([r["mb"] for r in prep_out])
-        mk = np.array([r["mk"] for r in prep_out])
-        ka = np.array([r["k"] for r in prep_out])
-        sbv = np.array([r["sb"] for r in prep_out])
-        skv = np.array([r["sk"] for r in prep_out])
+        mb, mk, ka = (souts[f].astype(np.int64) for f in ("mb", "mk", "k_always"))
+        sbv, skv = souts["sb"].astype(np.int64), souts["sk"].astype(np.int64)
         if int((sbv * skv).max()) * el > 64 * 1024:
             raise NotImplementedError("sometimes-matrix larger than the 64 KiB LDS stage of the determinant kernel")
         cb, ck = ncolV[ib], ncolV[ik]           # columns of V_bra / V_ket
@@ -431,13 +459,8 @@ class Engine:
         Vk_sub = Vp[ik] + np.where(mode == 1, 1, 0) * el     # right mode: physical orbital is row 0 of the ket block
         physp = Vp[ik] + np.where(mode == 1, 0, nb_rows) * el
         self.gemm(1, 1.0, 0.0, Vp[ib], Vk_sub, Op, cb, ck, nb_rows, ld1[ib], ld1[ik], np.maximum(cb, 1))
-        # selection arrays
-        rs_off, rs_tot = offsets(mb)
-        cs_off, cs_tot = offsets(mk)
-        row_sel = np.concatenate([r["row_sel"] for r in prep_out]).astype(np.int32)
-        col_sel = np.concatenate([r["col_sel"] for r in prep_out]).astype(np.int32)
-        row_sign = np.concatenate([r["row_sign"] for r in prep_out]).astype(np.int8)
-        col_sign = np.concatenate([r["col_sign"] for r in prep_out]).astype(np.int8)
+        # selection arrays (already flat, at the offsets given to the C++ call)
+        rs_off, cs_off = jobs["row_off"], jobs["col_off"]
         t_rs, t_cs, t_rg, t_cg = self._up(row_sel), self._up(col_sel), self._up(row_sign), self._up(col_sign)
         gd = np.zeros(L, nat.gather_desc)
         gd["src"], gd["dst"] = Op, Wp
@@ -458,50 +481,58 @@ class Engine:
 
         # ---- S4: all minors ----------------------------------------------------------------------
         t0 = time.perf_counter()
-        out_off, out_tot = offsets(np.array([r["out_elems"] for r in prep_out]))
-        pool_off, pool_tot = offsets(np.array([len(r["idx_pool"]) for r in prep_out]))
-        pool = np.concatenate([r["idx_pool"] for r in prep_out]) if pool_tot else np.zeros(1, np.uint8)
+        out_off, out_tot = offsets(souts["out_elems"])
         t_pool = self._up(pool)
         d_out = self._alloc(out_tot)
         Sp = Wp + (ka + ka * np.maximum(mb, 1)) * el
-        tiles = {8: [], 16: [], 32: [], 64: []}
-        lds_need = {8: 0, 16: 0, 32: 0, 64: 0}
-        a16 = lambda x: (x + 15) & ~15  # noqa: E731
-        for i, r in enumerate(prep_out):
-            for sec in r["sectors"]:
-                nq = int(sec["n"])
-                cls = 8 if nq <= 8 else 16 if nq <= 16 else 32 if nq <= 32 else 64
-                nsb, nsk = int(sec["r1"] - sec["r0"]), int(sec["c1"] - sec["c0"])
-                ta = max(1, min(nsb, _cdiv(4096, nsk)))
-                base = (Sp[i], detp[i], t_pool.data_ptr() + pool_off[i] + int(sec["bra_off"]),
-                        t_pool.data_ptr() + pool_off[i] + int(sec["ket_off"]),
-                        d_out.data_ptr() + (out_off[i] + int(sec["out_off"])) * el, int(sbv[i]), int(skv[i]),
-                        int(max(mb[i], 1)), nq, nsb, nsk)
-                lneed = a16(int(sbv[i]) * int(skv[i]) * el) + a16(nsk * nq) + a16(ta * nq) + (nq * nq * el if cls == 64 else 0)
-                lds_need[cls] = max(lds_need[cls], lneed)
-                for a0 in range(0, nsb, ta):
-                    tiles[cls].append(base + (a0, min(nsb, a0 + ta)))
+        nsec = souts["n_sectors"].astype(np.int64)
+        sec_site = np.repeat(np.arange(L), nsec)
+        sec_ptr = np.concatenate(([0], np.cumsum(nsec)))
+        sec_all = sec_buf[jobs["sec_off"][sec_site] + (np.arange(int(nsec.sum())) - sec_ptr[:-1][sec_site])]
         n_det = 0
-        for cls, tl in tiles.items():
-            if not tl:
-                continue
-            dd = np.zeros(len(tl), nat.det_desc)
-            arr = np.array(tl, dtype=np.int64)
-            for j, f in enumerate(("S", "scale", "bra_idx", "ket_idx", "out", "sb", "sk", "lds", "n", "nsb", "nsk", "a0", "a1")):
-                dd[f] = arr[:, j]
-            n_det += int(((dd["a1"] - dd["a0"]).astype(np.int64) * dd["nsk"]).sum())
-            # biggest tiles first
-            dd = dd[np.argsort(-((dd["a1"] - dd["a0"]).astype(np.int64) * dd["nsk"] * (dd["n"].astype(np.int64) + 1) ** 2), kind="stable")]
-            t_dd = self._up(dd)
-            flops = float((((dd["a1"] - dd["a0"]).astype(np.float64) * dd["nsk"]) * dd["n"].astype(np.float64) ** 3).sum())
-            flops *= (8.0 / 3.0) if cplx else (2.0 / 3.0)  # LU of an n x n complex / real matrix
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record(torch.cuda.current_stream(self.device))
-            nat.check(self.lib.tmf_det_gather_batched(self.dtype, cls, t_dd.data_ptr(), len(tl), int(lds_need[cls]) + 16,
-                                                      self.stream), "tmf_det_gather_batched")
-            ev1.record(torch.cuda.current_stream(self.device))
-            ndet_cls = int(((dd["a1"] - dd["a0"]).astype(np.int64) * dd["nsk"]).sum())
-            self.det_events.append((cls, ev0, ev1, flops, ndet_cls))
+        if len(sec_all):
+            nq = sec_all["n"].astype(np.int64)
+            nsb_ = (sec_all["r1"] - sec_all["r0"]).astype(np.int64)
+            nsk_ = (sec_all["c1"] - sec_all["c0"]).astype(np.int64)
+            cls_ = np.where(nq <= 8, 8, np.where(nq <= 16, 16, np.where(nq <= 32, 32, 64)))
+            ta = np.clip(_cdiv(4096, nsk_), 1, nsb_)
+            ntile = _cdiv(nsb_, ta)
+            tsec = np.repeat(np.arange(len(sec_all)), ntile)
+            tloc = np.arange(int(ntile.sum())) - np.repeat(np.cumsum(ntile) - ntile, ntile)
+            tsite = sec_site[tsec]
+            dd_all = np.zeros(len(tsec), nat.det_desc)
+            dd_all["S"], dd_all["scale"] = Sp[tsite], detp[tsite]
+            pbase = t_pool.data_ptr() + jobs["idx_off"][tsite]
+            dd_all["bra_idx"] = pbase + sec_all["bra_off"][tsec]
+            dd_all["ket_idx"] = pbase + sec_all["ket_off"][tsec]
+            dd_all["out"] = d_out.data_ptr() + (out_off[tsite] + sec_all["out_off"][tsec]) * el
+            dd_all["sb"], dd_all["sk"], dd_all["lds"] = sbv[tsite], skv[tsite], np.maximum(mb[tsite], 1)
+            dd_all["n"], dd_all["nsb"], dd_all["nsk"] = nq[tsec], nsb_[tsec], nsk_[tsec]
+            dd_all["a0"] = tloc * ta[tsec]
+            dd_all["a1"] = np.minimum(nsb_[tsec], dd_all["a0"] + ta[tsec])
+            a16 = lambda x: (x + 15) & ~15  # noqa: E731
+            tcls = cls_[tsec]
+            lneed = (a16(sbv[tsite] * skv[tsite] * el) + a16(nsk_[tsec] * nq[tsec]) + a16(ta[tsec] * nq[tsec])
+                     + np.where(tcls == 64, nq[tsec] ** 2 * el, 0))
+            pairs = (dd_all["a1"] - dd_all["a0"]).astype(np.int64) * dd_all["nsk"]
+            for cls in (8, 16, 32, 64):
+                selc = np.nonzero(tcls == cls)[0]
+                if selc.size == 0:
+                    continue
+                # biggest tiles first
+                selc = selc[np.argsort(-(pairs[selc] * (nq[tsec][selc] + 1) ** 2), kind="stable")]
+                dd = dd_all[selc]
+                t_dd = self._up(dd)
+                flops = float((pairs[selc].astype(np.float64) * nq[tsec][selc].astype(np.float64) ** 3).sum())
+                flops *= (8.0 / 3.0) if cplx else (2.0 / 3.0)  # LU of an n x n complex / real matrix
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(torch.cuda.current_stream(self.device))
+                nat.check(self.lib.tmf_det_gather_batched(self.dtype, cls, t_dd.data_ptr(), len(dd),
+                                                          int(lneed[selc].max()) + 16, self.stream),
+                          "tmf_det_gather_batched")
+                ev1.record(torch.cuda.current_stream(self.device))
+                self.det_events.append((cls, ev0, ev1, flops, int(pairs[selc].sum())))
+                n_det += int(pairs[selc].sum())
         self.n_det = n_det
         self._tick("S_determinants", t0)
         self.d_out = d_out  # device-resident result
@@ -516,17 +547,19 @@ class Engine:
         h_out = d_out.cpu().numpy()
         h_det = d_det.cpu().numpy()
         sites = [None] * s_lo
-        for j, r in enumerate(prep_out):
-            i = my_sites[j]
-            m_ = "left" if r["mode"] == 0 else "right"
-            bb, kb = (i, i + 1) if r["mode"] == 0 else (i + 1, i)
+        for j in range(L):
+            i = int(my_sites[j])
+            m_ = "left" if mode[j] == 0 else "right"
+            secs = sec_all[sec_ptr[j]: sec_ptr[j + 1]]
             blocks = []
-            for sec in r["sectors"]:
+            for sec in secs:
                 r0, r1, c0, c1 = (int(sec[f]) for f in ("r0", "r1", "c0", "c1"))
                 o = out_off[j] + int(sec["out_off"])
                 blocks.append((int(sec["q"]), r0, r1, c0, c1, h_out[o: o + (r1 - r0) * (c1 - c0)].reshape(r1 - r0, c1 - c0)))
-            sites.append(SiteData(mode=m_, det_always=h_det[j], qtotal=0, bra_p=r["bra_p"], bra_alpha=r["bra_alpha"],
-                                  blocks=blocks, chi_bra=bonds[bb].chi, chi_ket=bonds[kb].chi))
+            bo = int(jobs["bra_off"][j])
+            sites.append(SiteData(mode=m_, det_always=h_det[j], qtotal=0, bra_p=bra_p[bo: bo + 2 * int(chi_b[j])],
+                                  bra_alpha=bra_alpha[bo: bo + 2 * int(chi_b[j])], blocks=blocks,
+                                  chi_bra=int(chi_b[j]), chi_ket=int(chi_k[j])))
         sites += [None] * (L_all - s_hi)
         self._tick("download", t0)
         self.timings["total"] = time.perf_counter() - t_all

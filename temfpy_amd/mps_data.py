@@ -18,7 +18,7 @@ class BondData:
     e: np.ndarray            # entangled eigenvalues of C_LL, descending (SchmidtModes.e)
     n_filled_left: int
     n_filled_right: int
-    sets: np.ndarray         # (chi, k) bool: entangled orbital occupied on the left
+    masks: np.ndarray        # (chi, 2) uint64: bit i <-> entangled orbital i occupied on the left
     lam_raw: np.ndarray      # unnormalised Schmidt values (SchmidtVectors.schmidt_values)
     lam: np.ndarray          # normalised (utils.normalize_SV)
     q_left: np.ndarray       # particles to the left of the cut, ascending
@@ -27,6 +27,15 @@ class BondData:
     @property
     def chi(self):
         return len(self.lam)
+
+    @property
+    def sets(self):
+        """(chi, k) bool array as ``SchmidtVectors`` stores it (slater.py:438-443)."""
+        k = len(self.e)
+        out = np.zeros((len(self.masks), k), bool)
+        for i in range(k):
+            out[:, i] = (self.masks[:, i // 64] >> np.uint64(i % 64)) & np.uint64(1)
+        return out
 
     @property
     def idx_L(self):
