@@ -117,10 +117,13 @@ typedef struct {
   int32_t nsb, nsk, a0, a1;  /* this tile handles bra rows [a0, a1), all ket rows   */
 } tmf_det_desc;              /* 72 bytes */
 
-/* n_class in {8, 16, 32, 64}: every tile of the launch has n <= n_class (8/16/32 lanes own one
- * determinant; 64 = LDS-resident fallback).  lds_bytes = dynamic LDS per workgroup:
- * align16(sb*sk*elem) + align16(nsk*n) + align16((a1-a0)*n) [+ n*n*elem for class 64], max over tiles. */
-int tmf_det_gather_batched(int dtype, int n_class, const tmf_det_desc* d_desc, int ntiles, int lds_bytes,
+/* `order` = the exact order n of every minor of the launch for 0 <= n <= 32 (one straight-line
+ * kernel per order: 8 / 16 / 32 lanes own one determinant), or 64 = generic LDS-resident kernel
+ * for 33 <= n <= 64 (n read from the descriptor).  lds_bytes = dynamic LDS per workgroup:
+ * align16(sb*sk*elem) + align16(nsk*n) + align16((a1-a0)*n)
+ *   + 4 * ((n|1)*sk + gpw*(n+1)) * elem      (gpw = 8, 4, 2 groups per wavefront for n <= 8, 16, 32)
+ * or + n*n*elem for order 64; max over the tiles of the launch. */
+int tmf_det_gather_batched(int dtype, int order, const tmf_det_desc* d_desc, int ntiles, int lds_bytes,
                            void* stream);
 
 /* ---- small device utilities ------------------------------------------------------ */

@@ -7,8 +7,8 @@
 
 namespace tmf {
 
-struct cd {  // complex double, interleaved like numpy complex128
-  double x, y;
+struct __attribute__((aligned(16))) cd {  // complex double, interleaved like numpy complex128
+  double x, y;                            // 16-byte aligned: one dwordx4 / ds_*_b128 per element
 };
 
 __host__ __device__ inline cd make_cd(double x, double y) {
@@ -38,6 +38,12 @@ struct sc<double> {
   __device__ static inline double abs2(double a) { return a * a; }
   __device__ static inline double scale(double a, double s) { return a * s; }
   __device__ static inline double inv(double a) { return 1.0 / a; }
+  __device__ static inline double inv_fast(double a) {
+    double r = __builtin_amdgcn_rcp(a);
+    r = fma(fma(-a, r, 1.0), r, r);
+    r = fma(fma(-a, r, 1.0), r, r);
+    return r;
+  }
   __device__ static inline double real(double a) { return a; }
   __device__ static inline double from_real(double a) { return a; }
   __device__ static inline double neg(double a) { return -a; }
@@ -67,6 +73,14 @@ struct sc<cd> {
   __device__ static inline cd inv(cd a) {
     double d = 1.0 / fma(a.x, a.x, a.y * a.y);
     return make_cd(a.x * d, -a.y * d);
+  }
+  // 1/a with v_rcp_f64 + two Newton steps (no denormal / inf fix-ups: pivots are O(1e-300..1e300))
+  __device__ static inline cd inv_fast(cd a) {
+    const double q = fma(a.x, a.x, a.y * a.y);
+    double r = __builtin_amdgcn_rcp(q);
+    r = fma(fma(-q, r, 1.0), r, r);
+    r = fma(fma(-q, r, 1.0), r, r);
+    return make_cd(a.x * r, -a.y * r);
   }
   __device__ static inline double real(cd a) { return a.x; }
   __device__ static inline cd from_real(double a) { return make_cd(a, 0.0); }

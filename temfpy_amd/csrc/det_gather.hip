@@ -14,104 +14,146 @@
 
 namespace tmf {
 
-__device__ inline double sel(bool m, double a, double b) { return m ? a : b; }
-__device__ inline cd sel(bool m, cd a, cd b) { return make_cd(m ? a.x : b.x, m ? a.y : b.y); }
-
-// One determinant per G-lane group, column c of the minor in registers of lane c.
-template <typename T, int NMAX, int G>
-__device__ inline T det_group(T (&a)[NMAX], const int n, const int c) {
-  T det = sc<T>::one();
-#pragma unroll
-  for (int j = 0; j < NMAX; ++j) {
-    if (j < n) {  // wave-uniform: every determinant of a sector has the same order
-      // pivot search in column j (every lane scans its own column; lane j's answer counts)
-      int best = j;
-      double bv = sc<T>::abs2(a[j]);
-#pragma unroll
-      for (int r = j + 1; r < NMAX; ++r) {
-        const double v = sc<T>::abs2(a[r]);
-        if (r < n && v > bv) {
-          bv = v;
-          best = r;
-        }
-      }
-      const int piv = __shfl(best, j, G);
-      // row swap j <-> piv in every column, as selects (a runtime-indexed register array
-      // would be demoted to scratch: cdna_hip_programming.md section 5.4 rule 20)
-      {
-        const T aj = a[j];
-        T nj = aj;
-#pragma unroll
-        for (int r = j + 1; r < NMAX; ++r) {
-          const bool m = (r == piv);
-          const T ar = a[r];
-          nj = sel(m, ar, nj);
-          a[r] = sel(m, aj, ar);
-        }
-        a[j] = nj;
-      }
-      const T p = shfl_t<T>(a[j], j, G);
-      det = sc<T>::mul(det, p);
-      if (piv != j) det = sc<T>::neg(det);
-      const T pinv = sc<T>::abs2(p) > 0.0 ? sc<T>::inv(p) : sc<T>::zero();
-      const T pc = sc<T>::mul(pinv, a[j]);  // pivot-row entry of this column / pivot
-#pragma unroll
-      for (int r = j + 1; r < NMAX; ++r) {
-        if (r < n) {
-          const T l = shfl_t<T>(a[r], j, G);  // column-j entry below the pivot
-          a[r] = sc<T>::fms(a[r], l, pc);
-        }
-      }
+// max over the G lanes of a group, result in every lane.  Rows of 16 lanes use DPP
+// (quad_perm xor 1, xor 2, then row rotations), no LDS traffic.
+template <int G>
+__device__ inline unsigned group_max(unsigned k) {
+  unsigned o;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+  k = o > k ? o : k;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+  k = o > k ? o : k;
+  if (G == 8) {
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    k = o > k ? o : k;
+  } else {
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x124, 0xF, 0xF, false);  // row_ror:4
+    k = o > k ? o : k;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x128, 0xF, 0xF, false);  // row_ror:8
+    k = o > k ? o : k;
+    if (G == 32) {
+      o = (unsigned)__shfl_xor((int)k, 16, 32);
+      k = o > k ? o : k;
     }
+  }
+  return k;
+}
+
+// One determinant per G-lane group: lane c holds column c of the N x N minor in registers
+// (N is a template parameter: straight-line code, no predicates on the row index).
+// Gaussian elimination by COLUMN operations with column pivoting: at step j the pivot is the
+// largest |entry| of row j among the unused columns, so "swapping" is a change of lane roles
+// and costs nothing (a row swap would need a select chain over a register array).  The pivot
+// column is handed to the other lanes through a per-group LDS scratch (one ds_read_b128 per
+// element instead of four ds_bpermute).  det = prod(pivots) * sign(permutation).
+template <typename T, int N, int G>
+__device__ inline T det_group(T (&a)[N], const int c, T* __restrict__ scratch) {
+  T det = sc<T>::one();
+  unsigned used = 0u;         // columns already used as pivots (uniform inside the group)
+  bool mine_used = c >= N;    // padding lanes never take part
+  constexpr unsigned valid = (N >= 32) ? 0xffffffffu : ((1u << N) - 1u);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    // pivot = arg max |a[j]| over unused lanes; key = (float bits >> 1, lane), max-reduced
+    unsigned key = 0u;
+    if (!mine_used) {
+      const float m = (float)sc<T>::abs2(a[j]);
+      key = ((__float_as_uint(m) >> 1) & ~(unsigned)(G - 1)) | (unsigned)c | 0x80000000u;
+    }
+    key = group_max<G>(key);
+    const int piv = (int)(key & (unsigned)(G - 1));
+    const bool is_piv = (c == piv);
+    if (is_piv) {
+#pragma unroll
+      for (int r = j; r < N; ++r) scratch[r] = a[r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const T p = scratch[j];
+    det = sc<T>::mul(det, p);
+    if (__popc(~used & ((1u << piv) - 1u) & valid) & 1) det = sc<T>::neg(det);
+    used |= 1u << piv;
+    mine_used = mine_used || is_piv;
+    const T pinv = sc<T>::abs2(p) > 0.0 ? sc<T>::inv_fast(p) : sc<T>::zero();
+    const T m = sc<T>::mul(a[j], pinv);
+#pragma unroll
+    for (int r = j + 1; r < N; ++r) a[r] = sc<T>::fms(a[r], m, scratch[r]);
+    __builtin_amdgcn_wave_barrier();  // next step's pivot column overwrites the scratch
   }
   return det;
 }
 
-// LDS layout (dynamic): [ M : sb*sk T ][ ket idx : nsk*n u8 ][ bra idx : (a1-a0)*n u8 ]
-template <typename T, int NMAX, int G>
+// LDS layout (dynamic):
+//   [ M : sb*sk T ][ ket idx : nsk*N u8 ][ bra idx : (a1-a0)*N u8 ]
+//   [ per wave: Ma = M[rows(a), :]  (N|1)*sk T ][ per group: scratch N+1 T ]
+// Each wavefront takes one bra row-set a at a time, gathers its N rows of M once, and its
+// 64/G groups then sweep the ket sets b; the only HBM traffic is one result per determinant.
+// Column stride of Ma is odd (N|1) and the scratch stride is N+1 so that the 16-lane phases
+// of ds_read_b128 fall on distinct banks.
+template <typename T, int N, int G>
 __global__ __launch_bounds__(256) void det_kernel(const tmf_det_desc* __restrict__ desc) {
   extern __shared__ __align__(16) unsigned char smem[];
   const tmf_det_desc d = desc[blockIdx.x];
-  const int n = d.n;
+  constexpr int NS = N | 1;
   const int na = d.a1 - d.a0;
+  const int sk = d.sk;
   T* Ms = reinterpret_cast<T*>(smem);
-  const size_t mbytes = ((size_t)d.sb * d.sk * sizeof(T) + 15) & ~(size_t)15;
+  const size_t mbytes = ((size_t)d.sb * sk * sizeof(T) + 15) & ~(size_t)15;
   uint8_t* kidx = smem + mbytes;
-  uint8_t* bidx = kidx + (((size_t)d.nsk * n + 15) & ~(size_t)15);
+  uint8_t* bidx = kidx + (((size_t)d.nsk * N + 15) & ~(size_t)15);
+  T* wbase = reinterpret_cast<T*>(bidx + (((size_t)na * N + 15) & ~(size_t)15));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int GPW = 64 / G;  // groups per wavefront
+  T* Ma = wbase + (size_t)wave * ((size_t)NS * sk + GPW * (N + 1));
+  T* scratch = Ma + (size_t)NS * sk + (size_t)(lane / G) * (N + 1);
 
   const T* __restrict__ S = reinterpret_cast<const T*>(d.S);
-  for (int e = threadIdx.x; e < d.sb * d.sk; e += 256) {
+  for (int e = threadIdx.x; e < d.sb * sk; e += 256) {
     const int r = e % d.sb, c = e / d.sb;
     Ms[e] = S[(size_t)r + (size_t)c * d.lds];
   }
   const uint8_t* __restrict__ gk = reinterpret_cast<const uint8_t*>(d.ket_idx);
-  const uint8_t* __restrict__ gb = reinterpret_cast<const uint8_t*>(d.bra_idx) + (size_t)d.a0 * n;
-  for (int e = threadIdx.x; e < d.nsk * n; e += 256) kidx[e] = gk[e];
-  for (int e = threadIdx.x; e < na * n; e += 256) bidx[e] = gb[e];
+  const uint8_t* __restrict__ gb = reinterpret_cast<const uint8_t*>(d.bra_idx) + (size_t)d.a0 * N;
+  for (int e = threadIdx.x; e < d.nsk * N; e += 256) kidx[e] = gk[e];
+  for (int e = threadIdx.x; e < na * N; e += 256) bidx[e] = gb[e];
   __syncthreads();
 
   const T scale = *reinterpret_cast<const T*>(d.scale);
   T* __restrict__ out = reinterpret_cast<T*>(d.out);
-  constexpr int NG = 256 / G;
-  const int grp = threadIdx.x / G, c = threadIdx.x % G;
-  const int npairs = na * d.nsk;
-  // all groups of a wave iterate the same number of times (shuffles need the whole wave)
-  const int iters = (npairs + NG - 1) / NG;
-  for (int it = 0; it < iters; ++it) {
-    const int p = it * NG + grp;
-    const bool live = p < npairs;
-    const int al = live ? p / d.nsk : 0, b = live ? p % d.nsk : 0;
-    T a[NMAX];
-    const int col = (c < n) ? kidx[b * n + c] : 0;
-#pragma unroll
-    for (int r = 0; r < NMAX; ++r) {
-      T v = sc<T>::zero();
-      if (r < n && c < n) v = Ms[bidx[al * n + r] + col * d.sb];
-      a[r] = v;
+  const int grp = lane / G, c = lane % G;
+  for (int al = wave; al < na; al += 4) {
+    // gather the N rows of this bra set: Ma[r + col*NS] = M[rows_a[r], col]
+    const uint8_t* rows = bidx + al * N;
+    for (int e = lane; e < N * sk; e += 64) {
+      const int r = e % N, col = e / N;
+      Ma[r + col * NS] = Ms[rows[r] + col * d.sb];
     }
-    const T det = det_group<T, NMAX, G>(a, n, c);
-    if (live && c == 0) out[(size_t)(d.a0 + al) * d.nsk + b] = sc<T>::mul(scale, det);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    T* __restrict__ orow = out + (size_t)(d.a0 + al) * d.nsk;
+    for (int b0 = 0; b0 < d.nsk; b0 += GPW) {
+      const int b = b0 + grp;
+      const bool live = b < d.nsk;
+      const T* colp = Ma + ((live && c < N) ? (int)kidx[b * N + c] * NS : 0);
+      T a[N];
+#pragma unroll
+      for (int r = 0; r < N; ++r) a[r] = colp[r];
+      const T det = det_group<T, N, G>(a, c, scratch);
+      if (live && c == 0) orow[b] = sc<T>::mul(scale, det);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
+}
+
+// n = 0: every "minor" is the empty determinant 1
+template <typename T>
+__global__ __launch_bounds__(256) void det_fill_kernel(const tmf_det_desc* __restrict__ desc) {
+  const tmf_det_desc d = desc[blockIdx.x];
+  const T scale = *reinterpret_cast<const T*>(d.scale);
+  T* __restrict__ out = reinterpret_cast<T*>(d.out) + (size_t)d.a0 * d.nsk;
+  for (int e = threadIdx.x; e < (d.a1 - d.a0) * d.nsk; e += 256) out[e] = scale;
 }
 
 // Fallback for 32 < n <= 64: one determinant per wave, minor held in LDS.
@@ -175,24 +217,39 @@ __global__ __launch_bounds__(64) void det_lds_kernel(const tmf_det_desc* __restr
   }
 }
 
+template <typename T, int N>
+static void launch_exact(dim3 g, int lds, hipStream_t s, const tmf_det_desc* d) {
+  constexpr int G = N <= 8 ? 8 : (N <= 16 ? 16 : 32);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)det_kernel<T, N, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((det_kernel<T, N, G>), g, dim3(256), lds, s, d);
+}
+
 template <typename T>
-static int launch_det(int n_class, const tmf_det_desc* d, int nt, int lds, hipStream_t s) {
+static int launch_det(int n, const tmf_det_desc* d, int nt, int lds, hipStream_t s) {
   dim3 g(nt);
-  switch (n_class) {
-    case 8:
-      hipLaunchKernelGGL((det_kernel<T, 8, 8>), g, dim3(256), lds, s, d);
-      break;
-    case 16:
-      hipLaunchKernelGGL((det_kernel<T, 16, 16>), g, dim3(256), lds, s, d);
-      break;
-    case 32:
-      hipLaunchKernelGGL((det_kernel<T, 32, 32>), g, dim3(256), lds, s, d);
-      break;
-    case 64:
+  switch (n) {
+    case 0: hipLaunchKernelGGL((det_fill_kernel<T>), g, dim3(256), 0, s, d); break;
+#define TMF_CASE(N) case N: launch_exact<T, N>(g, lds, s, d); break;
+    TMF_CASE(1) TMF_CASE(2) TMF_CASE(3) TMF_CASE(4) TMF_CASE(5) TMF_CASE(6) TMF_CASE(7) TMF_CASE(8)
+    TMF_CASE(9) TMF_CASE(10) TMF_CASE(11) TMF_CASE(12) TMF_CASE(13) TMF_CASE(14) TMF_CASE(15) TMF_CASE(16)
+    TMF_CASE(17) TMF_CASE(18) TMF_CASE(19) TMF_CASE(20) TMF_CASE(21) TMF_CASE(22) TMF_CASE(23) TMF_CASE(24)
+    TMF_CASE(25) TMF_CASE(26) TMF_CASE(27) TMF_CASE(28) TMF_CASE(29) TMF_CASE(30) TMF_CASE(31) TMF_CASE(32)
+#undef TMF_CASE
+    case 64: {
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void*)det_lds_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+      }
       hipLaunchKernelGGL((det_lds_kernel<T>), g, dim3(64), lds, s, d);
       break;
+    }
     default:
-      set_error("tmf_det_gather_batched: n_class must be 8, 16, 32 or 64, got %d", n_class);
+      set_error("tmf_det_gather_batched: order must be 0..32 (exact) or 64 (generic), got %d", n);
       return TMF_E_ARG;
   }
   return check_hip(hipGetLastError(), "tmf_det_gather_batched launch");
@@ -200,7 +257,7 @@ static int launch_det(int n_class, const tmf_det_desc* d, int nt, int lds, hipSt
 
 }  // namespace tmf
 
-extern "C" int tmf_det_gather_batched(int dtype, int n_class, const tmf_det_desc* d_desc, int ntiles, int lds_bytes,
+extern "C" int tmf_det_gather_batched(int dtype, int order, const tmf_det_desc* d_desc, int ntiles, int lds_bytes,
                                       void* stream) {
   if (ntiles <= 0) return TMF_OK;
   if (lds_bytes < 0 || lds_bytes > 160 * 1024) {
@@ -208,22 +265,8 @@ extern "C" int tmf_det_gather_batched(int dtype, int n_class, const tmf_det_desc
     return TMF_E_LIMIT;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  static bool attr_done = false;
-  if (!attr_done) {  // allow > 64 KiB of dynamic LDS
-    using namespace tmf;
-    const int big = 160 * 1024;
-    (void)hipFuncSetAttribute((const void*)det_kernel<cd, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)det_kernel<cd, 16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)det_kernel<cd, 32, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)det_lds_kernel<cd>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)det_kernel<double, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)det_kernel<double, 16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)det_kernel<double, 32, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void*)det_lds_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    attr_done = true;
-  }
-  if (dtype == TMF_C128) return tmf::launch_det<tmf::cd>(n_class, d_desc, ntiles, lds_bytes, s);
-  if (dtype == TMF_F64) return tmf::launch_det<double>(n_class, d_desc, ntiles, lds_bytes, s);
+  if (dtype == TMF_C128) return tmf::launch_det<tmf::cd>(order, d_desc, ntiles, lds_bytes, s);
+  if (dtype == TMF_F64) return tmf::launch_det<double>(order, d_desc, ntiles, lds_bytes, s);
   tmf::set_error("tmf_det_gather_batched: bad dtype %d", dtype);
   return TMF_E_ARG;
 }

@@ -494,7 +494,7 @@ class Engine:
             nq = sec_all["n"].astype(np.int64)
             nsb_ = (sec_all["r1"] - sec_all["r0"]).astype(np.int64)
             nsk_ = (sec_all["c1"] - sec_all["c0"]).astype(np.int64)
-            cls_ = np.where(nq <= 8, 8, np.where(nq <= 16, 16, np.where(nq <= 32, 32, 64)))
+            cls_ = np.where(nq <= 32, nq, 64)  # exact order for n <= 32 (templated kernels), generic above
             ta = np.clip(_cdiv(4096, nsk_), 1, nsb_)
             ntile = _cdiv(nsb_, ta)
             tsec = np.repeat(np.arange(len(sec_all)), ntile)
@@ -512,10 +512,14 @@ class Engine:
             dd_all["a1"] = np.minimum(nsb_[tsec], dd_all["a0"] + ta[tsec])
             a16 = lambda x: (x + 15) & ~15  # noqa: E731
             tcls = cls_[tsec]
+            # LDS per workgroup (det_gather.hip): M, index lists, then per wave the gathered rows
+            # M[rows(a), :] (n*sk) + 64 scratch elements; class 64 instead holds one n x n minor
+            gpw = np.where(nq[tsec] <= 8, 8, np.where(nq[tsec] <= 16, 4, 2))
             lneed = (a16(sbv[tsite] * skv[tsite] * el) + a16(nsk_[tsec] * nq[tsec]) + a16(ta[tsec] * nq[tsec])
-                     + np.where(tcls == 64, nq[tsec] ** 2 * el, 0))
+                     + np.where(tcls == 64, nq[tsec] ** 2 * el,
+                                4 * ((nq[tsec] | 1) * skv[tsite] + gpw * (nq[tsec] + 1)) * el))
             pairs = (dd_all["a1"] - dd_all["a0"]).astype(np.int64) * dd_all["nsk"]
-            for cls in (8, 16, 32, 64):
+            for cls in sorted(set(tcls.tolist()), key=lambda c_: -int(pairs[tcls == c_].sum())):
                 selc = np.nonzero(tcls == cls)[0]
                 if selc.size == 0:
                     continue

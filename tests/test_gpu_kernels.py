@@ -204,7 +204,7 @@ def test_lu_schur(eng, cplx):
 
 
 @pytest.mark.parametrize("cplx", [True, False])
-@pytest.mark.parametrize("n,cls", [(0, 8), (1, 8), (5, 8), (8, 8), (9, 16), (13, 16), (16, 16), (19, 32), (32, 32), (40, 64)])
+@pytest.mark.parametrize("n,cls", [(0, 0), (1, 1), (2, 2), (5, 5), (8, 8), (9, 9), (12, 12), (13, 13), (16, 16), (17, 17), (19, 19), (25, 25), (32, 32), (40, 64)])
 def test_det_gather(eng, cplx, n, cls):
     setup(eng, cplx)
     nat = eng.nat
@@ -226,7 +226,8 @@ def test_det_gather(eng, cplx, n, cls):
         dd[j] = (dS_[1], dsc[1], tb.data_ptr(), tk.data_ptr(), out.data_ptr(), sb, sk, sb, n, nsb, nsk, j * ta,
                  min(nsb, (j + 1) * ta))
     a16 = lambda x: (x + 15) & ~15  # noqa: E731
-    lds = a16(sb * sk * eng.elem) + a16(nsk * n) + a16(ta * n) + (n * n * eng.elem if cls == 64 else 0) + 16
+    gpw = 8 if n <= 8 else 4 if n <= 16 else 2
+    lds = a16(sb * sk * eng.elem) + a16(nsk * n) + a16(ta * n) + (n * n * eng.elem if cls == 64 else 4 * ((n | 1) * sk + gpw * (n + 1)) * eng.elem) + 16
     t = eng._up(dd)
     nat.check(eng.lib.tmf_det_gather_batched(eng.dtype, cls, t.data_ptr(), len(dd), lds, eng.stream), "det")
     torch.cuda.synchronize()
@@ -254,7 +255,7 @@ def test_det_gather_singular_minor_is_zero(eng):
     dd = np.zeros(1, nat.det_desc)
     dd[0] = (dS_[1], dsc[1], tb.data_ptr(), tk.data_ptr(), out.data_ptr(), 4, 4, 4, 2, 2, 2, 0, 2)
     t = eng._up(dd)
-    nat.check(eng.lib.tmf_det_gather_batched(eng.dtype, 8, t.data_ptr(), 1, 1024, eng.stream), "det")
+    nat.check(eng.lib.tmf_det_gather_batched(eng.dtype, 2, t.data_ptr(), 1, 8192, eng.stream), "det")
     torch.cuda.synchronize()
     assert np.all(out.cpu().numpy() == 0)
 
