@@ -291,28 +291,26 @@ class Engine:
         csum = np.concatenate(([0.0], np.cumsum(diag)))
         n_fermion = int(np.round(csum[-1]))  # slater.py:414
         tr = np.where(cs_side == 0, csum[cs_b], csum[-1] - csum[cs_b])
-        k = np.zeros(ncs, np.int64)
-        ent0 = np.zeros(ncs, np.int64)  # first entangled column inside U_E
-        e_side = [np.zeros(0)] * ncs
-        for i in range(ncs):
-            if not doE[i]:
-                continue
-            if h_cnt[i] >= p[i] and p[i] == P and P < min(n[i], m[i]):
-                raise NotImplementedError(
-                    f"cut {cs_b[i]}: more than {P - 1} orbitals above the range-finder threshold; "
-                    f"entanglement rank beyond the compiled limit of the LDS Jacobi kernel")
-            ev = h_e[oS[i]: oS[i] + h_cnt[i]]
-            x_hi = int(np.sum(ev >= 1 - cutoff))          # kept but 'filled' by slater.py:350
-            x_lo = int(np.sum(ev < cutoff))
-            ent0[i] = x_hi
-            k[i] = len(ev) - x_hi - x_lo
-            e_side[i] = ev[x_hi: x_hi + k[i]].copy()
+        # kept Ritz values per cut side as a padded 2-D array (descending inside each row)
+        colP = np.arange(P)
+        valid = colP[None, :] < h_cnt[:, None]
+        E2 = np.where(valid, h_e[np.minimum(oS[:, None] + colP[None, :], max(len(h_e) - 1, 0))], 0.0)
+        sat = doE & (h_cnt >= p) & (p == P) & (P < np.minimum(n, m))
+        if np.any(sat):
+            raise NotImplementedError(
+                f"cut {cs_b[np.nonzero(sat)[0][0]]}: more than {P - 1} orbitals above the range-finder threshold; "
+                f"entanglement rank beyond the compiled limit of the LDS Jacobi kernel")
+        x_hi = np.sum(valid & (E2 >= 1 - cutoff), axis=1)   # kept but 'filled' by slater.py:350
+        x_lo = np.sum(valid & (E2 < cutoff), axis=1)
+        ent0 = np.where(doE, x_hi, 0)                        # first entangled column inside U_E
+        k = np.where(doE, h_cnt - x_hi - x_lo, 0).astype(np.int64)
+        e_side = [E2[i, ent0[i]: ent0[i] + k[i]].copy() for i in range(ncs)]
         # centre: right-side eigenvalues are 1 - e_L reversed (slater.py:386 convention)
         if has_centre:
             k[centre_R] = k[centre_L]
             e_side[centre_R] = (1.0 - e_side[centre_L])[::-1].copy()
         nf = np.array([int(np.round(tr[i] - e_side[i].sum())) for i in range(ncs)])
-        nf = np.clip(nf, 0, n - k)
+        nf = np.clip(nf, 0, n - k).astype(np.int64)
         self._tick("host_classify", t0)
 
         # ---- F: orbital matrices V = [U_E (k) | Q_f (nf)] -------------------------------------

@@ -181,3 +181,75 @@ def test_argument_errors_match_reference():
         slater.C_to_MPS(C, [1, 2])
     with pytest.raises(AssertionError):
         slater.C_to_MPS(C, {"chi_max": 0})
+
+
+def test_site_sharding_reproduces_unsharded_result_bitwise():
+    """Multi-GPU path (bench.py --gpus N): every rank converts a contiguous site range and
+    recomputes the cut on its boundary.  The kernels are deterministic, so shards must
+    reproduce the single-GPU tensors bit for bit (checked here on one GPU, shard by shard)."""
+    from tests_inputs import random_hopping
+    from temfpy_amd.engine import Engine
+    from temfpy_amd.schmidt_utils import to_stopping_condition
+    import bench
+
+    L, chi = 48, 32
+    C, _ = orc.correlation_matrix(random_hopping(L, 5))
+    tr = to_stopping_condition({"chi_max": chi})
+    eng = Engine("cuda:0")
+    full = eng.run(C, tr, L // 2, L)
+    for world in (2, 3, 4):
+        ranges = bench.shard_sites(L, L // 2, world)
+        assert ranges[0][0] == 0 and ranges[-1][1] == L
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        for (lo, hi) in ranges:
+            part = eng.run(C, tr, L // 2, L, site_range=(lo, hi))
+            for i in range(lo, hi):
+                assert len(part.sites[i].blocks) == len(full.sites[i].blocks)
+                for bp, bf in zip(part.sites[i].blocks, full.sites[i].blocks):
+                    assert bp[:5] == bf[:5]
+                    assert np.array_equal(bp[5], bf[5])
+            for b in range(lo, hi + 1):
+                assert np.array_equal(part.bonds[b].lam, full.bonds[b].lam)
+                assert np.array_equal(part.bonds[b].masks, full.bonds[b].masks)
+
+
+def test_real_dtype_path_matches_complex_path():
+    """A real correlation matrix takes the float64 kernels; promoted to complex it must give the
+    same Schmidt data and the same state."""
+    from tests_inputs import uniform_chain
+
+    L, chi = 40, 64
+    C, _ = orc.correlation_matrix(uniform_chain(L) + np.diag(0.3 * np.cos(1.7 * np.arange(L))))
+    assert not np.iscomplexobj(C)
+    m_r = run_hip(C, chi)
+    m_c = run_hip(C.astype(complex), chi)
+    assert m_r.sites[3].blocks[0][5].dtype == np.float64 and m_c.sites[3].blocks[0][5].dtype == np.complex128
+    for b in range(L + 1):
+        np.testing.assert_array_equal(m_r.bonds[b].masks, m_c.bonds[b].masks)
+        np.testing.assert_allclose(m_r.bonds[b].lam, m_c.bonds[b].lam, rtol=0, atol=1e-9)  # weak orbitals: e ~ 1e-11 +- 1e-16
+    T1, T2 = m_r.dense_tensors(), m_c.dense_tensors()
+    oc = L // 2
+    ov = abs(orc.mps_overlap(T1, m_r.lam[oc], T2, m_c.lam[oc], oc))
+    n1 = abs(orc.mps_overlap(T1, m_r.lam[oc], T1, m_r.lam[oc], oc))
+    assert abs(ov / n1 - 1) < 1e-9
+    cuts, sites = orc.c_to_mps(C, {"chi_max": chi})
+    assert abs(1 - overlap(cuts, sites, m_r, oc)) < 1e-9
+
+
+def test_sector_filter_and_unlimited_chi():
+    """trunc_par.sectors (schmidt_utils.py:22-32) and chi_max=None (svd_min-limited)."""
+    from tests_inputs import random_hopping
+    from temfpy_amd import slater
+
+    L = 12
+    C, N = orc.correlation_matrix(random_hopping(L, 9))
+    mps = slater.C_to_MPS(C, {"chi_max": None}, as_tenpy=False)
+    cuts, sites = orc.c_to_mps(C, {"chi_max": None})
+    for b in range(L + 1):
+        np.testing.assert_array_equal(mps.bonds[b].sets, cuts[b].sets)
+    assert abs(1 - overlap(cuts, sites, mps, L // 2)) < 1e-9
+    # untruncated up to svd_min: the MPS reproduces C (src/examples/slater.py:30-36)
+    G = orc.mps_correlation(mps.dense_tensors(), mps.lam[L // 2], L // 2)
+    np.testing.assert_allclose(G, C, atol=1e-8)
+    with pytest.raises(ValueError):
+        slater.C_to_MPS(C, {"chi_max": 8, "sectors": [L + 5]}, as_tenpy=False)
