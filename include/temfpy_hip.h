@@ -59,14 +59,17 @@ int tmf_gemm_batched(int dtype, int opA, double alpha, double beta, const tmf_ge
 
 /* Orthonormalise the columns [c0, c0+w) of A (n x *) in place against themselves
  * (classical Gram-Schmidt, twice), one workgroup per problem, panel staged in LDS.
- * Columns whose norm collapses (numerical rank deficiency) are replaced by a unit
- * vector orthogonal to the panel so that the result is always orthonormal.
+ * With `norms` given, a column whose residual is below 1e-14 of its original norm (pure
+ * rounding noise: the column is numerically dependent on the previous ones) is set to ZERO
+ * instead of being normalised; downstream such a column carries singular value 0.
  * Building block of the blocked QR that orthonormalises orbital slabs (the
  * orthonormal eigenvector blocks of slater.py:347). */
 typedef struct {
   uint64_t A;                /* device address of the first panel column            */
+  uint64_t norms;            /* 0, or device address of w doubles: the norms the panel's columns
+                                had BEFORE any projection (tmf_column_norms_batched)  */
   int32_t n, w, lda, pad;
-} tmf_panel_desc;            /* 24 bytes */
+} tmf_panel_desc;            /* 32 bytes */
 
 int tmf_orth_panel_batched(int dtype, const tmf_panel_desc* d_desc, int nprob, int max_n, int max_w,
                            void* stream);
@@ -143,6 +146,13 @@ typedef struct {
   int32_t rows, cols, lds_, ldd, ldp, pad;
 } tmf_gather_desc;           /* 80 bytes */
 int tmf_gather_signed_batched(int dtype, const tmf_gather_desc* d_desc, int nprob, void* stream);
+
+/* out[j] = 2-norm of column j of src (n x c) */
+typedef struct {
+  uint64_t src, out;
+  int32_t n, c, lds_, pad;
+} tmf_norms_desc;            /* 32 bytes */
+int tmf_column_norms_batched(int dtype, const tmf_norms_desc* d_desc, int nprob, void* stream);
 
 /* normalise each column of A (n x c) by its 2-norm; optionally reverse column order
  * and flip the sign of odd columns (slater.py:410) while copying into dst            */

@@ -18,7 +18,8 @@ TMF_F64, TMF_C128 = 0, 1
 # numpy mirrors of the descriptor structs (field order/offsets as in the header)
 gemm_desc = np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"),
                       ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4")])
-panel_desc = np.dtype([("A", "<u8"), ("n", "<i4"), ("w", "<i4"), ("lda", "<i4"), ("pad", "<i4")])
+panel_desc = np.dtype([("A", "<u8"), ("norms", "<u8"), ("n", "<i4"), ("w", "<i4"), ("lda", "<i4"), ("pad", "<i4")])
+norms_desc = np.dtype([("src", "<u8"), ("out", "<u8"), ("n", "<i4"), ("c", "<i4"), ("lds_", "<i4"), ("pad", "<i4")])
 jacobi_desc = np.dtype([("X", "<u8"), ("V", "<u8"), ("U", "<u8"), ("s", "<u8"), ("count", "<u8"),
                         ("thresh2", "<f8"), ("p", "<i4"), ("ldx", "<i4"), ("ldv", "<i4"), ("ldu", "<i4")])
 schur_desc = np.dtype([("W", "<u8"), ("S", "<u8"), ("det", "<u8"), ("mb", "<i4"), ("mk", "<i4"), ("k", "<i4"),
@@ -42,7 +43,7 @@ site_job = np.dtype([("mode", "<i4"), ("cut_b", "<i4"), ("cut_k", "<i4"), ("k_b"
                      ("k_k", "<i4"), ("nf_k", "<i4"), ("sec_cap", "<i4"), ("row_off", "<i8"), ("col_off", "<i8"),
                      ("bra_off", "<i8"), ("sec_off", "<i8"), ("idx_off", "<i8"), ("idx_cap", "<i8")])
 assert site_job.itemsize == 80
-assert gemm_desc.itemsize == 48 and panel_desc.itemsize == 24 and jacobi_desc.itemsize == 64
+assert gemm_desc.itemsize == 48 and panel_desc.itemsize == 32 and norms_desc.itemsize == 32 and jacobi_desc.itemsize == 64
 assert schur_desc.itemsize == 48 and det_desc.itemsize == 72 and gather_desc.itemsize == 80
 assert colnorm_desc.itemsize == 40 and sector.itemsize == 48 and site_out.itemsize == 40
 
@@ -50,7 +51,7 @@ SYMBOLS = [
     "tmf_last_error", "tmf_version", "tmf_device_count", "tmf_gemm_batched", "tmf_orth_panel_batched",
     "tmf_jacobi_batched", "tmf_lu_schur_batched", "tmf_det_gather_batched", "tmf_transpose", "tmf_fill_normal",
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_cut_vectors", "tmf_site_prepare",
-    "tmf_cut_vectors_batch", "tmf_site_prepare_batch",
+    "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_column_norms_batched",
 ]
 
 
@@ -82,6 +83,7 @@ def load():
     lib.tmf_fill_normal.argtypes = [i32, vp, i64, u64, vp]
     lib.tmf_gather_signed_batched.argtypes = [i32, vp, i32, vp]
     lib.tmf_normalise_columns_batched.argtypes = [i32, vp, i32, vp]
+    lib.tmf_column_norms_batched.argtypes = [i32, vp, i32, vp]
     lib.tmf_cut_vectors.argtypes = [vp, i32, i32, i64, f64, f64, vp, i32, i64, vp, vp, vp, vp, vp]
     lib.tmf_site_prepare.argtypes = [vp] * 13 + [i32, vp, i64, vp]
     lib.tmf_site_prepare.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i64, vp]

@@ -7,6 +7,10 @@
 // orthonormal orbital bases that the reference obtains from numpy.linalg.eigh
 // (slater.py:347).  A column whose norm is exactly zero stays zero (an exactly
 // rank-deficient slab, e.g. a product-state cut); downstream it carries singular value 0.
+// Inside the panel every column is re-orthogonalised THREE times: range-finder slabs are
+// numerically rank deficient, and for a column that is rounding noise after the first pass
+// "twice is enough" fails (measured: 6e-4 loss of orthogonality on spinful chains); the third
+// pass leaves the noise component outside span(Q) and removes the inside one to eps.
 //
 // Mapping: 16-lane group g computes the coefficient <q_g, v> (lanes stride the rows, one
 // ds_read_b128 per element, 4 shuffle steps to reduce); the update v -= Q c is one row per
@@ -26,6 +30,11 @@ __global__ __launch_bounds__(256) void orth_panel_kernel(const tmf_panel_desc* _
   T* P = reinterpret_cast<T*>(smem);            // P[c * n + r]
   T* coef = P + (size_t)n * w;                  // WMAX coefficients
   double* red = reinterpret_cast<double*>(coef + WMAX);  // 4 partial norms
+  // A residual below DROP * (original column norm) is rounding noise: the column is numerically
+  // dependent on the previous ones (rank-deficient slab, e.g. exactly decoupled spin species).
+  // Normalising it would break orthogonality, so it becomes an exact zero column.
+  const double* __restrict__ norms = reinterpret_cast<const double*>(d.norms);
+  const double DROP = 1e-14;
 
   T* __restrict__ A = reinterpret_cast<T*>(d.A);
   const int tid = threadIdx.x;
@@ -39,7 +48,7 @@ __global__ __launch_bounds__(256) void orth_panel_kernel(const tmf_panel_desc* _
   const int lane = tid & 63, wave = tid >> 6;
   for (int j = 0; j < w; ++j) {
     T* v = P + (size_t)j * n;
-    for (int pass = 0; pass < 2 && j > 0; ++pass) {
+    for (int pass = 0; pass < 3 && j > 0; ++pass) {
       // coefficients c_g = <q_g, v>, g < j
       if (grp < j) {
         const T* q = P + (size_t)grp * n;
@@ -63,7 +72,8 @@ __global__ __launch_bounds__(256) void orth_panel_kernel(const tmf_panel_desc* _
     if (lane == 0) red[wave] = s;
     __syncthreads();
     const double nrm2 = red[0] + red[1] + red[2] + red[3];
-    const double f = nrm2 > 0.0 ? 1.0 / sqrt(nrm2) : 0.0;
+    const double lim = norms ? DROP * norms[j] : 0.0;
+    const double f = (nrm2 > 0.0 && nrm2 >= lim * lim) ? 1.0 / sqrt(nrm2) : 0.0;
     for (int r = tid; r < n; r += 256) v[r] = sc<T>::scale(v[r], f);
     __syncthreads();
   }

@@ -108,6 +108,21 @@ __global__ __launch_bounds__(256) void colnorm_kernel(const tmf_colnorm_desc* __
   }
 }
 
+// ---- column norms -----------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void norms_kernel(const tmf_norms_desc* __restrict__ desc) {
+  const tmf_norms_desc d = desc[blockIdx.x];
+  const T* __restrict__ src = reinterpret_cast<const T*>(d.src);
+  double* __restrict__ out = reinterpret_cast<double*>(d.out);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = wave; c < d.c; c += 4) {  // one wavefront per column
+    double s = 0.0;
+    for (int r = lane; r < d.n; r += 64) s += sc<T>::abs2(src[(size_t)r + (size_t)c * d.lds_]);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[c] = sqrt(s);
+  }
+}
+
 }  // namespace tmf
 
 using namespace tmf;
@@ -177,4 +192,18 @@ extern "C" int tmf_normalise_columns_batched(int dtype, const tmf_colnorm_desc* 
     return TMF_E_ARG;
   }
   return check_hip(hipGetLastError(), "tmf_normalise_columns_batched");
+}
+
+extern "C" int tmf_column_norms_batched(int dtype, const tmf_norms_desc* d_desc, int nprob, void* stream) {
+  if (nprob <= 0) return TMF_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == TMF_C128)
+    hipLaunchKernelGGL(norms_kernel<cd>, dim3(nprob), dim3(256), 0, s, d_desc);
+  else if (dtype == TMF_F64)
+    hipLaunchKernelGGL(norms_kernel<double>, dim3(nprob), dim3(256), 0, s, d_desc);
+  else {
+    set_error("tmf_column_norms_batched: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+  return check_hip(hipGetLastError(), "tmf_column_norms_batched");
 }

@@ -108,9 +108,11 @@ class Engine:
         nat.check(self.lib.tmf_gemm_batched(self.dtype, opA, float(alpha), float(beta), dd.data_ptr(), dt.data_ptr(),
                                             total, tn, self.stream), "tmf_gemm_batched")
 
-    def bcgs2(self, base, rows, ld, c_begin, c_end, scratch_ptr):
+    def bcgs2(self, base, rows, ld, c_begin, c_end, scratch_ptr, passes=2):
         """Orthonormalise columns [c_begin, c_end) of every matrix against all columns before
-        them (blocked classical Gram-Schmidt, two passes), panels of width w."""
+        them (blocked classical Gram-Schmidt with re-orthogonalisation), panels of width w.
+        passes=2 for well-conditioned slabs; passes=3 for numerically rank-deficient ones
+        (range finder), where a second pass still acts on rounding noise."""
         base, rows, ld, c_begin, c_end = (np.asarray(x, np.int64) for x in (base, rows, ld, c_begin, c_end))
         if base.size == 0:
             return
@@ -119,6 +121,16 @@ class Engine:
         while max_rows * w * self.elem + 1024 > 150 * 1024 and w > 1:
             w //= 2
         span = c_end - c_begin
+        # norms of the raw columns: the panel kernel zeroes columns whose residual is rounding noise
+        noff = np.concatenate(([0], np.cumsum(span)))[:-1]
+        d_nrm = self.torch.zeros(max(int(span.sum()), 1), dtype=self.torch.float64, device=self.device)
+        self._keep.append(d_nrm)
+        nrmp = d_nrm.data_ptr() + 8 * noff
+        nd = np.zeros(base.size, nat.norms_desc)
+        nd["src"], nd["out"] = base + c_begin * ld * self.elem, nrmp
+        nd["n"], nd["c"], nd["lds_"] = rows, span, ld
+        t_nd = self._up(nd)
+        nat.check(self.lib.tmf_column_norms_batched(self.dtype, t_nd.data_ptr(), base.size, self.stream), "norms")
         for t in range(0, int(span.max()), w):
             act = np.nonzero((span > t) & (rows > 0))[0]
             if act.size == 0:
@@ -126,13 +138,14 @@ class Engine:
             j = c_begin[act] + t
             wj = np.minimum(w, c_end[act] - j)
             colp = base[act] + j * ld[act] * self.elem
-            for _ in range(2):
+            for _ in range(passes):
                 self.gemm(1, 1.0, 0.0, base[act], colp, scratch_ptr[act], j, wj, rows[act], ld[act], ld[act],
                           np.maximum(j, 1))
                 self.gemm(0, -1.0, 1.0, base[act], scratch_ptr[act], colp, rows[act], wj, j, ld[act],
                           np.maximum(j, 1), ld[act])
             d = np.zeros(act.size, nat.panel_desc)
             d["A"], d["n"], d["w"], d["lda"] = colp, rows[act], wj, ld[act]
+            d["norms"] = nrmp[act] + 8 * t
             dd = self._up(d)
             nat.check(self.lib.tmf_orth_panel_batched(self.dtype, dd.data_ptr(), act.size, max_rows, w, self.stream),
                       "tmf_orth_panel_batched")
@@ -264,12 +277,12 @@ class Engine:
         # E1: Y = F Omega
         self.gemm(0, 1.0, 0.0, off, omp, Yp, n, p, m, L, L, ld1)
         # E2: Q = qr(Y)
-        self.bcgs2(Yp[doE], n[doE], n[doE], zero[doE], p[doE], scrp[doE])
+        self.bcgs2(Yp[doE], n[doE], n[doE], zero[doE], p[doE], scrp[doE], passes=3)
         # E3: B^H = F^H Q  (m x p), R = Q2^H B^H
         self.gemm(1, 1.0, 0.0, off, Yp, Btp, m, p, n, L, ld1, np.maximum(m, 1))
         torch.cuda.current_stream(self.device)  # (same stream; copy below is stream-ordered)
         d_Q2.copy_(d_Bt)
-        self.bcgs2(Q2p[doE], m[doE], m[doE], zero[doE], p[doE], scrp[doE])
+        self.bcgs2(Q2p[doE], m[doE], m[doE], zero[doE], p[doE], scrp[doE], passes=3)
         self.gemm(1, 1.0, 0.0, Q2p, Btp, Rp, p, p, m, np.maximum(m, 1), np.maximum(m, 1), np.maximum(p, 1))
         # E4: Jacobi SVD of R: right singular vectors Z, sigma; columns below the threshold zeroed
         self.jacobi(Rp, Zp, sigp, cntp, thr2, p, np.maximum(p, 1), np.maximum(p, 1))

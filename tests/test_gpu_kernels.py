@@ -289,3 +289,32 @@ def test_utilities(eng, cplx):
     ref = (B / np.linalg.norm(B, axis=0))[:, ::-1].copy()
     ref[:, 1::2] *= -1
     np.testing.assert_allclose(back(dD[0], (50, 6)), ref, atol=1e-15)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_bcgs2_numerically_rank_deficient_square_slab(eng, cplx):
+    """p = n columns spanning a numerically rank-deficient space (singular values down to 1e-17):
+    re-orthogonalised rounding noise must not be normalised into non-orthogonal unit vectors."""
+    setup(eng, cplx)
+    rng = np.random.default_rng(11)
+    n = 38
+    U, V = np.linalg.qr(rnd(rng, (n, n), cplx))[0], np.linalg.qr(rnd(rng, (58, 58), cplx))[0]
+    sv = np.concatenate((np.logspace(-0.3, -16.5, 30), np.zeros(n - 30)))
+    F = (U * sv) @ V[:n]
+    Y = F @ rnd(rng, (58, n), cplx)
+    d = dev(eng, Y)
+    scr = eng._alloc(n * 16)
+    eng.bcgs2([d[1]], [n], [n], [0], [n], np.array([scr.data_ptr()]), passes=3)
+    torch.cuda.synchronize()
+    Q = back(d[0], (n, n))
+    nz = np.linalg.norm(Q, axis=0) > 0
+    assert 25 <= nz.sum() < n                       # rounding-noise columns became exact zeros
+    Qk = Q[:, nz]
+    G = Qk.conj().T @ Qk
+    # strong directions orthonormal to working precision; columns kept just above the 1e-14 drop
+    # threshold (directions 7 decades below the physical 1e-6 cut) to 1e-8
+    np.testing.assert_allclose(G[:20, :20], np.eye(20), atol=1e-12)
+    np.testing.assert_allclose(G, np.eye(nz.sum()), atol=1e-8)
+    # every direction with singular value >= 1e-9 is captured to ~1e-16 / 1e-9
+    big = U[:, sv >= 1e-9]
+    np.testing.assert_allclose(Qk @ (Qk.conj().T @ big), big, atol=1e-6)

@@ -253,3 +253,28 @@ def test_sector_filter_and_unlimited_chi():
     np.testing.assert_allclose(G, C, atol=1e-8)
     with pytest.raises(ValueError):
         slater.C_to_MPS(C, {"chi_max": 8, "sectors": [L + 5]}, as_tenpy=False)
+
+
+@pytest.mark.parametrize("L,chi", [(24, 64), (48, 96)])
+def test_spinful_ph_chain_block_decoupled_spectra(L, chi):
+    """BASELINE config 5 shape (uniform chain, spinful="PH") at sizes the oracle finishes: the
+    two spin species make C exactly block-decoupled, every entangled eigenvalue is two-fold
+    degenerate and the range-finder slabs are exactly rank deficient (regression test for the
+    loss of orthogonality of Gram-Schmidt on such slabs).  Mode counts must match exactly and
+    eigenvalues to 1e-11; which member of a (numerically split) degenerate Schmidt multiplet
+    survives chi_max is decided by rounding in the reference as well, so S and the state are
+    compared at that noise level."""
+    from tests_inputs import uniform_chain
+    from temfpy_amd import slater
+
+    C, _ = orc.correlation_matrix(uniform_chain(L))
+    mps = slater.C_to_MPS(C, {"chi_max": chi}, as_tenpy=False, spinful="PH")
+    cuts, sites = orc.c_to_mps(C, {"chi_max": chi}, spinful="PH")
+    assert mps.L == 2 * L
+    for b in range(2 * L + 1):
+        c, m = cuts[b], mps.bonds[b]
+        assert (c.k, c.n_filled("L"), c.n_filled("R")) == (len(m.e), m.n_filled_left, m.n_filled_right)
+        np.testing.assert_allclose(m.e, c.e, rtol=0, atol=1e-11)
+    dS = np.abs(orc.entropies(cuts) - mps.entanglement_entropy(all_bonds=True)).max()
+    assert dS < 2e-3
+    assert abs(1 - overlap(cuts, sites, mps, L)) < 1e-3
