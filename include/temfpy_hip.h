@@ -129,6 +129,15 @@ typedef struct {
 int tmf_det_gather_batched(int dtype, int order, const tmf_det_desc* d_desc, int ntiles, int lds_bytes,
                            void* stream);
 
+/* Same result as tmf_det_gather_batched through one shared reduction per bra row-set: a
+ * Gauss-Jordan elimination of S[rows(a), :] with full pivoting (once per a, lane = column) turns
+ * every minor into a determinant of order d = |cols(b) \ pivot columns| (d <= 2 for ~96 % of
+ * the minors of a sweep).  Requires sk <= 64 and 1 <= order <= 32.  lds_bytes per workgroup:
+ * align16(sb*sk*elem) + align16(nsk*n) + align16(nsk*8) + align16((a1-a0)*n)
+ *   + 4 * (((n|1)*sk + 264) * elem + 64). */
+int tmf_det_reduced_batched(int dtype, int order, const tmf_det_desc* d_desc, int ntiles, int lds_bytes,
+                            void* stream);
+
 /* ---- small device utilities ------------------------------------------------------ */
 /* out (n x n col-major) = transpose of the row-major host layout already on device   */
 int tmf_transpose(int dtype, const void* d_in, void* d_out, int n, void* stream);

@@ -51,7 +51,7 @@ SYMBOLS = [
     "tmf_last_error", "tmf_version", "tmf_device_count", "tmf_gemm_batched", "tmf_orth_panel_batched",
     "tmf_jacobi_batched", "tmf_lu_schur_batched", "tmf_det_gather_batched", "tmf_transpose", "tmf_fill_normal",
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_cut_vectors", "tmf_site_prepare",
-    "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_column_norms_batched",
+    "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_column_norms_batched", "tmf_det_reduced_batched",
 ]
 
 
@@ -79,6 +79,7 @@ def load():
     lib.tmf_jacobi_batched.argtypes = [i32, vp, i32, i32, vp, vp]
     lib.tmf_lu_schur_batched.argtypes = [i32, vp, i32, i32, vp]
     lib.tmf_det_gather_batched.argtypes = [i32, i32, vp, i32, i32, vp]
+    lib.tmf_det_reduced_batched.argtypes = [i32, i32, vp, i32, i32, vp]
     lib.tmf_transpose.argtypes = [i32, vp, vp, i32, vp]
     lib.tmf_fill_normal.argtypes = [i32, vp, i64, u64, vp]
     lib.tmf_gather_signed_batched.argtypes = [i32, vp, i32, vp]

@@ -58,6 +58,7 @@ class Engine:
         self.profile = bool(int(os.environ.get("TMF_PROFILE", "0"))) if profile is None else profile
         self.timings = {}
         self._keep = []  # descriptor tensors must outlive the launches that read them
+        self.force_direct_det = bool(int(os.environ.get("TMF_DIRECT_DET", "0")))  # A/B switch
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -530,8 +531,19 @@ class Engine:
                      + np.where(tcls == 64, nq[tsec] ** 2 * el,
                                 4 * ((nq[tsec] | 1) * skv[tsite] + gpw * (nq[tsec] + 1)) * el))
             pairs = (dd_all["a1"] - dd_all["a0"]).astype(np.int64) * dd_all["nsk"]
-            for cls in sorted(set(tcls.tolist()), key=lambda c_: -int(pairs[tcls == c_].sum())):
-                selc = np.nonzero(tcls == cls)[0]
+            # reduced-minor kernel (one Gauss-Jordan per bra row-set) whenever the sometimes-matrix has
+            # <= 64 columns and 1 <= n <= 32; the direct kernel covers the rest
+            use_red = (tcls >= 1) & (tcls <= 32) & (skv[tsite] <= 64) & (not self.force_direct_det)
+            lneed_red = (a16(sbv[tsite] * skv[tsite] * el) + a16(nsk_[tsec] * nq[tsec]) + a16(nsk_[tsec] * 8)
+                         + a16(ta[tsec] * nq[tsec]) + 4 * (((nq[tsec] | 1) * skv[tsite] + 264) * el + 64))
+            use_red &= lneed_red + 16 <= 160 * 1024
+            lneed = np.where(use_red, lneed_red, lneed)
+            if int(lneed.max()) > 160 * 1024:
+                raise NotImplementedError("determinant tile exceeds the 160 KiB LDS of a CU")
+            launches = sorted({(int(c_), bool(r_)) for c_, r_ in zip(tcls.tolist(), use_red.tolist())},
+                              key=lambda cr: -int(pairs[(tcls == cr[0]) & (use_red == cr[1])].sum()))
+            for cls, red in launches:
+                selc = np.nonzero((tcls == cls) & (use_red == red))[0]
                 if selc.size == 0:
                     continue
                 # biggest tiles first
@@ -542,11 +554,11 @@ class Engine:
                 flops *= (8.0 / 3.0) if cplx else (2.0 / 3.0)  # LU of an n x n complex / real matrix
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record(torch.cuda.current_stream(self.device))
-                nat.check(self.lib.tmf_det_gather_batched(self.dtype, cls, t_dd.data_ptr(), len(dd),
-                                                          int(lneed[selc].max()) + 16, self.stream),
-                          "tmf_det_gather_batched")
+                fn = self.lib.tmf_det_reduced_batched if red else self.lib.tmf_det_gather_batched
+                nat.check(fn(self.dtype, cls, t_dd.data_ptr(), len(dd), int(lneed[selc].max()) + 16, self.stream),
+                          "tmf_det_reduced_batched" if red else "tmf_det_gather_batched")
                 ev1.record(torch.cuda.current_stream(self.device))
-                self.det_events.append((cls, ev0, ev1, flops, int(pairs[selc].sum())))
+                self.det_events.append((f"{cls}{'r' if red else ''}", ev0, ev1, flops, int(pairs[selc].sum())))
                 n_det += int(pairs[selc].sum())
         self.n_det = n_det
         self._tick("S_determinants", t0)

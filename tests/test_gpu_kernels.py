@@ -318,3 +318,72 @@ def test_bcgs2_numerically_rank_deficient_square_slab(eng, cplx):
     # every direction with singular value >= 1e-9 is captured to ~1e-16 / 1e-9
     big = U[:, sv >= 1e-9]
     np.testing.assert_allclose(Qk @ (Qk.conj().T @ big), big, atol=1e-6)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("n,sk,mode", [(1, 5, "near"), (2, 9, "near"), (5, 12, "near"), (8, 20, "near"), (12, 30, "near"),
+                                       (13, 31, "far"), (16, 40, "near"), (19, 45, "near"), (20, 64, "far"),
+                                       (32, 64, "near"), (12, 30, "rankdef"), (6, 14, "graded")])
+def test_det_reduced_matches_numpy(eng, cplx, n, sk, mode):
+    """tmf_det_reduced_batched (one pivoted Gauss-Jordan per bra row-set, order-d minors) against
+    numpy.linalg.det of every minor.  'near': ket sets differ from the first one in <= 3 columns
+    (the situation of a sweep); 'far': random ket sets (up to n exchanged columns, the > 8 path);
+    'rankdef': some bra row-sets select a rank-deficient slab (all their minors are 0);
+    'graded': rows scaled over 12 decades (weak orbitals)."""
+    setup(eng, cplx)
+    nat = eng.nat
+    rng = np.random.default_rng(100 + n)
+    sb = n + 7
+    S = rnd(rng, (sb, sk), cplx)
+    if mode == "graded":
+        S *= np.logspace(0, -12, sb)[:, None]
+    if mode == "rankdef":
+        S[3] = 2.0 * S[1] - S[2]          # rows 1, 2, 3 linearly dependent
+    nsb, nsk = 23, 41
+    bra = np.stack([np.sort(rng.choice(sb, n, replace=False)) for _ in range(nsb)]).astype(np.uint8)
+    if mode == "rankdef":
+        for a_ in (0, 5):  # these row-sets contain the dependent rows 1, 2, 3
+            rest = np.setdiff1d(rng.choice(sb, sb, replace=False), [1, 2, 3])[: n - 3]
+            bra[a_] = np.sort(np.concatenate(([1, 2, 3], rest)))
+    base = np.sort(rng.choice(sk, n, replace=False))
+    ket = []
+    for _ in range(nsk):
+        if mode == "far":
+            ket.append(np.sort(rng.choice(sk, n, replace=False)))
+        else:
+            k = base.copy()
+            for _ in range(rng.integers(0, min(3, n, sk - n) + 1)):
+                free = np.setdiff1d(np.arange(sk), k)
+                k[rng.integers(n)] = rng.choice(free)
+            ket.append(np.sort(k))
+    ket[0] = base
+    ket = np.stack(ket).astype(np.uint8)
+    scale = rnd(rng, (1,), cplx)
+    dS_, dsc = dev(eng, S), dev(eng, scale)
+    tb, tk = eng._up(bra), eng._up(ket)
+    out = eng._alloc(nsb * nsk, zero=True)
+    ta = 8
+    dd = np.zeros(_cdiv(nsb, ta), nat.det_desc)
+    for j in range(len(dd)):
+        dd[j] = (dS_[1], dsc[1], tb.data_ptr(), tk.data_ptr(), out.data_ptr(), sb, sk, sb, n, nsb, nsk, j * ta,
+                 min(nsb, (j + 1) * ta))
+    a16 = lambda x: (x + 15) & ~15  # noqa: E731
+    lds = (a16(sb * sk * eng.elem) + a16(nsk * n) + a16(nsk * 8) + a16(ta * n)
+           + 4 * (((n | 1) * sk + 264) * eng.elem + 64) + 16)
+    if lds > 160 * 1024:
+        pytest.skip("tile exceeds the 160 KiB LDS; the engine uses tmf_det_gather_batched for it")
+    t = eng._up(dd)
+    nat.check(eng.lib.tmf_det_reduced_batched(eng.dtype, n, t.data_ptr(), len(dd), lds, eng.stream), "red")
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(nsb, nsk)
+    ref = np.empty((nsb, nsk), S.dtype)
+    for a in range(nsb):
+        for b in range(nsk):
+            ref[a, b] = scale[0] * np.linalg.det(S[np.ix_(bra[a], ket[b])])
+    if mode == "graded":  # every row of `ref` has its own scale
+        for a in range(nsb):
+            np.testing.assert_allclose(got[a], ref[a], rtol=0, atol=1e-9 * np.abs(ref[a]).max())
+    else:
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+    if mode == "rankdef":
+        assert np.abs(got[0]).max() <= 1e-10 * np.abs(ref).max() and np.abs(got[5]).max() <= 1e-10 * np.abs(ref).max()
