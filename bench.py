@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--L", type=int, default=1024)
     ap.add_argument("--chi", type=int, default=512)
     ap.add_argument("--cpu-sample", type=int, default=40, help="sites timed with the CPU oracle (0 = skip)")
+    ap.add_argument("--streams", type=int, default=1, help="shards converted concurrently on one GPU (HIP streams)")
     a = ap.parse_args()
 
     import torch
@@ -109,8 +110,29 @@ def main():
         if world > 1:
             dist.barrier()
 
+    engines = [eng] + [Engine(dev, profile=False) for _ in range(a.streams - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(a.streams)]
+
     def step():
-        return eng.run(d_C, trunc, oc, L, download=False, site_range=rng_sites if world > 1 else None)
+        if a.streams == 1:
+            return eng.run(d_C, trunc, oc, L, download=False, site_range=rng_sites if world > 1 else None)
+        # several shards of this rank's range in flight on separate HIP streams: the host phases of
+        # one shard (enumeration, descriptors) overlap the kernels of the others
+        import threading
+        lo, hi = rng_sites if world > 1 else (0, L)
+        sub = [(lo + a_ - 0, lo + b_) for a_, b_ in shard_sites(hi - lo, max(min(oc - lo, hi - lo), 0), a.streams)]
+        res = [None] * a.streams
+
+        def work(j):
+            with torch.cuda.stream(streams[j]):
+                res[j] = engines[j].run(d_C, trunc, oc, L, download=False, site_range=sub[j])
+                streams[j].synchronize()
+
+        th = [threading.Thread(target=work, args=(j,)) for j in range(a.streams)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        eng.det_events = [e for en in engines for e in en.det_events]
+        return res[0]
 
     for _ in range(a.warmup):
         step()
