@@ -138,6 +138,9 @@ def main():
         step()
     barrier()
     det_ms, det_flops, det_n = {}, {}, {}
+    gemm_ms, gemm_fl = [], []
+    for e_ in engines:
+        e_.time_gemm = True
     t0 = time.perf_counter()
     for _ in range(a.steps):
         mps = step()
@@ -145,6 +148,8 @@ def main():
         for cls, e0, e1, fl, nd in eng.det_events:
             det_ms.setdefault(cls, []).append(e0.elapsed_time(e1))
             det_flops[cls], det_n[cls] = fl, nd
+        gemm_ms.append(sum(e0.elapsed_time(e1) for e0, e1, _ in eng.gemm_events))
+        gemm_fl.append(sum(fl for _, _, fl in eng.gemm_events))
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -167,11 +172,25 @@ def main():
         if dom is not None:
             avg_ms = float(np.mean(det_ms[dom]))
             ach = det_flops[dom] / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": f"det_kernel<complex128, n<={dom}>", "achieved": round(ach, 4),
+            kname = (f"tmf::reduced_det_kernel<tmf::cd, {str(dom)[:-1]}>" if str(dom).endswith("r")
+                     else f"tmf::det_kernel<tmf::cd, {dom}, G>")
+            traffic = None  # HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)
+            pmc = os.path.join(ROOT, "profiles", "r01", "pmc_reduced_det_n12.json")
+            if os.path.exists(pmc):
+                pj = json.load(open(pmc))
+                if pj.get("kernel") == kname and L == 1024 and chi == 512 and world == 1:
+                    traffic = pj["hbm_bytes_per_launch"]
+            all_ms = sum(float(np.mean(v)) for v in det_ms.values())
+            all_fl = sum(det_flops.values())
+            roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 4),
                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_PEAK_TFLOPS, 5),
-                    "traffic": None, "avg_launch_ms": round(avg_ms, 3), "dets_per_launch": det_n[dom],
+                    "traffic": traffic, "avg_launch_ms": round(avg_ms, 3), "dets_per_launch": det_n[dom],
                     "flops_per_launch": det_flops[dom],
-                    "all_det_launch_ms": {str(c): round(float(np.mean(v)), 3) for c, v in det_ms.items()}}
+                    "all_det_launches": {"ms": round(all_ms, 3), "achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 3),
+                                         "per_order_ms": {str(c): round(float(np.mean(v)), 3) for c, v in det_ms.items()}},
+                    "mfma_gemm": {"launches": len(eng.gemm_events), "ms": round(float(np.mean(gemm_ms)), 3),
+                                  "achieved": round(float(np.mean(gemm_fl)) / (float(np.mean(gemm_ms)) * 1e-3) / 1e12, 3),
+                                  "frac": round(float(np.mean(gemm_fl)) / (float(np.mean(gemm_ms)) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4)}}
         out = {
             "metric": "sites/sec (Slater->MPS, L=%d chi=%d fp64)" % (L, chi), "value": round(L / (dt / a.steps), 2),
             "unit": "sites/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),

@@ -61,6 +61,8 @@ class Engine:
         self._pin_t = self._pin_np = self._dev_arena = None
         self._pin_cap = self._pin_off = 0
         self.force_direct_det = bool(int(os.environ.get("TMF_DIRECT_DET", "0")))  # A/B switch
+        self.time_gemm = False   # bench.py: HIP events around every MFMA GEMM launch
+        self.gemm_events = []
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -124,8 +126,15 @@ class Engine:
         order = np.argsort(-d["K"][prob].astype(np.int64), kind="stable")  # longest tiles first
         tiles = tiles[order]
         dd, dt = self._up(d), self._up(tiles)
+        if self.time_gemm:
+            ev0, ev1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            ev0.record(self.torch.cuda.current_stream(self.device))
         nat.check(self.lib.tmf_gemm_batched(self.dtype, opA, float(alpha), float(beta), dd.data_ptr(), dt.data_ptr(),
                                             total, tn, self.stream), "tmf_gemm_batched")
+        if self.time_gemm:
+            ev1.record(self.torch.cuda.current_stream(self.device))
+            fl = float((d["M"].astype(np.float64) * d["N"] * d["K"]).sum()) * (8.0 if self.dtype == nat.TMF_C128 else 2.0)
+            self.gemm_events.append((ev0, ev1, fl))
 
     def bcgs2(self, base, rows, ld, c_begin, c_end, scratch_ptr, passes=2):
         """Orthonormalise columns [c_begin, c_end) of every matrix against all columns before
@@ -208,6 +217,7 @@ class Engine:
         t_all = time.perf_counter()
         self.timings = {}
         self.det_events = []
+        self.gemm_events = []
         torch.cuda.current_stream(self.device).synchronize()  # staging arena of the previous call is free
         self._pin_off = 0
         if isinstance(C, torch.Tensor):
