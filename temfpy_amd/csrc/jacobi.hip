@@ -14,7 +14,7 @@
 namespace tmf {
 
 template <typename T>
-__global__ __launch_bounds__(256) void jacobi_kernel(const tmf_jacobi_desc* __restrict__ desc,
+__global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __restrict__ desc,
                                                      int32_t* __restrict__ sweeps_out) {
   extern __shared__ __align__(16) unsigned char smem[];
   const tmf_jacobi_desc d = desc[blockIdx.x];
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void jacobi_kernel(const tmf_jacobi_desc* __re
 
   const int tid = threadIdx.x;
   const T* __restrict__ Xg = reinterpret_cast<const T*>(d.X);
-  for (int e = tid; e < p * p; e += 256) {
+  for (int e = tid; e < p * p; e += 512) {
     const int r = e % p, c = e / p;
     X[e] = Xg[(size_t)r + (size_t)c * d.ldx];
     V[e] = (r == c) ? sc<T>::one() : sc<T>::zero();
@@ -38,8 +38,8 @@ __global__ __launch_bounds__(256) void jacobi_kernel(const tmf_jacobi_desc* __re
   const int pe = (p + 1) & ~1;      // players (even)
   const int m = pe - 1;             // players on the circle; player m sits still
   const int npairs = pe / 2;
-  int tpp = 64;                     // lanes per pair: largest power of two with npairs*tpp <= 256
-  while (tpp * npairs > 256) tpp >>= 1;
+  int tpp = 64;                     // lanes per pair: largest power of two with npairs*tpp <= 512
+  while (tpp * npairs > 512) tpp >>= 1;
   const int pair = tid / tpp, pl = tid % tpp;
   const double eps = 1.1e-16;
 
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void jacobi_kernel(const tmf_jacobi_desc* __re
   if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sweep;
 
   // column norms, rank by descending norm (ties: lower index first)
-  for (int c = tid; c < p; c += 256) {
+  for (int c = tid; c < p; c += 512) {
     double s = 0.0;
     for (int r = 0; r < p; ++r) s += sc<T>::abs2(X[(size_t)c * p + r]);
     nrm[c] = sqrt(s);
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void jacobi_kernel(const tmf_jacobi_desc* __re
   T* __restrict__ Vg = reinterpret_cast<T*>(d.V);
   T* __restrict__ Ug = reinterpret_cast<T*>(d.U);
   double* __restrict__ sg = reinterpret_cast<double*>(d.s);
-  for (int e = tid; e < p * p; e += 256) {
+  for (int e = tid; e < p * p; e += 512) {
     const int r = e % p, c = e / p;
     const double sc_ = nrm[c];
     int rank = 0;
@@ -160,9 +160,9 @@ extern "C" int tmf_jacobi_batched(int dtype, const tmf_jacobi_desc* d_desc, int 
     attr_done = true;
   }
   if (dtype == TMF_C128)
-    hipLaunchKernelGGL(jacobi_kernel<cd>, dim3(nprob), dim3(256), lds, s, d_desc, d_sweeps);
+    hipLaunchKernelGGL(jacobi_kernel<cd>, dim3(nprob), dim3(512), lds, s, d_desc, d_sweeps);
   else if (dtype == TMF_F64)
-    hipLaunchKernelGGL(jacobi_kernel<double>, dim3(nprob), dim3(256), lds, s, d_desc, d_sweeps);
+    hipLaunchKernelGGL(jacobi_kernel<double>, dim3(nprob), dim3(512), lds, s, d_desc, d_sweeps);
   else {
     set_error("tmf_jacobi_batched: bad dtype %d", dtype);
     return TMF_E_ARG;

@@ -357,6 +357,118 @@ class Engine:
         nf = np.clip(nf, 0, n - k).astype(np.int64)
         self._tick("host_classify", t0)
 
+        def host_phase():
+            # ---- host: best-first enumeration for every cut (one threaded C++ call) ----------------
+            t0 = time.perf_counter()
+            sectors = _sector_list(trunc, L)
+            cut_idx = {}
+            for i in range(ncs):
+                cut_idx[(int(cs_b[i]), int(cs_side[i]))] = i
+            my_cuts = sorted({b for b, _ in need})
+            ncut = len(my_cuts)
+            cpos = {b: j for j, b in enumerate(my_cuts)}
+            e_left, nfl, nfr = [None] * ncut, np.zeros(ncut, np.int32), np.zeros(ncut, np.int32)
+            for j, b in enumerate(my_cuts):
+                iL, iR = cut_idx.get((b, 0)), cut_idx.get((b, 1))
+                if iL is not None:
+                    e_left[j] = e_side[iL]
+                    nfl[j] = nf[iL]
+                    nfr[j] = nf[iR] if iR is not None else n_fermion - len(e_left[j]) - nfl[j]  # slater.py:167
+                else:
+                    e_left[j] = (1.0 - e_side[iR])[::-1].copy()  # slater.py:386
+                    nfr[j] = nf[iR]
+                    nfl[j] = n_fermion - len(e_left[j]) - nfr[j]  # slater.py:172
+            kk_cut = np.array([len(x) for x in e_left], np.int32)
+            e_off = np.concatenate(([0], np.cumsum(kk_cut)))[:-1].astype(np.int64)
+            e_pool = np.concatenate(e_left + [np.zeros(1)])
+            sec_arr = None if sectors is None else np.ascontiguousarray(sectors, np.int64)
+            cap = int(trunc.chi_max) + 1 if trunc.chi_max else 4096
+            while True:
+                c_sets = np.zeros((ncut, cap, 2), np.uint64)
+                c_lam = np.zeros((ncut, cap))
+                c_q = np.zeros((ncut, cap), np.int32)
+                c_chi, c_chk = np.zeros(ncut, np.int64), np.zeros(ncut, np.int64)
+                st = self.lib.tmf_cut_vectors_batch(
+                    ncut, nat._p(e_pool), nat._p(e_off), nat._p(kk_cut), nat._p(nfl), int(trunc.chi_max or 0),
+                    float(trunc.svd_min), float(trunc.degeneracy_tol), None if sec_arr is None else nat._p(sec_arr),
+                    0 if sec_arr is None else sec_arr.size, cap, nat._p(c_sets), nat._p(c_lam), nat._p(c_q), nat._p(c_chi),
+                    nat._p(c_chk), threads)
+                if st == -3 and not trunc.chi_max and int(c_chi.max()) > cap:
+                    cap = int(c_chi.max()) + 1  # unlimited chi: grow the per-cut capacity and redo
+                    continue
+                nat.check(st, "tmf_cut_vectors_batch")
+                break
+            if np.any(c_chi == 0):
+                raise ValueError("No Schmidt vectors left after filtering by `trunc_par.sectors`!")  # slater.py:668
+            bonds = [None] * (L + 1)
+            for j, b in enumerate(my_cuts):
+                ch = int(c_chi[j])
+                lam_raw = c_lam[j, :ch]
+                nrm = float(np.sqrt(np.dot(lam_raw, lam_raw)))
+                if logger.isEnabledFor(logging.INFO):
+                    logger.info("bond %d: %d Schmidt modes, checked %d subsets, kept %d, norm %.12g", b, kk_cut[j],
+                                c_chk[j], ch, nrm)
+                bonds[b] = BondData(x=b, e=e_left[j], n_filled_left=int(nfl[j]), n_filled_right=int(nfr[j]),
+                                    masks=c_sets[j, :ch], lam_raw=lam_raw, lam=lam_raw / nrm, q_left=c_q[j, :ch],
+                                    n_checked=int(c_chk[j]))
+            self.timings["host_enumerate"] = time.perf_counter() - t0
+
+            # ---- host: per-site integer preparation (one threaded C++ call) --------------------------
+            t0 = time.perf_counter()
+            my_sites = np.arange(s_lo, s_hi)
+            ns = len(my_sites)
+            mode = (my_sites >= oc).astype(np.int32)
+            bb = np.where(mode == 0, my_sites, my_sites + 1)
+            kb_ = np.where(mode == 0, my_sites + 1, my_sites)
+            ib = np.array([cut_idx[(int(b_), int(m_))] for b_, m_ in zip(bb, mode)])
+            ik = np.array([cut_idx[(int(b_), int(m_))] for b_, m_ in zip(kb_, mode)])
+            cb_i = np.array([cpos[int(b_)] for b_ in bb])
+            ck_i = np.array([cpos[int(b_)] for b_ in kb_])
+            chi_b, chi_k = c_chi[cb_i], c_chi[ck_i]
+            jobs = np.zeros(ns, nat.site_job)
+            jobs["mode"], jobs["cut_b"], jobs["cut_k"] = mode, cb_i, ck_i
+            jobs["k_b"], jobs["nf_b"], jobs["k_k"], jobs["nf_k"] = k[ib], nf[ib], k[ik], nf[ik]
+            mb_cap = k[ib] + nf[ib] + 1
+            mk_cap = np.maximum(k[ik] + nf[ik], 1)
+            sec_cap = k[ik] + 2
+            n_bound = np.minimum(255, k[ik] + np.maximum(0, nf[ik] + k[ik] - nf[ib]) + 1)
+            idx_cap = (2 * chi_b + chi_k) * n_bound + 16
+            jobs["sec_cap"] = sec_cap
+            jobs["row_off"], rs_tot = offsets(mb_cap)
+            jobs["col_off"], cs_tot = offsets(mk_cap)
+            jobs["bra_off"], br_tot = offsets(2 * chi_b)
+            jobs["sec_off"], sc_tot = offsets(sec_cap)
+            jobs["idx_off"], ix_tot = offsets(idx_cap)
+            jobs["idx_cap"] = idx_cap
+            row_sel, row_sign = np.zeros(rs_tot + 1, np.int32), np.zeros(rs_tot + 1, np.int8)
+            col_sel, col_sign = np.zeros(cs_tot + 1, np.int32), np.zeros(cs_tot + 1, np.int8)
+            bra_p, bra_alpha = np.zeros(br_tot + 1, np.int32), np.zeros(br_tot + 1, np.int32)
+            sec_buf = np.zeros(sc_tot + 1, nat.sector)
+            pool = np.zeros(ix_tot + 1, np.uint8)
+            souts = np.zeros(ns, nat.site_out)
+            nat.check(self.lib.tmf_site_prepare_batch(
+                ns, nat._p(jobs), nat._p(c_sets), nat._p(c_q), nat._p(c_chi), cap, nat._p(row_sel), nat._p(row_sign),
+                nat._p(col_sel), nat._p(col_sign), nat._p(bra_p), nat._p(bra_alpha), nat._p(sec_buf), nat._p(pool),
+                nat._p(souts), threads), "tmf_site_prepare_batch")
+            self.timings["host_site_prepare"] = time.perf_counter() - t0
+
+            return dict(bonds=bonds, jobs=jobs, souts=souts, row_sel=row_sel, row_sign=row_sign, col_sel=col_sel,
+                        col_sign=col_sign, bra_p=bra_p, bra_alpha=bra_alpha, sec_buf=sec_buf, pool=pool, mode=mode,
+                        ib=ib, ik=ik, chi_b=chi_b, chi_k=chi_k, my_sites=my_sites, ns=ns, cut_idx=cut_idx)
+
+        # the integer host phase (C++, GIL released) runs while the filled-basis launches are enqueued
+        import threading
+        hp = {}
+
+        def _run_host():
+            try:
+                hp["out"] = host_phase()
+            except BaseException as exc:  # re-raised on the main thread
+                hp["exc"] = exc
+
+        th = threading.Thread(target=_run_host)
+        th.start()
+
         # ---- F: orbital matrices V = [U_E (k) | Q_f (nf)] -------------------------------------
         t0 = time.perf_counter()
         ncolV = k + nf
@@ -389,99 +501,14 @@ class Engine:
             self.bcgs2(Vp[has], n[has], ld1[has], k[has], ncolV[has], scr2[has])
         self._tick("F_filled", t0)
 
-        # ---- host: best-first enumeration for every cut (one threaded C++ call) ----------------
-        t0 = time.perf_counter()
-        sectors = _sector_list(trunc, L)
-        cut_idx = {}
-        for i in range(ncs):
-            cut_idx[(int(cs_b[i]), int(cs_side[i]))] = i
-        my_cuts = sorted({b for b, _ in need})
-        ncut = len(my_cuts)
-        cpos = {b: j for j, b in enumerate(my_cuts)}
-        e_left, nfl, nfr = [None] * ncut, np.zeros(ncut, np.int32), np.zeros(ncut, np.int32)
-        for j, b in enumerate(my_cuts):
-            iL, iR = cut_idx.get((b, 0)), cut_idx.get((b, 1))
-            if iL is not None:
-                e_left[j] = e_side[iL]
-                nfl[j] = nf[iL]
-                nfr[j] = nf[iR] if iR is not None else n_fermion - len(e_left[j]) - nfl[j]  # slater.py:167
-            else:
-                e_left[j] = (1.0 - e_side[iR])[::-1].copy()  # slater.py:386
-                nfr[j] = nf[iR]
-                nfl[j] = n_fermion - len(e_left[j]) - nfr[j]  # slater.py:172
-        kk_cut = np.array([len(x) for x in e_left], np.int32)
-        e_off = np.concatenate(([0], np.cumsum(kk_cut)))[:-1].astype(np.int64)
-        e_pool = np.concatenate(e_left + [np.zeros(1)])
-        sec_arr = None if sectors is None else np.ascontiguousarray(sectors, np.int64)
-        cap = int(trunc.chi_max) + 1 if trunc.chi_max else 4096
-        while True:
-            c_sets = np.zeros((ncut, cap, 2), np.uint64)
-            c_lam = np.zeros((ncut, cap))
-            c_q = np.zeros((ncut, cap), np.int32)
-            c_chi, c_chk = np.zeros(ncut, np.int64), np.zeros(ncut, np.int64)
-            st = self.lib.tmf_cut_vectors_batch(
-                ncut, nat._p(e_pool), nat._p(e_off), nat._p(kk_cut), nat._p(nfl), int(trunc.chi_max or 0),
-                float(trunc.svd_min), float(trunc.degeneracy_tol), None if sec_arr is None else nat._p(sec_arr),
-                0 if sec_arr is None else sec_arr.size, cap, nat._p(c_sets), nat._p(c_lam), nat._p(c_q), nat._p(c_chi),
-                nat._p(c_chk), threads)
-            if st == -3 and not trunc.chi_max and int(c_chi.max()) > cap:
-                cap = int(c_chi.max()) + 1  # unlimited chi: grow the per-cut capacity and redo
-                continue
-            nat.check(st, "tmf_cut_vectors_batch")
-            break
-        if np.any(c_chi == 0):
-            raise ValueError("No Schmidt vectors left after filtering by `trunc_par.sectors`!")  # slater.py:668
-        bonds = [None] * (L + 1)
-        for j, b in enumerate(my_cuts):
-            ch = int(c_chi[j])
-            lam_raw = c_lam[j, :ch]
-            nrm = float(np.sqrt(np.dot(lam_raw, lam_raw)))
-            if logger.isEnabledFor(logging.INFO):
-                logger.info("bond %d: %d Schmidt modes, checked %d subsets, kept %d, norm %.12g", b, kk_cut[j],
-                            c_chk[j], ch, nrm)
-            bonds[b] = BondData(x=b, e=e_left[j], n_filled_left=int(nfl[j]), n_filled_right=int(nfr[j]),
-                                masks=c_sets[j, :ch], lam_raw=lam_raw, lam=lam_raw / nrm, q_left=c_q[j, :ch],
-                                n_checked=int(c_chk[j]))
-        self._tick("host_enumerate", t0)
-
-        # ---- host: per-site integer preparation (one threaded C++ call) --------------------------
-        t0 = time.perf_counter()
-        my_sites = np.arange(s_lo, s_hi)
-        ns = len(my_sites)
-        mode = (my_sites >= oc).astype(np.int32)
-        bb = np.where(mode == 0, my_sites, my_sites + 1)
-        kb_ = np.where(mode == 0, my_sites + 1, my_sites)
-        ib = np.array([cut_idx[(int(b_), int(m_))] for b_, m_ in zip(bb, mode)])
-        ik = np.array([cut_idx[(int(b_), int(m_))] for b_, m_ in zip(kb_, mode)])
-        cb_i = np.array([cpos[int(b_)] for b_ in bb])
-        ck_i = np.array([cpos[int(b_)] for b_ in kb_])
-        chi_b, chi_k = c_chi[cb_i], c_chi[ck_i]
-        jobs = np.zeros(ns, nat.site_job)
-        jobs["mode"], jobs["cut_b"], jobs["cut_k"] = mode, cb_i, ck_i
-        jobs["k_b"], jobs["nf_b"], jobs["k_k"], jobs["nf_k"] = k[ib], nf[ib], k[ik], nf[ik]
-        mb_cap = k[ib] + nf[ib] + 1
-        mk_cap = np.maximum(k[ik] + nf[ik], 1)
-        sec_cap = k[ik] + 2
-        n_bound = np.minimum(255, k[ik] + np.maximum(0, nf[ik] + k[ik] - nf[ib]) + 1)
-        idx_cap = (2 * chi_b + chi_k) * n_bound + 16
-        jobs["sec_cap"] = sec_cap
-        jobs["row_off"], rs_tot = offsets(mb_cap)
-        jobs["col_off"], cs_tot = offsets(mk_cap)
-        jobs["bra_off"], br_tot = offsets(2 * chi_b)
-        jobs["sec_off"], sc_tot = offsets(sec_cap)
-        jobs["idx_off"], ix_tot = offsets(idx_cap)
-        jobs["idx_cap"] = idx_cap
-        row_sel, row_sign = np.zeros(rs_tot + 1, np.int32), np.zeros(rs_tot + 1, np.int8)
-        col_sel, col_sign = np.zeros(cs_tot + 1, np.int32), np.zeros(cs_tot + 1, np.int8)
-        bra_p, bra_alpha = np.zeros(br_tot + 1, np.int32), np.zeros(br_tot + 1, np.int32)
-        sec_buf = np.zeros(sc_tot + 1, nat.sector)
-        pool = np.zeros(ix_tot + 1, np.uint8)
-        souts = np.zeros(ns, nat.site_out)
-        nat.check(self.lib.tmf_site_prepare_batch(
-            ns, nat._p(jobs), nat._p(c_sets), nat._p(c_q), nat._p(c_chi), cap, nat._p(row_sel), nat._p(row_sign),
-            nat._p(col_sel), nat._p(col_sign), nat._p(bra_p), nat._p(bra_alpha), nat._p(sec_buf), nat._p(pool),
-            nat._p(souts), threads), "tmf_site_prepare_batch")
-        self._tick("host_site_prepare", t0)
+        th.join()
+        if "exc" in hp:
+            raise hp["exc"]
+        ho = hp["out"]
+        bonds, jobs, souts, pool, mode = ho["bonds"], ho["jobs"], ho["souts"], ho["pool"], ho["mode"]
+        row_sel, row_sign, col_sel, col_sign = ho["row_sel"], ho["row_sign"], ho["col_sel"], ho["col_sign"]
+        bra_p, bra_alpha, sec_buf = ho["bra_p"], ho["bra_alpha"], ho["sec_buf"]
+        ib, ik, chi_b, chi_k, my_sites, ns = ho["ib"], ho["ik"], ho["chi_b"], ho["chi_k"], ho["my_sites"], ho["ns"]
         L_all, L = L, ns  # from here on "L" counts the sites of this shard
 
         # ---- S1/S2: overlaps and W assembly ---------------------------------------------------
