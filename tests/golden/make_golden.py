@@ -44,11 +44,18 @@ def load_reference():
         sys.modules[name] = m
         return m
 
-    class _Placeholder:  # import-time names only; never used for arithmetic
+    class _Meta(type):  # class-level attribute access (e.g. LegCharge.from_qdict) -> inert callable
+        def __getattr__(cls, name):
+            return lambda *a, **k: cls()
+
+    class _Placeholder(metaclass=_Meta):  # names only; never used for arithmetic
         def __init__(self, *a, **k):
             pass
 
         def __getattr__(self, name):
+            return _Placeholder()
+
+        def __call__(self, *a, **k):
             return _Placeholder()
 
     npc = mod("tenpy.linalg.np_conserved", Array=_Placeholder, LegCharge=_Placeholder, LegPipe=_Placeholder)
