@@ -138,6 +138,24 @@ int tmf_det_gather_batched(int dtype, int order, const tmf_det_desc* d_desc, int
 int tmf_det_reduced_batched(int dtype, int order, const tmf_det_desc* d_desc, int ntiles, int lds_bytes,
                             void* stream);
 
+/* Batched gathered Pfaffians (pfaffian.py:1429-1479 `_tensor_block` + :1413-1426 `_many_pfaffian`,
+ * i.e. pfapack.ctypes.pfaffian in a Python loop).  For every pair (bra row a, ket row b):
+ * out[a, b] = scale * Pf(N[idx, idx]),  idx = [ket positions of b (n2), bra positions of a (n1)].
+ * `order` = n1 + n2 of every tile of the launch (even, <= 32).  lds_bytes per workgroup:
+ * align16(nn*nn*elem) + align16(nsk*n2) + align16((a1-a0)*n1) + (256/G) * 2*order*elem,
+ * G = 8, 16, 32 for order <= 8, 16, 32. */
+typedef struct {
+  uint64_t N;                /* nn x nn skew-symmetric Pfaffian matrix, ldn          */
+  uint64_t scale;            /* device address of the Onishi norm factor (one element) */
+  uint64_t bra_idx;          /* uint8 [nsb][n1]                                      */
+  uint64_t ket_idx;          /* uint8 [nsk][n2]                                      */
+  uint64_t out;              /* nsb x nsk row-major block                            */
+  int32_t nn, ldn, n1, n2;
+  int32_t nsb, nsk, a0, a1;
+} tmf_pf_desc;               /* 72 bytes */
+int tmf_pf_gather_batched(int dtype, int order, const tmf_pf_desc* d_desc, int ntiles, int lds_bytes,
+                          void* stream);
+
 /* ---- small device utilities ------------------------------------------------------ */
 /* out (n x n col-major) = transpose of the row-major host layout already on device   */
 int tmf_transpose(int dtype, const void* d_in, void* d_out, int n, void* stream);

@@ -39,6 +39,10 @@ site_out = np.dtype([("mb", "<i4"), ("mk", "<i4"), ("k_always", "<i4"), ("sb", "
 sector = np.dtype([("q", "<i4"), ("r0", "<i4"), ("r1", "<i4"), ("c0", "<i4"), ("c1", "<i4"), ("n", "<i4"),
                    ("bra_off", "<i8"), ("ket_off", "<i8"), ("out_off", "<i8")])
 
+pf_desc = np.dtype([("N", "<u8"), ("scale", "<u8"), ("bra_idx", "<u8"), ("ket_idx", "<u8"), ("out", "<u8"),
+                    ("nn", "<i4"), ("ldn", "<i4"), ("n1", "<i4"), ("n2", "<i4"), ("nsb", "<i4"), ("nsk", "<i4"),
+                    ("a0", "<i4"), ("a1", "<i4")])
+assert pf_desc.itemsize == 72
 site_job = np.dtype([("mode", "<i4"), ("cut_b", "<i4"), ("cut_k", "<i4"), ("k_b", "<i4"), ("nf_b", "<i4"),
                      ("k_k", "<i4"), ("nf_k", "<i4"), ("sec_cap", "<i4"), ("row_off", "<i8"), ("col_off", "<i8"),
                      ("bra_off", "<i8"), ("sec_off", "<i8"), ("idx_off", "<i8"), ("idx_cap", "<i8")])
@@ -51,7 +55,7 @@ SYMBOLS = [
     "tmf_last_error", "tmf_version", "tmf_device_count", "tmf_gemm_batched", "tmf_orth_panel_batched",
     "tmf_jacobi_batched", "tmf_lu_schur_batched", "tmf_det_gather_batched", "tmf_transpose", "tmf_fill_normal",
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_cut_vectors", "tmf_site_prepare",
-    "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_column_norms_batched", "tmf_det_reduced_batched",
+    "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_column_norms_batched", "tmf_det_reduced_batched", "tmf_pf_gather_batched",
 ]
 
 
@@ -80,6 +84,7 @@ def load():
     lib.tmf_lu_schur_batched.argtypes = [i32, vp, i32, i32, vp]
     lib.tmf_det_gather_batched.argtypes = [i32, i32, vp, i32, i32, vp]
     lib.tmf_det_reduced_batched.argtypes = [i32, i32, vp, i32, i32, vp]
+    lib.tmf_pf_gather_batched.argtypes = [i32, i32, vp, i32, i32, vp]
     lib.tmf_transpose.argtypes = [i32, vp, vp, i32, vp]
     lib.tmf_fill_normal.argtypes = [i32, vp, i64, u64, vp]
     lib.tmf_gather_signed_batched.argtypes = [i32, vp, i32, vp]

@@ -15,7 +15,8 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+    """Slater fixtures (the Pfaffian ones, pf_*.npz, are used by tests/test_oracle_pfaffian.py)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith("pf_"))
 
 
 @pytest.fixture(scope="session")

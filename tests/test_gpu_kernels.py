@@ -387,3 +387,50 @@ def test_det_reduced_matches_numpy(eng, cplx, n, sk, mode):
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
     if mode == "rankdef":
         assert np.abs(got[0]).max() <= 1e-10 * np.abs(ref).max() and np.abs(got[5]).max() <= 1e-10 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("n1,n2", [(0, 0), (1, 1), (2, 0), (0, 2), (3, 1), (4, 4), (5, 3), (7, 7), (8, 8), (9, 11), (16, 16)])
+def test_pf_gather(eng, cplx, n1, n2):
+    """tmf_pf_gather_batched against the oracle's Parlett-Reid Pfaffian on every gathered skew
+    sub-matrix (index order: ket positions then bra positions, pfaffian.py:1468-1473)."""
+    from oracle import pfaffian_oracle as porc
+
+    setup(eng, cplx)
+    nat = eng.nat
+    rng = np.random.default_rng(50 + 7 * n1 + n2)
+    nb_, nk_ = n1 + 5, n2 + 6           # bra / ket mode counts; N = [[BB, BA], [-BA^T, AA]] (pfaffian.py:1400)
+    nn = nb_ + nk_
+    M = rnd(rng, (nn, nn), cplx)
+    N = M - M.T
+    nsb, nsk = 19, 13
+    # ket positions live in [0, nk_), bra positions in [nk_, nn)
+    ket = np.stack([np.sort(rng.choice(nk_, n2, replace=False)) for _ in range(nsk)]).astype(np.uint8).reshape(nsk, n2)
+    bra = np.stack([nk_ + np.sort(rng.choice(nb_, n1, replace=False)) for _ in range(nsb)]).astype(np.uint8).reshape(nsb, n1)
+    scale = rnd(rng, (1,), cplx)
+    dN, dsc = dev(eng, N), dev(eng, scale)
+    tb = eng._up(bra if n1 else np.zeros(1, np.uint8))
+    tk = eng._up(ket if n2 else np.zeros(1, np.uint8))
+    out = eng._alloc(nsb * nsk, zero=True)
+    ta = 7
+    dd = np.zeros(_cdiv(nsb, ta), nat.pf_desc)
+    for j in range(len(dd)):
+        dd[j] = (dN[1], dsc[1], tb.data_ptr(), tk.data_ptr(), out.data_ptr(), nn, nn, n1, n2, nsb, nsk, j * ta,
+                 min(nsb, (j + 1) * ta))
+    m = n1 + n2
+    G = 8 if m <= 8 else 16 if m <= 16 else 32
+    a16 = lambda x: (x + 15) & ~15  # noqa: E731
+    lds = a16(nn * nn * eng.elem) + a16(nsk * n2) + a16(ta * n1) + (256 // G) * 2 * max(m, 1) * eng.elem + 16
+    t = eng._up(dd)
+    nat.check(eng.lib.tmf_pf_gather_batched(eng.dtype, m, t.data_ptr(), len(dd), lds, eng.stream), "pf")
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(nsb, nsk)
+    ref = np.empty((nsb, nsk), N.dtype)
+    for a in range(nsb):
+        for b in range(nsk):
+            ix = np.concatenate((ket[b], bra[a])).astype(int)
+            ref[a, b] = scale[0] * (porc.pfaffian(N[np.ix_(ix, ix)]) if m else 1.0)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+    if m:  # Pf^2 = det on the GPU values as well
+        ix = np.concatenate((ket[0], bra[0])).astype(int)
+        np.testing.assert_allclose((got[0, 0] / scale[0]) ** 2, np.linalg.det(N[np.ix_(ix, ix)]), rtol=1e-8)
