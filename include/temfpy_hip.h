@@ -156,6 +156,34 @@ typedef struct {
 int tmf_pf_gather_batched(int dtype, int order, const tmf_pf_desc* d_desc, int ntiles, int lds_bytes,
                           void* stream);
 
+/* ---- assembly kernels of the Pfaffian path (complex128 only) ------------------------------- */
+/* dst[:, j] = M2C( [conj] src[:, col_src[j]] ): Bogoliubov matrix [a | a^dag] of a cut side in the
+ * complex-fermion basis from mode blocks in the Majorana basis (pfaffian.py:880-895, :104-124). */
+typedef struct {
+  uint64_t src, dst;         /* n2 x * (lds_) and n2 x n2 (ldd), column-major        */
+  uint64_t col_src;          /* int32[n2] source column of every result column       */
+  uint64_t col_conj;         /* int8[n2]  1: take the complex conjugate (Majorana basis) */
+  int32_t n2, lds_, ldd, pad;
+} tmf_nambu_asm_desc;        /* 48 bytes */
+int tmf_nambu_assemble_batched(const tmf_nambu_asm_desc* d_desc, int nprob, void* stream);
+
+/* W = [[Vr[L:,L:], Q],[P, 0]], Q = [I[:,idx1] | Vr[L:,idx2]], P = [Vr[idx1,L:] ; I[idx2,:]]
+ * (the operand of tmf_lu_schur_batched that yields det(U^*) and the AA, BA, BB blocks of
+ * pfaffian.py:1384-1391 in one pass). */
+typedef struct {
+  uint64_t Vr, W;            /* 2L x 2L (ldv) ; (L+na+nb)^2 (ldw)                     */
+  uint64_t idx1, idx2;       /* int32[na], int32[nb]                                 */
+  int32_t L, na, nb, ldv, ldw, pad;
+} tmf_nambu_w_desc;          /* 56 bytes */
+int tmf_nambu_w_batched(const tmf_nambu_w_desc* d_desc, int nprob, void* stream);
+
+/* N = [[BB, BA],[-BA^T, AA]] (antisymmetrised) from S = -P (U^*)^-1 Q  (pfaffian.py:1394-1400) */
+typedef struct {
+  uint64_t S, N;             /* (na+nb)^2 each, lds_ / ldn                           */
+  int32_t na, nb, lds_, ldn;
+} tmf_pf_matrix_desc;        /* 32 bytes */
+int tmf_pf_matrix_batched(const tmf_pf_matrix_desc* d_desc, int nprob, void* stream);
+
 /* ---- small device utilities ------------------------------------------------------ */
 /* out (n x n col-major) = transpose of the row-major host layout already on device   */
 int tmf_transpose(int dtype, const void* d_in, void* d_out, int n, void* stream);
@@ -165,11 +193,11 @@ int tmf_fill_normal(int dtype, void* d_out, int64_t count, uint64_t seed, void* 
 typedef struct {
   uint64_t src;              /* col-major, lds_                                     */
   uint64_t dst;              /* col-major, ldd                                      */
-  uint64_t row_sel;          /* int32[rows]: source row, or -1 -> take from `phys`  */
+  uint64_t row_sel;          /* int32[rows]: source row, or -(1+j) -> row j of `phys` */
   uint64_t col_sel;          /* int32[cols]: source col                              */
   uint64_t row_sign;         /* int8[rows]                                          */
   uint64_t col_sign;         /* int8[cols]                                          */
-  uint64_t phys;             /* col-major vector base for row_sel == -1: element (col_sel[c]) * ldp */
+  uint64_t phys;             /* col-major base of the physical rows: element j + col_sel[c] * ldp */
   int32_t rows, cols, lds_, ldd, ldp, pad;
 } tmf_gather_desc;           /* 80 bytes */
 int tmf_gather_signed_batched(int dtype, const tmf_gather_desc* d_desc, int nprob, void* stream);
@@ -182,7 +210,8 @@ typedef struct {
 int tmf_column_norms_batched(int dtype, const tmf_norms_desc* d_desc, int nprob, void* stream);
 
 /* normalise each column of A (n x c) by its 2-norm; optionally reverse column order
- * and flip the sign of odd columns (slater.py:410) while copying into dst            */
+ * and flip the sign of odd columns (slater.py:410) while copying into dst;
+ * reverse & 2: also take the complex conjugate                                        */
 typedef struct {
   uint64_t src, dst;
   int32_t n, c, lds_, ldd, reverse, flip_odd;

@@ -43,6 +43,12 @@ pf_desc = np.dtype([("N", "<u8"), ("scale", "<u8"), ("bra_idx", "<u8"), ("ket_id
                     ("nn", "<i4"), ("ldn", "<i4"), ("n1", "<i4"), ("n2", "<i4"), ("nsb", "<i4"), ("nsk", "<i4"),
                     ("a0", "<i4"), ("a1", "<i4")])
 assert pf_desc.itemsize == 72
+nambu_asm_desc = np.dtype([("src", "<u8"), ("dst", "<u8"), ("col_src", "<u8"), ("col_conj", "<u8"), ("n2", "<i4"),
+                           ("lds_", "<i4"), ("ldd", "<i4"), ("pad", "<i4")])
+nambu_w_desc = np.dtype([("Vr", "<u8"), ("W", "<u8"), ("idx1", "<u8"), ("idx2", "<u8"), ("L", "<i4"), ("na", "<i4"),
+                         ("nb", "<i4"), ("ldv", "<i4"), ("ldw", "<i4"), ("pad", "<i4")])
+pf_matrix_desc = np.dtype([("S", "<u8"), ("N", "<u8"), ("na", "<i4"), ("nb", "<i4"), ("lds_", "<i4"), ("ldn", "<i4")])
+assert nambu_asm_desc.itemsize == 48 and nambu_w_desc.itemsize == 56 and pf_matrix_desc.itemsize == 32
 site_job = np.dtype([("mode", "<i4"), ("cut_b", "<i4"), ("cut_k", "<i4"), ("k_b", "<i4"), ("nf_b", "<i4"),
                      ("k_k", "<i4"), ("nf_k", "<i4"), ("sec_cap", "<i4"), ("row_off", "<i8"), ("col_off", "<i8"),
                      ("bra_off", "<i8"), ("sec_off", "<i8"), ("idx_off", "<i8"), ("idx_cap", "<i8")])
@@ -55,7 +61,8 @@ SYMBOLS = [
     "tmf_last_error", "tmf_version", "tmf_device_count", "tmf_gemm_batched", "tmf_orth_panel_batched",
     "tmf_jacobi_batched", "tmf_lu_schur_batched", "tmf_det_gather_batched", "tmf_transpose", "tmf_fill_normal",
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_cut_vectors", "tmf_site_prepare",
-    "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_column_norms_batched", "tmf_det_reduced_batched", "tmf_pf_gather_batched",
+    "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_column_norms_batched", "tmf_det_reduced_batched", "tmf_pf_gather_batched", "tmf_nambu_assemble_batched",
+    "tmf_nambu_w_batched", "tmf_pf_matrix_batched",
 ]
 
 
@@ -85,6 +92,8 @@ def load():
     lib.tmf_det_gather_batched.argtypes = [i32, i32, vp, i32, i32, vp]
     lib.tmf_det_reduced_batched.argtypes = [i32, i32, vp, i32, i32, vp]
     lib.tmf_pf_gather_batched.argtypes = [i32, i32, vp, i32, i32, vp]
+    for fn in (lib.tmf_nambu_assemble_batched, lib.tmf_nambu_w_batched, lib.tmf_pf_matrix_batched):
+        fn.argtypes = [vp, i32, vp]
     lib.tmf_transpose.argtypes = [i32, vp, vp, i32, vp]
     lib.tmf_fill_normal.argtypes = [i32, vp, i64, u64, vp]
     lib.tmf_gather_signed_batched.argtypes = [i32, vp, i32, vp]

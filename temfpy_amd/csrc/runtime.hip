@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const tmf_gather_desc* __re
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
     const int r = e % d.rows, c = e / d.rows;
     const int sr = rs[r], sc_ = cs[c];
-    T v = (sr < 0) ? phys[(size_t)sc_ * d.ldp] : src[(size_t)sr + (size_t)sc_ * d.lds_];
+    T v = (sr < 0) ? phys[(size_t)(-sr - 1) + (size_t)sc_ * d.ldp] : src[(size_t)sr + (size_t)sc_ * d.lds_];
     const double sg = (double)(rg[r] * cg[c]);
     dst[(size_t)r + (size_t)c * d.ldd] = sc<T>::scale(v, sg);
   }
@@ -100,11 +100,14 @@ __global__ __launch_bounds__(256) void colnorm_kernel(const tmf_colnorm_desc* __
     if (lane == 0) red[wave] = s;
     __syncthreads();
     const double nrm = sqrt(red[0] + red[1] + red[2] + red[3]);
-    const int cd_ = d.reverse ? d.c - 1 - c : c;
+    const int cd_ = (d.reverse & 1) ? d.c - 1 - c : c;
     double f = nrm > 0.0 ? 1.0 / nrm : 0.0;
     if (d.flip_odd && (cd_ & 1)) f = -f;
-    for (int r = threadIdx.x; r < d.n; r += 256)
-      dst[(size_t)r + (size_t)cd_ * d.ldd] = sc<T>::scale(src[(size_t)r + (size_t)c * d.lds_], f);
+    for (int r = threadIdx.x; r < d.n; r += 256) {
+      T v = src[(size_t)r + (size_t)c * d.lds_];
+      if (d.reverse & 2) v = sc<T>::conj(v);
+      dst[(size_t)r + (size_t)cd_ * d.ldd] = sc<T>::scale(v, f);
+    }
   }
 }
 

@@ -205,6 +205,65 @@ class Engine:
         nat.check(self.lib.tmf_normalise_columns_batched(self.dtype, dd.data_ptr(), sel.size, self.stream),
                   "tmf_normalise_columns_batched")
 
+    def entangled_stage(self, L, n, m, blk, off, omp, doE, p, thr2, P):
+        """Stages E1-E7 of the module docstring for a batch of cut sides: returns the device
+        addresses of the Ritz vectors U_E (n x p per problem, leading dimension n), their Ritz values
+        (descending, d_e at offsets oS) and the number of directions above the threshold (d_cnt).
+        L is the leading dimension of the correlation matrix; blk / off / omp are device addresses
+        of the diagonal block, the off-diagonal block and the rows of Omega on the other side."""
+        torch = self.torch
+        el = self.elem
+        ncs = len(n)
+
+        def offsets(sizes):
+            o = np.concatenate(([0], np.cumsum(sizes)))
+            return o[:-1], int(o[-1])
+
+        oY, tY = offsets(n * p)
+        oB, tB = offsets(m * p)
+        oR, tR = offsets(p * p)
+        oS, tS = offsets(p)
+        d_Y, d_U0, d_W1 = self._alloc(tY), self._alloc(tY), self._alloc(tY)
+        d_Bt, d_Q2 = self._alloc(tB), self._alloc(tB)
+        d_R, d_Z, d_T, d_X = self._alloc(tR), self._alloc(tR), self._alloc(tR), self._alloc(tR)
+        d_sig = self._alloc(tS, real=True, zero=True)
+        d_e = self._alloc(tS, real=True, zero=True)
+        d_cnt = torch.zeros(ncs, dtype=torch.int32, device=self.device)
+        d_scr = self._alloc(ncs * P * PANEL_W)
+        Yp, U0p, W1p = (t.data_ptr() + oY * el for t in (d_Y, d_U0, d_W1))
+        Btp, Q2p = (t.data_ptr() + oB * el for t in (d_Bt, d_Q2))
+        Rp, Zp, Tp, Xp = (t.data_ptr() + oR * el for t in (d_R, d_Z, d_T, d_X))
+        sigp, ep = d_sig.data_ptr() + oS * 8, d_e.data_ptr() + oS * 8
+        cntp = d_cnt.data_ptr() + np.arange(ncs) * 4
+        scrp = d_scr.data_ptr() + np.arange(ncs) * P * PANEL_W * el
+        zero = np.zeros(ncs, np.int64)
+        ld1 = np.maximum(n, 1)
+
+        # E1: Y = F Omega
+        self.gemm(0, 1.0, 0.0, off, omp, Yp, n, p, m, L, L, ld1)
+        # E2: Q = qr(Y)
+        self.bcgs2(Yp[doE], n[doE], n[doE], zero[doE], p[doE], scrp[doE], passes=3)
+        # E3: B^H = F^H Q  (m x p), R = Q2^H B^H
+        self.gemm(1, 1.0, 0.0, off, Yp, Btp, m, p, n, L, ld1, np.maximum(m, 1))
+        torch.cuda.current_stream(self.device)  # (same stream; copy below is stream-ordered)
+        d_Q2.copy_(d_Bt)
+        self.bcgs2(Q2p[doE], m[doE], m[doE], zero[doE], p[doE], scrp[doE], passes=3)
+        self.gemm(1, 1.0, 0.0, Q2p, Btp, Rp, p, p, m, np.maximum(m, 1), np.maximum(m, 1), np.maximum(p, 1))
+        # E4: Jacobi SVD of R: right singular vectors Z, sigma; columns below the threshold zeroed
+        self.jacobi(Rp, Zp, sigp, cntp, thr2, p, np.maximum(p, 1), np.maximum(p, 1))
+        # E5: U0 = Q Z
+        self.gemm(0, 1.0, 0.0, Yp, Zp, U0p, n, p, p, ld1, np.maximum(p, 1), ld1)
+        # E6: T = U0^H (A U0), Jacobi eigen-decomposition
+        self.gemm(0, 1.0, 0.0, blk, U0p, W1p, n, p, n, L, ld1, ld1)
+        self.gemm(1, 1.0, 0.0, U0p, W1p, Tp, p, p, n, ld1, ld1, np.maximum(p, 1))
+        self.jacobi(Tp, Xp, ep, 0, 0.0, p, np.maximum(p, 1), np.maximum(p, 1))
+        # E7: U_E = U0 X  (reuses the Y buffer; Q is no longer needed)
+        self.gemm(0, 1.0, 0.0, U0p, Xp, Yp, n, p, p, ld1, np.maximum(p, 1), ld1)
+        UEp = Yp
+
+        return dict(UEp=UEp, oS=oS, d_e=d_e, d_cnt=d_cnt, ld1=ld1,
+                    keep=(d_Y, d_U0, d_W1, d_Bt, d_Q2, d_R, d_Z, d_T, d_X, d_sig, d_scr))
+
     # ------------------------------------------------------------------ the sweep
     def run(self, C, trunc, ortho_center, unit_cell_width, threads=None, download=True, site_range=None):
         """One C -> MPS conversion.
@@ -285,47 +344,8 @@ class Engine:
             return o[:-1], int(o[-1])
 
         t0 = time.perf_counter()
-        oY, tY = offsets(n * p)
-        oB, tB = offsets(m * p)
-        oR, tR = offsets(p * p)
-        oS, tS = offsets(p)
-        d_Y, d_U0, d_W1 = self._alloc(tY), self._alloc(tY), self._alloc(tY)
-        d_Bt, d_Q2 = self._alloc(tB), self._alloc(tB)
-        d_R, d_Z, d_T, d_X = self._alloc(tR), self._alloc(tR), self._alloc(tR), self._alloc(tR)
-        d_sig = self._alloc(tS, real=True, zero=True)
-        d_e = self._alloc(tS, real=True, zero=True)
-        d_cnt = torch.zeros(ncs, dtype=torch.int32, device=self.device)
-        d_scr = self._alloc(ncs * P * PANEL_W)
-        Yp, U0p, W1p = (t.data_ptr() + oY * el for t in (d_Y, d_U0, d_W1))
-        Btp, Q2p = (t.data_ptr() + oB * el for t in (d_Bt, d_Q2))
-        Rp, Zp, Tp, Xp = (t.data_ptr() + oR * el for t in (d_R, d_Z, d_T, d_X))
-        sigp, ep = d_sig.data_ptr() + oS * 8, d_e.data_ptr() + oS * 8
-        cntp = d_cnt.data_ptr() + np.arange(ncs) * 4
-        scrp = d_scr.data_ptr() + np.arange(ncs) * P * PANEL_W * el
-        zero = np.zeros(ncs, np.int64)
-        ld1 = np.maximum(n, 1)
-
-        # E1: Y = F Omega
-        self.gemm(0, 1.0, 0.0, off, omp, Yp, n, p, m, L, L, ld1)
-        # E2: Q = qr(Y)
-        self.bcgs2(Yp[doE], n[doE], n[doE], zero[doE], p[doE], scrp[doE], passes=3)
-        # E3: B^H = F^H Q  (m x p), R = Q2^H B^H
-        self.gemm(1, 1.0, 0.0, off, Yp, Btp, m, p, n, L, ld1, np.maximum(m, 1))
-        torch.cuda.current_stream(self.device)  # (same stream; copy below is stream-ordered)
-        d_Q2.copy_(d_Bt)
-        self.bcgs2(Q2p[doE], m[doE], m[doE], zero[doE], p[doE], scrp[doE], passes=3)
-        self.gemm(1, 1.0, 0.0, Q2p, Btp, Rp, p, p, m, np.maximum(m, 1), np.maximum(m, 1), np.maximum(p, 1))
-        # E4: Jacobi SVD of R: right singular vectors Z, sigma; columns below the threshold zeroed
-        self.jacobi(Rp, Zp, sigp, cntp, thr2, p, np.maximum(p, 1), np.maximum(p, 1))
-        # E5: U0 = Q Z
-        self.gemm(0, 1.0, 0.0, Yp, Zp, U0p, n, p, p, ld1, np.maximum(p, 1), ld1)
-        # E6: T = U0^H (A U0), Jacobi eigen-decomposition
-        self.gemm(0, 1.0, 0.0, blk, U0p, W1p, n, p, n, L, ld1, ld1)
-        self.gemm(1, 1.0, 0.0, U0p, W1p, Tp, p, p, n, ld1, ld1, np.maximum(p, 1))
-        self.jacobi(Tp, Xp, ep, 0, 0.0, p, np.maximum(p, 1), np.maximum(p, 1))
-        # E7: U_E = U0 X  (reuses the Y buffer; Q is no longer needed)
-        self.gemm(0, 1.0, 0.0, U0p, Xp, Yp, n, p, p, ld1, np.maximum(p, 1), ld1)
-        UEp = Yp
+        st = self.entangled_stage(L, n, m, blk, off, omp, doE, p, thr2, P)
+        UEp, oS, d_e, d_cnt, ld1 = st["UEp"], st["oS"], st["d_e"], st["d_cnt"], st["ld1"]
         self._tick("E_entangled", t0)
 
         # ---- host round trip 1: eigenvalues -> classification, filled counts ------------------

@@ -1,0 +1,489 @@
+"""Host driver of the MI355X Pfaffian (BCS / Nambu mean-field) -> MPS sweep.
+
+Mirrors pfaffian.C_to_MPS (pfaffian.py:1785-1921) with the same batching idea as engine.py: all
+cuts and all sites of the chain are independent given the Nambu correlation matrix, so every
+stage is one batched launch.  C is a projector here as well, and in the Majorana basis
+1 - A = conj(A) for every diagonal block A, which gives the whole Bogoliubov matrix of a cut side
+from the Slater building blocks:
+
+  entangled pairs (lambda, 1 - lambda)   left singular vectors of the off-diagonal block, Rayleigh-Ritz
+                                         (Engine.entangled_stage; 2 k_e directions above the threshold)
+  filled basis  (lambda ~ 1)             dominant subspace of A, orthogonal to the entangled vectors
+  empty basis   (lambda ~ 0)             complex conjugate of the filled basis (Nambu symmetry,
+                                         pfaffian.py:886,891)
+  vacuum parity                          det(v) = (-1)^(p + n(n-1)/2) with the LU kernel instead of the
+                                         singular-value gap rule of pfaffian.py:396-456
+  _pfaffian_matrix (pfaffian.py:1258-1410)  one LU / Schur pass on [[U^*, Q], [P, 0]] (nambu.hip)
+  _tensor_block    (pfaffian.py:1429-1479)  gathered-Pfaffian kernel (pf_gather.hip)
+
+Limits of this round: no eigenvalue-1/2 modes (kh = 0, i.e. no Majorana zero modes at a cut),
+at most 31 entangled pairs per cut, sub-Pfaffians of order <= 32.
+"""
+from __future__ import annotations
+
+import logging
+import time
+
+import numpy as np
+
+from . import _native as nat
+from .engine import Engine, P_RANGE, PANEL_W, _cdiv, _sector_list
+
+logger = logging.getLogger("temfpy_amd.pfaffian")
+
+
+def parity_n_argsort(exc):
+    """pfaffian.py:986-997."""
+    exc = np.asarray(exc).ravel()
+    return np.lexsort((np.arange(len(exc)), exc, exc % 2))
+
+
+def _bunched(x):
+    idx = np.nonzero(x[1:] != x[:-1])[0]
+    idx = np.concatenate(([0], idx + 1, [len(x)]))
+    return {int(x[idx[i]]): (int(idx[i]), int(idx[i + 1])) for i in range(len(idx) - 1)}
+
+
+class PfBond:
+    """Schmidt data of one cut (pfaffian.SchmidtVectors)."""
+
+    def __init__(self, x, e, pL, pR, sets, lam_raw):
+        self.x, self.e, self.pL, self.pR = x, e, pL, pR
+        self.sets = sets                      # (chi, k) bool, sorted by (parity, number)
+        self.lam_raw = lam_raw
+        self.lam = lam_raw / np.linalg.norm(lam_raw)
+        exc = sets.sum(axis=1)
+        self.idx_n = _bunched(exc)
+        self.idx_parity = _bunched(exc % 2)
+
+    @property
+    def chi(self):
+        return len(self.lam)
+
+    @property
+    def k(self):
+        return len(self.e)
+
+    def parity(self, which="T"):
+        return self.pL if which == "L" else self.pR if which == "R" else (self.pL + self.pR) % 2
+
+    def side_sets(self, side):
+        return self.sets if side == "L" else self.sets[:, ::-1]
+
+
+class PfSite:
+    def __init__(self, mode, norm, qtotal, leg_idx_bra, blocks, chi_bra, chi_ket):
+        self.mode, self.norm, self.qtotal = mode, norm, qtotal
+        self.leg_idx_bra = leg_idx_bra
+        self.blocks = blocks    # (n_bra, n_ket) -> (r0, r1, c0, c1, ndarray)
+        self.chi_bra, self.chi_ket = chi_bra, chi_ket
+
+    def dense(self):
+        M = np.zeros((2 * self.chi_bra, self.chi_ket), complex)
+        for (r0, r1, c0, c1, blk) in self.blocks.values():
+            M[self.leg_idx_bra[r0:r1], c0:c1] = blk
+        t = M.reshape(2, self.chi_bra, self.chi_ket)  # LegPipe([p, bra], sort=False): p more major
+        return t if self.mode == "left" else t.transpose(0, 2, 1)
+
+
+class PfMPSData:
+    def __init__(self, bonds, sites, ortho_center, unit_cell_width, timings):
+        self.bonds, self.sites = bonds, sites
+        self.L = len(sites)
+        self.ortho_center, self.unit_cell_width = ortho_center, unit_cell_width
+        self.form = ["A"] * ortho_center + ["B"] * (self.L - ortho_center)
+        self.timings = timings
+
+    @property
+    def lam(self):
+        return [b.lam for b in self.bonds]
+
+    @property
+    def chi(self):
+        return [b.chi for b in self.bonds]
+
+    def entanglement_entropy(self, all_bonds=False):
+        out = np.zeros(self.L + 1)
+        for i, b in enumerate(self.bonds):
+            p = b.lam**2
+            p = p[p > 0]
+            out[i] = -(p * np.log(p)).sum()
+        return out if all_bonds else out[1:-1]
+
+    def dense_tensors(self):
+        return [s.dense() for s in self.sites]
+
+
+class PfEngine(Engine):
+    def run(self, C, trunc, ortho_center, unit_cell_width, threads=None):
+        torch = self.torch
+        t_all = time.perf_counter()
+        self.timings = {}
+        self.det_events, self.gemm_events = [], []
+        torch.cuda.current_stream(self.device).synchronize()
+        self._pin_off = 0
+        self.dtype, self.elem = nat.TMF_C128, 16
+        el = 16
+        C = np.ascontiguousarray(C, np.complex128)
+        D = len(C)            # 2 L
+        L = D // 2
+        oc = ortho_center
+        cutoff = trunc.svd_min**2
+        thr2 = cutoff * (1.0 - cutoff)
+        deg_tol = trunc.degeneracy_tol
+
+        def offsets(sizes):
+            o = np.concatenate(([0], np.cumsum(sizes)))
+            return o[:-1].astype(np.int64), int(o[-1])
+
+        t0 = time.perf_counter()
+        d_Crm = torch.from_numpy(C.reshape(-1)).to(self.device)
+        d_C = self._alloc(D * D)
+        nat.check(self.lib.tmf_transpose(self.dtype, d_Crm.data_ptr(), d_C.data_ptr(), D, self.stream), "transpose")
+        Cp = d_C.data_ptr()
+        P = P_RANGE
+        d_Om = self._alloc(D * P)
+        nat.check(self.lib.tmf_fill_normal(self.dtype, d_Om.data_ptr(), D * P, 0x5EED2, self.stream), "fill")
+        self._tick("upload", t0)
+
+        # ---- cut sides ----------------------------------------------------------------------------
+        cs_b, cs_side = [], []
+        for b in range(L + 1):
+            if b <= oc:
+                cs_b.append(b), cs_side.append(0)
+            if b >= oc:
+                cs_b.append(b), cs_side.append(1)
+        cs_b, cs_side = np.array(cs_b), np.array(cs_side)
+        ncs = len(cs_b)
+        ns = np.where(cs_side == 0, cs_b, L - cs_b)     # sites of the block
+        n = 2 * ns                                       # dimension of the Nambu block
+        m = D - n
+        blk = Cp + np.where(cs_side == 0, 0, 2 * cs_b + 2 * cs_b * D) * el
+        off = Cp + np.where(cs_side == 0, 2 * cs_b * D, 2 * cs_b) * el
+        omp = d_Om.data_ptr() + np.where(cs_side == 0, 2 * cs_b, 0) * el
+        cidx = {(int(b), int(s_)): i for i, (b, s_) in enumerate(zip(cs_b, cs_side))}
+        centre_L, centre_R = cidx[(oc, 0)], cidx[(oc, 1)]
+        doE = (n > 0) & (m > 0)
+        doE[centre_R] = False
+        p = np.where(doE, np.minimum(P, np.minimum(n, m)), 0)
+
+        t0 = time.perf_counter()
+        st = self.entangled_stage(D, n, m, blk, off, omp, doE, p, thr2, P)
+        UEp, oS, ld1 = st["UEp"], st["oS"], st["ld1"]
+        self._tick("E_entangled", t0)
+
+        # ---- host round trip 1: pairs (lambda, 1 - lambda) --------------------------------------------
+        t0 = time.perf_counter()
+        h_e, h_cnt = st["d_e"].cpu().numpy(), st["d_cnt"].cpu().numpy()
+        ke = np.zeros(ncs, np.int64)
+        e_cut = [np.zeros(0)] * ncs
+        for i in range(ncs):
+            if not doE[i]:
+                continue
+            cnt = int(h_cnt[i])
+            if cnt >= p[i] and p[i] == P and P < min(n[i], m[i]):
+                raise NotImplementedError(f"cut {cs_b[i]}: more than {P // 2 - 1} entangled pairs (LDS Jacobi limit)")
+            lam = h_e[oS[i]: oS[i] + cnt]
+            if cnt % 2 or np.abs(lam + lam[::-1] - 1.0).max(initial=0.0) > 1e-8:
+                raise ValueError("Eigenvalues break Nambu symmetry")  # pfaffian.py:799-800
+            if np.any(np.abs(lam - 0.5) <= deg_tol):
+                raise NotImplementedError("eigenvalue-1/2 modes (Majorana zero modes at a cut) are not supported yet")
+            ke[i] = cnt // 2
+            e_cut[i] = lam[ke[i]:][::-1].copy()     # lower half, ascending (pfaffian.py:839)
+        ke[centre_R] = ke[centre_L]
+        e_cut[centre_R] = e_cut[centre_L]
+        nb_ = ns - ke                                  # filled / empty basis vectors
+        self._tick("host_classify", t0)
+
+        # ---- mode blocks Vtmp = [entangled (2 ke, Ritz order: lambda descending) | filled basis] -----
+        t0 = time.perf_counter()
+        ncol = 2 * ke + nb_
+        oV, tV = offsets(n * ncol)
+        d_Vt = self._alloc(tV)
+        Vt = d_Vt.data_ptr() + oV * el
+        cp = doE.copy()
+        self.colcopy(UEp[cp], Vt[cp], n[cp], 2 * ke[cp], ld1[cp], ld1[cp])
+        kc = int(ke[centre_L])
+        if kc > 0 and n[centre_R] > 0:
+            # paired upper modes of the centre's right side: normalise(C_RL v_L,i) (block_svd, pfaffian.py:855)
+            d_pair = self._alloc(n[centre_R] * kc)
+            self.gemm(0, 1.0, 0.0, [off[centre_R]], [Vt[centre_L] + kc * ld1[centre_L] * el], [d_pair.data_ptr()],
+                      [n[centre_R]], [kc], [m[centre_R]], [D], [ld1[centre_L]], [ld1[centre_R]])
+            self.colcopy([d_pair.data_ptr()], [Vt[centre_R]], [n[centre_R]], [kc], [ld1[centre_R]], [ld1[centre_R]],
+                         reverse=1)
+            self.colcopy([d_pair.data_ptr()], [Vt[centre_R] + kc * ld1[centre_R] * el], [n[centre_R]], [kc],
+                         [ld1[centre_R]], [ld1[centre_R]], reverse=2)
+        maxnb = int(nb_.max())
+        if maxnb > 0:
+            d_OmF = self._alloc(D * maxnb)
+            nat.check(self.lib.tmf_fill_normal(self.dtype, d_OmF.data_ptr(), D * maxnb, 0xF111EE, self.stream), "fill")
+            oY1, tY1 = offsets(n * nb_)
+            d_Y1 = self._alloc(tY1)
+            Y1p = d_Y1.data_ptr() + oY1 * el
+            Vf = Vt + 2 * ke * ld1 * el
+            self.gemm(0, 1.0, 0.0, blk, d_OmF.data_ptr(), Y1p, n, nb_, n, D, D, ld1)
+            self.gemm(0, 1.0, 0.0, blk, Y1p, Vf, n, nb_, n, D, ld1, ld1)
+            d_scr2 = self._alloc(int((ncol.max() + 1) * PANEL_W) * ncs)
+            scr2 = d_scr2.data_ptr() + np.arange(ncs) * int((ncol.max() + 1) * PANEL_W) * el
+            has = nb_ > 0
+            self.bcgs2(Vt[has], n[has], ld1[has], 2 * ke[has], ncol[has], scr2[has])
+        # ---- Bogoliubov matrices v = [a | a^dag] in the complex-fermion basis (pfaffian.py:880-895) ----
+        oVC, tVC = offsets(n * n)
+        d_VC, d_VW = self._alloc(tVC), self._alloc(tVC)
+        VC, VW = d_VC.data_ptr() + oVC * el, d_VW.data_ptr() + oVC * el
+        cs_off, cs_tot = offsets(n)
+        col_src, col_conj = np.zeros(cs_tot + 1, np.int32), np.zeros(cs_tot + 1, np.int8)
+        for i in range(ncs):
+            k_, q_, o_ = int(ke[i]), int(ns[i]), int(cs_off[i])
+            if q_ == 0:
+                continue
+            src, cj = np.zeros(2 * q_, np.int32), np.zeros(2 * q_, np.int8)
+            if cs_side[i] == 0:   # lower modes: [empty = conj(filled) | entangled lower, ascending]; upper = conj
+                src[: q_ - k_] = 2 * k_ + np.arange(q_ - k_)
+                cj[: q_ - k_] = 1
+                src[q_ - k_: q_] = 2 * k_ - 1 - np.arange(k_)
+                src[q_:], cj[q_:] = src[:q_], 1 - cj[:q_]
+            else:                 # upper modes: [entangled upper, ascending | filled]; lower = conj
+                src[q_: q_ + k_] = k_ - 1 - np.arange(k_)
+                src[q_ + k_:] = 2 * k_ + np.arange(q_ - k_)
+                src[:q_], cj[:q_] = src[q_:], 1
+            col_src[o_: o_ + 2 * q_], col_conj[o_: o_ + 2 * q_] = src, cj
+        t_cs, t_cj = self._up(col_src), self._up(col_conj)
+        ad = np.zeros(ncs, nat.nambu_asm_desc)
+        ad["src"], ad["dst"] = Vt, VC
+        ad["col_src"], ad["col_conj"] = t_cs.data_ptr() + cs_off * 4, t_cj.data_ptr() + cs_off
+        ad["n2"], ad["lds_"], ad["ldd"] = n, ld1, ld1
+        sel = np.nonzero(n > 0)[0]
+        t_ad = self._up(ad[sel])
+        nat.check(self.lib.tmf_nambu_assemble_batched(t_ad.data_ptr(), len(sel), self.stream), "nambu_assemble")
+        # ---- vacuum parities from det(v) (LU on a copy) ---------------------------------------------
+        d_VW.copy_(d_VC)
+        d_pdet = self._alloc(ncs, zero=True)
+        sd = np.zeros(ncs, nat.schur_desc)
+        sd["W"], sd["S"], sd["det"] = VW, 0, d_pdet.data_ptr() + np.arange(ncs) * el
+        sd["mb"], sd["mk"], sd["k"], sd["ldw"], sd["lds"] = n, n, n, ld1, 1
+        t_sd = self._up(sd[sel])
+        nat.check(self.lib.tmf_lu_schur_batched(self.dtype, t_sd.data_ptr(), len(sel), int(n.max()), self.stream), "lu")
+        self._tick("F_modes_parity", t0)
+
+        t0 = time.perf_counter()
+        h_pdet = d_pdet.cpu().numpy()
+        par = np.zeros(ncs, np.int64)
+        for i in range(ncs):
+            if ns[i] == 0:
+                continue
+            sgn = -1.0 if (ns[i] * (ns[i] - 1) // 2) % 2 else 1.0
+            dv = h_pdet[i].real * sgn
+            if abs(abs(dv) - 1.0) > 1e-6 or abs(h_pdet[i].imag) > 1e-6:
+                raise ValueError(f"cut {cs_b[i]}: Bogoliubov matrix is not unitary (det = {h_pdet[i]})")
+            par[i] = 0 if dv > 0 else 1
+        total_parity = int((par[centre_L] + par[centre_R]) % 2)
+        pL, pR = np.zeros(L + 1, np.int64), np.zeros(L + 1, np.int64)
+        for b in range(L + 1):
+            if b <= oc:
+                pL[b] = par[cidx[(b, 0)]]
+                pR[b] = par[centre_R] if b == oc else (total_parity + pL[b]) % 2   # pfaffian.py:902-903
+            else:
+                pR[b] = par[cidx[(b, 1)]]
+                pL[b] = (total_parity + pR[b]) % 2                                  # pfaffian.py:909-910
+        flip_centre_R = pL[oc] == 1                                                 # pfaffian.py:915-916
+
+        # ---- enumeration (same native routine as the Slater path, no filled offsets) ------------------
+        sectors = _sector_list(trunc, L)
+        bonds = []
+        for b in range(L + 1):
+            e_b = e_cut[cidx[(b, 0)]] if b <= oc else e_cut[cidx[(b, 1)]]
+            sets_m, lam_raw, q, _ = nat.cut_vectors(e_b, 0, trunc.chi_max or 0, trunc.svd_min, trunc.degeneracy_tol,
+                                                    sectors)
+            if len(lam_raw) == 0:
+                raise ValueError("No Schmidt vectors left after filtering by `trunc_par.sectors`!")
+            kk = len(e_b)
+            sb_ = np.zeros((len(sets_m), kk), bool)
+            for i in range(kk):
+                sb_[:, i] = (sets_m[:, i // 64] >> np.uint64(i % 64)) & np.uint64(1)
+            idx = parity_n_argsort(sb_.sum(axis=1))                                   # pfaffian.py:1195-1197
+            bonds.append(PfBond(b, e_b, int(pL[b]), int(pR[b]), sb_[idx], lam_raw[idx]))
+        self._tick("host_enumerate", t0)
+
+        # ---- per-site integer preparation (pfaffian.py:1617-1733, :1361-1408, :1766-1776) ---------------
+        t0 = time.perf_counter()
+        prep = []
+        for i in range(L):
+            mode = 0 if i < oc else 1
+            side = "L" if mode == 0 else "R"
+            bb, kb = (i, i + 1) if mode == 0 else (i + 1, i)
+            B, K = bonds[bb], bonds[kb]
+            ib, ik = cidx[(bb, mode)], cidx[(kb, mode)]
+            nbs, nks = int(ns[ib]), int(ns[ik])          # sites: nks = nbs + 1
+            sets1 = B.side_sets(side)
+            chi_b = len(sets1)
+            z, o = np.zeros((chi_b, 1), bool), np.ones((chi_b, 1), bool)
+            sets1 = np.block([[sets1, z], [sets1, o]]) if mode == 0 else np.block([[z, sets1], [o, sets1]])
+            fix = B.parity(side) % 2 != K.parity(side) % 2
+            u_p = -1 if (mode == 0 and B.parity("L") % 2 == 1) else 1
+            # rows of Vr = columns of the extended bra matrix: [a (nks) | a^dag (nks)]
+            rs, rg = np.zeros(2 * nks, np.int32), np.ones(2 * nks, np.int8)
+            if mode == 0:   # physical orbital last (pfaffian.py:1667-1673); its rows are -1 (c^dag) and -2 (c)
+                rs[:nbs], rs[nbs] = np.arange(nbs), -1
+                rs[nks: nks + nbs], rs[nks + nbs] = nbs + np.arange(nbs), -2
+                rg[nbs] = rg[nks + nbs] = u_p
+                if fix:     # swap the physical a and a^dag columns, flip the last set bit (pfaffian.py:1711-1713)
+                    rs[nbs], rs[nks + nbs] = -2, -1
+                    sets1 = sets1.copy()
+                    sets1[:, -1] = ~sets1[:, -1]
+            else:           # physical orbital first (pfaffian.py:1682-1688)
+                rs[0], rs[1: nks] = -1, np.arange(nbs)
+                rs[nks], rs[nks + 1:] = -2, nbs + np.arange(nbs)
+                if fix:     # pfaffian.py:1714-1719: all Bogoliubov columns negated, physical pair swapped
+                    rg[:] = -1
+                    rs[0], rs[nks] = -2, -1
+                    rg[0] = rg[nks] = 1
+                    sets1 = sets1.copy()
+                    sets1[:, 0] = ~sets1[:, 0]
+            sets2 = K.side_sets(side)
+            act1, act2 = sets1.shape[1], sets2.shape[1]
+            i1 = np.nonzero(sets1.any(axis=0))[0]
+            i2 = np.nonzero(sets2.any(axis=0))[0][::-1]
+            s1, s2 = sets1[:, i1], sets2[:, i2]
+            if mode == 0:   # active modes at the end (pfaffian.py:1377-1379)
+                i1, i2 = i1 + nks - act1, i2 + nks - act2
+            na_, nb2 = len(i1), len(i2)
+            new1 = np.concatenate((np.zeros((len(s1), nb2), bool), s1), axis=1)
+            new2 = np.concatenate((s2, np.zeros((len(s2), na_), bool)), axis=1)
+            leg_idx = parity_n_argsort(new1.sum(axis=1))
+            new1 = new1[leg_idx]
+            idx_n_bra = _bunched(new1.sum(axis=1))
+            blocks = []
+            for nbq, (r0, r1) in idx_n_bra.items():
+                for nkq, (c0, c1) in K.idx_n.items():
+                    if (nbq + nkq) % 2 == 0:
+                        blocks.append((nbq, nkq, r0, r1, c0, c1))
+            prep.append(dict(mode=mode, ib=ib, ik=ik, nbs=nbs, nks=nks, rs=rs, rg=rg, i1=i1.astype(np.int32),
+                             i2=i2.astype(np.int32), na=na_, nb=nb2, new1=new1, new2=new2, leg_idx=leg_idx,
+                             blocks=blocks, chi_b=chi_b, chi_k=len(sets2),
+                             col_sign=-1 if (mode == 1 and kb == oc and flip_centre_R) else 1))
+        self._tick("host_site_prepare", t0)
+
+        # ---- device: Vr = ext^H v_ket, W, LU/Schur, Pfaffian matrix -------------------------------------
+        t0 = time.perf_counter()
+        ib = np.array([r["ib"] for r in prep])
+        ik = np.array([r["ik"] for r in prep])
+        mode = np.array([r["mode"] for r in prep])
+        nb2n, nk2n = n[ib], n[ik]                       # 2 nbs, 2 nks
+        Lk = nk2n // 2
+        na_v = np.array([r["na"] for r in prep])
+        nb_v = np.array([r["nb"] for r in prep])
+        oO, tO = offsets(nb2n * nk2n)
+        oVr, tVr = offsets(nk2n * nk2n)
+        mw = Lk + na_v + nb_v
+        oW, tW = offsets(mw * mw)
+        mn = na_v + nb_v
+        oN, tN = offsets(mn * mn)
+        d_O, d_Vr, d_W, d_N = self._alloc(tO), self._alloc(tVr), self._alloc(tW), self._alloc(tN)
+        d_det, d_norm = self._alloc(L), self._alloc(L)
+        Op, Vrp, Wp, Np = (t.data_ptr() + o * el for t, o in ((d_O, oO), (d_Vr, oVr), (d_W, oW), (d_N, oN)))
+        detp, normp = d_det.data_ptr() + np.arange(L) * el, d_norm.data_ptr() + np.arange(L) * el
+        Vk_sub = VC[ik] + np.where(mode == 1, 2, 0) * el     # right mode: the site's rows are rows 0, 1 of the ket
+        physp = VC[ik] + np.where(mode == 1, 0, nb2n) * el
+        self.gemm(1, 1.0, 0.0, VC[ib], Vk_sub, Op, nb2n, nk2n, nb2n, ld1[ib], ld1[ik], np.maximum(nb2n, 1))
+        rs_off, rs_tot = offsets(nk2n)
+        row_sel = np.concatenate([r["rs"] for r in prep]).astype(np.int32)
+        row_sign = np.concatenate([r["rg"] for r in prep]).astype(np.int8)
+        col_sel = np.concatenate([np.arange(x, dtype=np.int32) for x in nk2n])
+        col_sign = np.concatenate([np.full(x, r["col_sign"], np.int8) for x, r in zip(nk2n, prep)])
+        t_rs, t_rg, t_cs2, t_cg = self._up(row_sel), self._up(row_sign), self._up(col_sel), self._up(col_sign)
+        gd = np.zeros(L, nat.gather_desc)
+        gd["src"], gd["dst"] = Op, Vrp
+        gd["row_sel"], gd["col_sel"] = t_rs.data_ptr() + rs_off * 4, t_cs2.data_ptr() + rs_off * 4
+        gd["row_sign"], gd["col_sign"] = t_rg.data_ptr() + rs_off, t_cg.data_ptr() + rs_off
+        gd["phys"] = physp
+        gd["rows"], gd["cols"] = nk2n, nk2n
+        gd["lds_"], gd["ldd"], gd["ldp"] = np.maximum(nb2n, 1), nk2n, ld1[ik]
+        t_gd = self._up(gd)
+        nat.check(self.lib.tmf_gather_signed_batched(self.dtype, t_gd.data_ptr(), L, self.stream), "gather")
+        i1_off, i1_tot = offsets(na_v)
+        i2_off, i2_tot = offsets(nb_v)
+        t_i1 = self._up(np.concatenate([r["i1"] for r in prep] + [np.zeros(1, np.int32)]))
+        t_i2 = self._up(np.concatenate([r["i2"] for r in prep] + [np.zeros(1, np.int32)]))
+        wd = np.zeros(L, nat.nambu_w_desc)
+        wd["Vr"], wd["W"] = Vrp, Wp
+        wd["idx1"], wd["idx2"] = t_i1.data_ptr() + i1_off * 4, t_i2.data_ptr() + i2_off * 4
+        wd["L"], wd["na"], wd["nb"], wd["ldv"], wd["ldw"] = Lk, na_v, nb_v, nk2n, mw
+        t_wd = self._up(wd)
+        nat.check(self.lib.tmf_nambu_w_batched(t_wd.data_ptr(), L, self.stream), "nambu_w")
+        sd = np.zeros(L, nat.schur_desc)
+        sd["W"], sd["S"], sd["det"] = Wp, 0, detp
+        sd["mb"], sd["mk"], sd["k"], sd["ldw"], sd["lds"] = mw, mw, Lk, mw, 1
+        t_sd2 = self._up(sd)
+        nat.check(self.lib.tmf_lu_schur_batched(self.dtype, t_sd2.data_ptr(), L, int(mw.max()), self.stream), "lu_schur")
+        pd = np.zeros(L, nat.pf_matrix_desc)
+        pd["S"], pd["N"] = Wp + (Lk + Lk * mw) * el, Np
+        pd["na"], pd["nb"], pd["lds_"], pd["ldn"] = na_v, nb_v, mw, np.maximum(mn, 1)
+        t_pd = self._up(pd)
+        nat.check(self.lib.tmf_pf_matrix_batched(t_pd.data_ptr(), L, self.stream), "pf_matrix")
+        # Onishi norm sqrt(prod sv(U)) = |det U|^(1/2) (pfaffian.py:1352-1359): tiny, on the host
+        h_det = d_det.cpu().numpy()
+        norms = np.sqrt(np.abs(h_det)).astype(np.complex128)
+        d_norm.copy_(torch.from_numpy(norms).to(self.device))
+        self._tick("S_overlap_schur", t0)
+
+        # ---- all sub-Pfaffians ------------------------------------------------------------------------------
+        t0 = time.perf_counter()
+        out_sizes = [sum((r1 - r0) * (c1 - c0) for (_, _, r0, r1, c0, c1) in r["blocks"]) for r in prep]
+        out_off, out_tot = offsets(np.array(out_sizes))
+        d_out = self._alloc(out_tot)
+        pool_parts, tiles = [], {}
+        pool_off = 0
+        a16 = lambda x: (x + 15) & ~15  # noqa: E731
+        lds_need = {}
+        for i, r in enumerate(prep):
+            o = int(out_off[i])
+            r["block_out"] = []
+            for (nbq, nkq, r0, r1, c0, c1) in r["blocks"]:
+                bl = np.nonzero(r["new1"][r0:r1])[1].astype(np.uint8).reshape(r1 - r0, nbq)
+                kl = np.nonzero(r["new2"][c0:c1])[1].astype(np.uint8).reshape(c1 - c0, nkq)
+                bo, ko = pool_off, pool_off + bl.size
+                pool_parts += [bl.reshape(-1), kl.reshape(-1)]
+                pool_off += bl.size + kl.size
+                mq = nbq + nkq
+                if mq > 32:
+                    raise NotImplementedError(f"sub-Pfaffian of order {mq} > 32")
+                nsb, nsk = r1 - r0, c1 - c0
+                ta = max(1, min(nsb, _cdiv(2048, nsk)))
+                G = 8 if mq <= 8 else 16 if mq <= 16 else 32
+                need = (a16(int(mn[i]) ** 2 * el) + a16(nsk * nkq) + a16(ta * nbq) + (256 // G) * 2 * max(mq, 1) * el + 16)
+                lds_need[mq] = max(lds_need.get(mq, 0), need)
+                for a0 in range(0, nsb, ta):
+                    tiles.setdefault(mq, []).append((Np[i], normp[i], bo, ko, d_out.data_ptr() + o * el, int(mn[i]),
+                                                     int(max(mn[i], 1)), nbq, nkq, nsb, nsk, a0, min(nsb, a0 + ta)))
+                r["block_out"].append(o)
+                o += nsb * nsk
+        pool = np.concatenate(pool_parts + [np.zeros(1, np.uint8)]) if pool_parts else np.zeros(1, np.uint8)
+        t_pool = self._up(pool)
+        for mq, tl in tiles.items():
+            dd = np.zeros(len(tl), nat.pf_desc)
+            arr = np.array(tl, dtype=np.int64)
+            for j, f in enumerate(("N", "scale", "bra_idx", "ket_idx", "out", "nn", "ldn", "n1", "n2", "nsb", "nsk", "a0", "a1")):
+                dd[f] = arr[:, j]
+            dd["bra_idx"] += t_pool.data_ptr()
+            dd["ket_idx"] += t_pool.data_ptr()
+            t_dd = self._up(dd)
+            nat.check(self.lib.tmf_pf_gather_batched(self.dtype, mq, t_dd.data_ptr(), len(dd), int(lds_need[mq]),
+                                                     self.stream), "tmf_pf_gather_batched")
+        self._tick("S_pfaffians", t0)
+
+        t0 = time.perf_counter()
+        h_out = d_out.cpu().numpy()
+        sites = []
+        for i, r in enumerate(prep):
+            blocks = {}
+            for (nbq, nkq, r0, r1, c0, c1), o in zip(r["blocks"], r["block_out"]):
+                blocks[(nbq, nkq)] = (r0, r1, c0, c1, h_out[o: o + (r1 - r0) * (c1 - c0)].reshape(r1 - r0, c1 - c0))
+            bb, kb = (i, i + 1) if r["mode"] == 0 else (i + 1, i)
+            qtotal = 0 if r["mode"] == 0 else int((bonds[bb].parity() + bonds[kb].parity()) % 2)
+            sites.append(PfSite("left" if r["mode"] == 0 else "right", float(norms[i].real), qtotal, r["leg_idx"],
+                                blocks, r["chi_b"], r["chi_k"]))
+        self._tick("download", t0)
+        self.timings["total"] = time.perf_counter() - t_all
+        self._keep.clear()
+        return PfMPSData(bonds, sites, oc, unit_cell_width, dict(self.timings))

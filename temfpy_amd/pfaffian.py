@@ -1,0 +1,130 @@
+"""BCS / Pfaffian mean-field state -> MPS with TeMFpy's entry points (temfpy/pfaffian.py), on MI355X.
+
+Same names, arguments and defaults as the reference for the converter entry points
+(pfaffian.py:1785-1793, :2094-2102, :302-304) and the basis-change helpers (pfaffian.py:75-184).
+Returns a :class:`temfpy_amd.engine_pf.PfMPSData` (parity-graded blocks, Schmidt values, vacuum
+parities); assembling a TeNPy ``MPS`` needs TeNPy's parity ``LegPipe`` and is not wired up yet.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+
+from .schmidt_utils import StoppingCondition, to_stopping_condition
+from .testing import _DIAG_TOL, assert_allclose, assert_array_less
+from .utils import HT
+
+logger = logging.getLogger(__name__)
+_ENGINES = {}
+
+_M_C2M = np.array([[1, 1], [1j, -1j]]) / 2**0.5   # pfaffian.py:93
+_M_M2C = np.array([[1, -1j], [1, 1j]]) / 2**0.5   # pfaffian.py:122
+
+
+def vector_C2M(v: np.ndarray) -> np.ndarray:
+    """pfaffian.py:75-101."""
+    n = v.shape[0]
+    assert n % 2 == 0, "Got vector(s) of odd size (cannot be Nambu)"
+    w = v.reshape(n // 2, 2, *v.shape[1:])
+    return np.einsum("xa...,ca->xc...", w, _M_C2M).reshape(n, *v.shape[1:])
+
+
+def vector_M2C(v: np.ndarray) -> np.ndarray:
+    """pfaffian.py:104-130."""
+    n = v.shape[0]
+    assert n % 2 == 0, "Got vector(s) of odd size (cannot be Nambu)"
+    w = v.reshape(n // 2, 2, *v.shape[1:])
+    return np.einsum("xa...,ca->xc...", w, _M_M2C).reshape(n, *v.shape[1:])
+
+
+def matrix_C2M(H: np.ndarray) -> np.ndarray:
+    """pfaffian.py:133-157."""
+    n, m = H.shape
+    assert n % 2 == 0 and m % 2 == 0, "Got a matrix with odd side length (cannot be Nambu)"
+    return np.einsum("xayb,ca,db->xcyd", H.reshape(n // 2, 2, m // 2, 2), _M_C2M, _M_C2M.conj()).reshape(n, m)
+
+
+def matrix_M2C(H: np.ndarray) -> np.ndarray:
+    """pfaffian.py:160-184."""
+    n, m = H.shape
+    assert n % 2 == 0 and m % 2 == 0, "Got a matrix with odd side length (cannot be Nambu)"
+    return np.einsum("xayb,ca,db->xcyd", H.reshape(n // 2, 2, m // 2, 2), _M_M2C, _M_M2C.conj()).reshape(n, m)
+
+
+def assert_nambu(C, basis=None, offset=None, name="", rtol=0, atol=1e-10):
+    """pfaffian.py:189-286: Hermitise and enforce the Nambu structure (checks follow TEST_ACTION)."""
+    n, m = C.shape
+    assert n == m > 0, f"Got non-square {name}"
+    assert n % 2 == 0, f"Got {name} with odd side length (cannot be Nambu)"
+    n //= 2
+    tol = dict(atol=atol, rtol=rtol)
+    assert_allclose(C, HT(C), **tol, err_msg=f"{name} is not Hermitian")
+    C = (C + HT(C)) / 2
+    if basis == "M":
+        real = np.eye(2 * n) * offset / 2
+        assert_allclose(C.real, real, **tol, err_msg="Unexpected real parts in Majorana basis")
+        C = real + 1j * C.imag
+    elif basis == "C":
+        err = f"{name.capitalize()} is not Nambu symmetric"
+        assert_allclose(C[::2, ::2], offset * np.eye(n) - C[1::2, 1::2].conj(), **tol, err_msg=err)
+        assert_allclose(C[1::2, ::2], -C[::2, 1::2].conj(), **tol, err_msg=err)
+        if np.allclose(C.imag, 0, **tol):
+            C = C.real
+    elif basis is not None:
+        raise ValueError("Invalid `basis` " + repr(basis))
+    return C
+
+
+def correlation_matrix(H: np.ndarray, basis: str | None = None, *, rtol: float = 0, atol: float = 1e-10):
+    """Ground-state Nambu correlation matrix of a BdG Hamiltonian (pfaffian.py:302-393).
+    Outside the timed C -> MPS path; host LAPACK like the reference."""
+    assert basis in [None, "M->M", "M->C", "C->M", "C->C"], f"Invalid basis spec {basis!r}, should be of form '[MC]->[MC]'"
+    tol = dict(rtol=rtol, atol=atol)
+    H = assert_nambu(H, None if basis is None else basis[0], offset=0, name="Hamiltonian", **tol)
+    n = len(H) // 2
+    e, v = np.linalg.eigh(H)
+    assert_allclose(e + e[::-1], 0, **tol)
+    if np.any(abs(e) < atol):
+        raise RuntimeError("Some energy eigenvalues are zero. You need to construct\nyour own correlation matrix!\n"
+                           f"Middle 10 eigenvalues:\n{e[n - 5: n + 5, None]}")
+    assert_array_less(e[:n], 0, "Lower half of eigenvalues is not all negative")
+    v = v[:, :n]
+    if basis == "C->M":
+        v = vector_C2M(v)
+    elif basis == "M->C":
+        v = vector_M2C(v)
+    C = v @ HT(v)
+    return assert_nambu(C, None if basis is None else basis[3], offset=1, name="correlation matrix", **tol)
+
+
+def C_to_MPS(C: np.ndarray, trunc_par: dict | StoppingCondition, *, basis: str, diag_tol: float = _DIAG_TOL,
+             ortho_center: int = None, unit_cell_width: int | None = None, device: str = "cuda:0"):
+    """MPS of a BCS / Pfaffian state from its Nambu correlation matrix (pfaffian.py:1785-1921)."""
+    from .engine_pf import PfEngine
+
+    trunc_par = to_stopping_condition(trunc_par)
+    C = np.asarray(C)
+    L = len(C) // 2
+    if unit_cell_width is None:
+        unit_cell_width = L
+    elif L % unit_cell_width != 0:
+        raise ValueError(f"{unit_cell_width = } does not divide system size {L}")  # pfaffian.py:1839
+    if basis == "C":
+        C = matrix_C2M(C)  # pfaffian.py:750-751
+    elif basis != "M":
+        raise ValueError(f"Argument `basis` must be 'M' or 'C', got {basis!r}")
+    C = assert_nambu(np.asarray(C, complex), "M", offset=1, name="correlation matrix", atol=trunc_par.svd_min**2)
+    ortho_center = ortho_center or L // 2
+    logger.info("Central bond %d", ortho_center)
+    if device not in _ENGINES:
+        _ENGINES[device] = PfEngine(device)
+    return _ENGINES[device].run(C, trunc_par, ortho_center, unit_cell_width)
+
+
+def H_to_MPS(H: np.ndarray, trunc_par: dict | StoppingCondition, *, basis: str, diag_tol: float = _DIAG_TOL,
+             ortho_center: int = None, unit_cell_width: int | None = None, device: str = "cuda:0"):
+    """pfaffian.py:2094-2148."""
+    C = correlation_matrix(H, f"{basis}->M")
+    return C_to_MPS(C, trunc_par, basis="M", diag_tol=diag_tol, ortho_center=ortho_center,
+                    unit_cell_width=unit_cell_width, device=device)

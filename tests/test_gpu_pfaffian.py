@@ -1,0 +1,99 @@
+"""GPU parity tests of the Pfaffian (BCS) -> MPS sweep against the pinned oracle
+(oracle/pfaffian_oracle.py) and the reference-generated fixtures (tests/golden/pf_*.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import pfaffian_oracle as porc
+from oracle import slater_oracle as orc
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+NAMES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("pf_") and f.endswith(".npz"))
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def oracle_dense(cuts, sites):
+    T = []
+    for i, s in enumerate(sites):
+        bra, ket = (cuts[i], cuts[i + 1]) if s.mode == "left" else (cuts[i + 1], cuts[i])
+        cb, ck = len(bra.lam), len(ket.lam)
+        M = np.zeros((2 * cb, ck), complex)
+        for (r0, r1, c0, c1, blk) in s.blocks.values():
+            M[s.leg_idx_bra[r0:r1], c0:c1] = blk
+        t = M.reshape(2, cb, ck)
+        T.append(t if s.mode == "left" else t.transpose(0, 2, 1))
+    return T
+
+
+def check_against_oracle(C, chi, oc=None, tol=1e-9, elem_tol=1e-7):
+    from temfpy_amd import pfaffian
+
+    mps = pfaffian.C_to_MPS(C, {"chi_max": chi}, basis="M", ortho_center=oc)
+    cuts, sites = porc.c_to_mps(C, {"chi_max": chi}, oc)
+    L = len(C) // 2
+    o = oc or L // 2
+    for b in range(L + 1):
+        np.testing.assert_allclose(mps.bonds[b].e, cuts[b].e, rtol=0, atol=1e-13)
+        np.testing.assert_array_equal(mps.bonds[b].sets, cuts[b].sets)
+        assert (mps.bonds[b].pL, mps.bonds[b].pR) == (cuts[b].pL, cuts[b].pR)
+        np.testing.assert_allclose(mps.bonds[b].lam, cuts[b].lam, rtol=0, atol=1e-10)
+    for i in range(L):
+        assert abs(mps.sites[i].norm - abs(sites[i].norm)) < 1e-9
+        assert sorted(mps.sites[i].blocks) == sorted(sites[i].blocks)
+        np.testing.assert_array_equal(mps.sites[i].leg_idx_bra, sites[i].leg_idx_bra)
+        for key, (r0, r1, c0, c1, blk) in mps.sites[i].blocks.items():
+            ref = sites[i].blocks[key][4]
+            np.testing.assert_allclose(np.abs(blk), np.abs(ref), rtol=0, atol=elem_tol * max(1.0, np.abs(ref).max()))
+    T1, T2 = oracle_dense(cuts, sites), mps.dense_tensors()
+    n1 = abs(orc.mps_overlap(T1, cuts[o].lam, T1, cuts[o].lam, o))
+    n2 = abs(orc.mps_overlap(T2, mps.lam[o], T2, mps.lam[o], o))
+    ov = abs(orc.mps_overlap(T1, cuts[o].lam, T2, mps.lam[o], o)) / np.sqrt(n1 * n2)
+    assert abs(1 - ov) < tol
+    return mps
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_pfaffian_sweep_matches_reference_fixture(name):
+    g = load(name)
+    oc = int(g["kw_ortho_center"]) if "kw_ortho_center" in g else None
+    mps = check_against_oracle(g["C"], int(g["chi_max"]), oc)
+    L = int(g["L"])
+    for b in range(L + 1):
+        np.testing.assert_array_equal(mps.bonds[b].sets, g[f"b{b}_sets"])
+        np.testing.assert_allclose(mps.bonds[b].lam, g[f"b{b}_lam"], rtol=0, atol=1e-10)
+    for i in range(L):
+        np.testing.assert_allclose(mps.sites[i].norm, abs(g[f"s{i}_norm"]), rtol=1e-8)
+
+
+@pytest.mark.parametrize("L,chi,seed", [(12, 32, 7), (20, 64, 8), (32, 64, 9)])
+def test_pfaffian_sweep_larger_random(L, chi, seed):
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_golden_pfaffian import random_majorana_H
+
+    C = porc.correlation_matrix(random_majorana_H(L, seed))
+    # elementwise bound 1e-6: entries that involve modes within a decade of the 1e-12 cutoff are only
+    # determined to ~1e-16 / sqrt(1e-12) by C itself; the gauge-invariant overlap bound stays 1e-9
+    mps = check_against_oracle(C, chi, elem_tol=1e-6)
+    S = mps.entanglement_entropy(all_bonds=True)
+    cuts, _ = porc.c_to_mps(C, {"chi_max": chi})
+    Sref = np.array([-(c.lam**2 * np.log(c.lam**2)).sum() for c in cuts])
+    assert np.abs(S - Sref).max() < 1e-10
+
+
+def test_pfaffian_api_errors():
+    from temfpy_amd import pfaffian
+
+    with pytest.raises(ValueError):
+        pfaffian.C_to_MPS(np.eye(4) * 0.5, {"chi_max": 4}, basis="X")
+    with pytest.raises(ValueError):
+        pfaffian.C_to_MPS(np.eye(8) * 0.5, {"chi_max": 4}, basis="M", unit_cell_width=3)
+    with pytest.raises(AssertionError):
+        pfaffian.correlation_matrix(np.eye(4), "Q->M")
