@@ -198,7 +198,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"L={L} random complex hopping (seed 0, range 3) Slater->MPS, chi_max={chi}, "
                                    f"svd_min=1e-6; sites sharded over {world} rank(s)", "N_fermions": N,
-                       "stage_ms": {k: round(v * 1e3, 1) for k, v in mps.timings.items()}},
+                       "stage_ms": {k: round(v * 1e3, 1) for k, v in mps.timings.items()},
+                       "range_finder": {"subspace_iterations": eng.range_iterations_used,
+                                        "smallest_captured_sigma": eng.range_floor}},
             "roofline": roof, "value_pcie": None if value_pcie is None else round(value_pcie, 2),
         }
         if world == 1 and a.cpu_sample > 0:

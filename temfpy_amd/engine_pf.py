@@ -115,6 +115,8 @@ class PfMPSData:
 
 
 class PfEngine(Engine):
+    range_floor_tol = 3e-15  # see Engine.entangled_stage_adaptive
+
     def run(self, C, trunc, ortho_center, unit_cell_width, threads=None):
         torch = self.torch
         t_all = time.perf_counter()
@@ -168,13 +170,13 @@ class PfEngine(Engine):
         p = np.where(doE, np.minimum(P, np.minimum(n, m)), 0)
 
         t0 = time.perf_counter()
-        st = self.entangled_stage(D, n, m, blk, off, omp, doE, p, thr2, P)
+        st = self.entangled_stage_adaptive(D, n, m, blk, off, omp, doE, p, thr2, P, cs_b)
         UEp, oS, ld1 = st["UEp"], st["oS"], st["ld1"]
         self._tick("E_entangled", t0)
 
         # ---- host round trip 1: pairs (lambda, 1 - lambda) --------------------------------------------
         t0 = time.perf_counter()
-        h_e, h_cnt = st["d_e"].cpu().numpy(), st["d_cnt"].cpu().numpy()
+        h_e, h_cnt = st["h_e"], st["h_cnt"]
         ke = np.zeros(ncs, np.int64)
         e_cut = [np.zeros(0)] * ncs
         for i in range(ncs):
@@ -486,4 +488,4 @@ class PfEngine(Engine):
         self._tick("download", t0)
         self.timings["total"] = time.perf_counter() - t_all
         self._keep.clear()
-        return PfMPSData(bonds, sites, oc, unit_cell_width, dict(self.timings))
+        return self._finish(PfMPSData(bonds, sites, oc, unit_cell_width, dict(self.timings)))
