@@ -177,3 +177,11 @@ def site_prepare(mode, k_b, nf_b, sets_b, q_b, k_k, nf_k, sets_k, q_k):
                 row_sel=row_sel[: o["mb"]], row_sign=row_sign[: o["mb"]], col_sel=col_sel[: o["mk"]],
                 col_sign=col_sign[: o["mk"]], bra_p=bra_p, bra_alpha=bra_alpha, sectors=secs[: o["n_sectors"]].copy(),
                 idx_pool=pool[: o["idx_bytes"]].copy(), out_elems=int(o["out_elems"]))
+
+
+def reduced_det_lds(el, n, sb, sk, nsk, na):
+    """Dynamic LDS bytes of one tmf_det_reduced_batched tile (layout: csrc/det_reduced.hip);
+    works on scalars and NumPy arrays alike."""
+    a16 = lambda x: (x + 15) & ~15  # noqa: E731
+    return (a16(sb * sk * el) + a16(nsk * n) + a16(nsk * 8) + a16(na * n)
+            + 4 * (((n | 1) * sk + 264) * el + 576) + 16)

@@ -15,9 +15,11 @@
 // pivoting makes it as stable as the pivoted LU it replaces (no fallback path needed).
 //
 // One wavefront owns one bra row-set at a time: lane = column of M_a (sk <= 64) during the
-// elimination, result kept in the wavefront's LDS; then 8-lane groups sweep the ket sets,
-// derive d, the row/column lists and the permutation sign from 64-bit column masks, and
-// evaluate the order-d determinant with det_group (det_gather.hip).
+// elimination, result kept in the wavefront's LDS.  The ket sets are then swept with ONE LANE
+// PER PAIR: d, the row/column lists and the permutation sign come from 64-bit column masks and
+// two small per-row-set tables in O(d), and the order-d determinant (d <= 3) is a closed form.
+// Pairs with d > 3 (a few per cent) are queued in LDS and evaluated eight at a time by 8-lane
+// groups with det_group (det_gather.hip).
 #include "det_common.hpp"
 
 namespace tmf {
@@ -68,7 +70,7 @@ __device__ inline T minor_det(const T* __restrict__ Na, const int NS, const uint
 }
 
 // LDS (dynamic): [ M : sb*sk T ][ ket idx : nsk*N u8 ][ ket masks : nsk u64 ][ bra idx : na*N u8 ]
-//                [ per wave: R (N|1)*sk T | scratch 8*(33) T | rowof 64 u8 ]
+//                [ per wave: R (N|1)*sk T | scratch 8*(33) T | rowsbelow 64 u32 | queue 72 u16 | rowof, invc 64 u8 ]
 template <typename T, int N>
 __global__ __launch_bounds__(256) void reduced_det_kernel(const tmf_det_desc* __restrict__ desc) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -85,11 +87,14 @@ __global__ __launch_bounds__(256) void reduced_det_kernel(const tmf_det_desc* __
   uint8_t* bidx = smem + off;
   off += ((size_t)na * N + 15) & ~(size_t)15;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t per_wave = ((size_t)NS * sk + SCR) * sizeof(T) + 64;
+  const size_t per_wave = ((size_t)NS * sk + SCR) * sizeof(T) + 576;
   unsigned char* wb = smem + off + (size_t)wave * per_wave;
   T* Na = reinterpret_cast<T*>(wb);
   T* scr_w = Na + (size_t)NS * sk;
-  uint8_t* rowof = reinterpret_cast<uint8_t*>(scr_w + SCR);
+  unsigned* rowsbelow = reinterpret_cast<unsigned*>(scr_w + SCR);        // 64 x u32
+  uint16_t* queue = reinterpret_cast<uint16_t*>(rowsbelow + 64);         // 72 x u16 (<= 7 + 64 waiting pairs)
+  uint8_t* rowof = reinterpret_cast<uint8_t*>(queue + 72);               // 64 x u8
+  uint8_t* invc = rowof + 64;                                            // 64 x u8
 
   const T* __restrict__ S = reinterpret_cast<const T*>(d.S);
   for (int e = threadIdx.x; e < d.sb * sk; e += 256) Ms[e] = S[(size_t)(e % d.sb) + (size_t)(e / d.sb) * d.lds];
@@ -185,10 +190,35 @@ __global__ __launch_bounds__(256) void reduced_det_kernel(const tmf_det_desc* __
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const T pref_fac = sc<T>::mul(scale, detg);
 
-    // ---------------- sweep the ket sets: 8 lanes per pair ---------------------------------------
-    for (int b0 = 0; b0 < nsk; b0 += 8) {
-      const int b = b0 + grp;
-      const bool live = b < nsk;
+    // ---------------- per row-set tables for the permutation sign -------------------------------
+    // sigma maps position u of the (ascending) ket set b to a row: a kept pivot column goes to its
+    // pivot row, the new columns (ascending) to the rows of the removed pivot columns (ascending).
+    // Its inversion parity splits into  inv(P_a) + sum_{c removed} invc[c] + inv(removed pairs)
+    // + sum_{new column j -> row i} cross(j, i)   (mod 2), every term O(1) from these tables:
+    //   rowsbelow[j] = rows of the pivot columns c < j,   invc[c] = inversions of P_a that involve c
+    const unsigned mybit = colused ? (1u << myrow) : 0u;
+    unsigned incl = mybit;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned y = (unsigned)__shfl_up((int)incl, o);
+      if (lane >= o) incl |= y;
+    }
+    const unsigned below = incl & ~mybit;  // pivot rows are distinct: removing the own bit = exclusive scan
+    constexpr unsigned allrows = (N >= 32) ? 0xffffffffu : ((1u << N) - 1u);
+    int myinv = 0;
+    if (colused) myinv = __popcll((uint64_t)below >> (myrow + 1)) + __popc(allrows & ~incl & ((1u << myrow) - 1u));
+    int invsum = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) invsum += __popcll(__ballot((myinv >> k) & 1)) << k;
+    const int par_pp = (invsum >> 1) & 1;
+    rowsbelow[lane] = below;
+    invc[lane] = (uint8_t)myinv;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---------------- slow path: 8 lanes per pair, any number of exchanged columns ---------------
+    auto slow_batch = [&](const int b, const bool live) {
       const uint64_t bm = live ? kmask[b] : pa;
       const uint64_t jmask = bm & ~pa;          // columns of b outside the pivot set
       uint64_t rem = pa & ~bm;                  // pivot columns missing in b
@@ -199,8 +229,6 @@ __global__ __launch_bounds__(256) void reduced_det_kernel(const tmf_det_desc* __
         rem &= rem - 1;
         imask |= 1u << rowof[cc];
       }
-      // sign of sigma: column position u of b -> row (unit columns: their pivot row; the others:
-      // the rows of `imask` in ascending order); parity by counting inversions
       uint64_t seen = 0ull;  // 64-bit: the shift below reaches 32 for r = 31
       unsigned irest = imask;
       int inv = 0;
@@ -218,18 +246,9 @@ __global__ __launch_bounds__(256) void reduced_det_kernel(const tmf_det_desc* __
         inv += __popcll(seen >> (r + 1));
         seen |= 1ull << r;
       }
-      if (!live) inv = 0;
-      // order of this wavefront-iteration: the largest d of its 8 pairs
       const unsigned dmax = wave_max_u32(live ? (unsigned)dd : 0u);
       T det = sc<T>::one();
-      if (dmax == 0u) {
-      } else if (dmax == 1u) {
-        // 1 x 1: one element (row of the single missing pivot column, the single new column)
-        const int row = __ffs(imask) - 1, col = __ffsll((unsigned long long)jmask) - 1;
-        if (dd == 1) det = Na[row + col * NS];
-      } else if (dmax <= 2u) {
-        det = minor_det<T, 2, 8>(Na, NS, jmask, imask, live ? dd : 0, c8, scr_g);
-      } else if (dmax <= 4u) {
+      if (dmax <= 4u) {
         det = minor_det<T, 4, 8>(Na, NS, jmask, imask, live ? dd : 0, c8, scr_g);
       } else if (dmax <= 8u) {
         det = minor_det<T, 8, 8>(Na, NS, jmask, imask, live ? dd : 0, c8, scr_g);
@@ -257,7 +276,82 @@ __global__ __launch_bounds__(256) void reduced_det_kernel(const tmf_det_desc* __
         if (inv & 1) v = sc<T>::neg(v);
         orow[b] = v;
       }
+    };
+
+    // ---------------- sweep the ket sets: one lane per pair while <= 3 columns are exchanged ------
+    int qn = 0;  // pairs waiting for the slow path (uniform)
+    for (int b0 = 0; b0 < nsk; b0 += 64) {
+      const int b = b0 + lane;
+      const bool live = b < nsk;
+      const uint64_t bm = live ? kmask[b] : pa;
+      const uint64_t jmask = bm & ~pa;
+      uint64_t rem = pa & ~bm;
+      const int dd = __popcll(jmask);
+      const bool slow = dd > 3;
+      if (live && !slow) {
+        unsigned imask = 0u;
+        int par = par_pp;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          if (rem) {
+            const int cc = __ffsll((unsigned long long)rem) - 1;
+            rem &= rem - 1;
+            const int r = rowof[cc];
+            par += invc[cc] + __popcll((uint64_t)imask >> (r + 1));
+            imask |= 1u << r;
+          }
+        }
+        const unsigned krows = allrows & ~imask;
+        int iv[3], jv[3];
+        unsigned im = imask;
+        uint64_t jm = jmask;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          iv[t] = 0;
+          jv[t] = 0;
+          if (t < dd) {
+            const int i = __ffs(im) - 1, j = __ffsll((unsigned long long)jm) - 1;
+            im &= im - 1;
+            jm &= jm - 1;
+            const unsigned rb = rowsbelow[j];
+            par += __popc(rb & krows & ~((2u << i) - 1u)) + __popc(~rb & krows & ((1u << i) - 1u));
+            iv[t] = i;
+            jv[t] = j * NS;
+          }
+        }
+        T det = sc<T>::one();
+        if (dd == 1) {
+          det = Na[iv[0] + jv[0]];
+        } else if (dd == 2) {
+          const T m00 = Na[iv[0] + jv[0]], m10 = Na[iv[1] + jv[0]], m01 = Na[iv[0] + jv[1]], m11 = Na[iv[1] + jv[1]];
+          det = sc<T>::fms(sc<T>::mul(m00, m11), m01, m10);
+        } else if (dd == 3) {
+          const T m00 = Na[iv[0] + jv[0]], m10 = Na[iv[1] + jv[0]], m20 = Na[iv[2] + jv[0]];
+          const T m01 = Na[iv[0] + jv[1]], m11 = Na[iv[1] + jv[1]], m21 = Na[iv[2] + jv[1]];
+          const T m02 = Na[iv[0] + jv[2]], m12 = Na[iv[1] + jv[2]], m22 = Na[iv[2] + jv[2]];
+          const T c0 = sc<T>::fms(sc<T>::mul(m11, m22), m12, m21);
+          const T c1 = sc<T>::fms(sc<T>::mul(m10, m22), m12, m20);
+          const T c2 = sc<T>::fms(sc<T>::mul(m10, m21), m11, m20);
+          det = sc<T>::fmac(sc<T>::fms(sc<T>::mul(m00, c0), m01, c1), m02, c2);
+        }
+        T v = sc<T>::mul(pref_fac, det);
+        if (par & 1) v = sc<T>::neg(v);
+        orow[b] = v;
+      }
+      const uint64_t sm = __ballot(live && slow);
+      if (sm) {
+        if (live && slow) queue[qn + __popcll(sm & ((1ull << lane) - 1ull))] = (uint16_t)b;
+        qn += __popcll(sm);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        while (qn >= 8) {
+          qn -= 8;
+          slow_batch((int)queue[qn + grp], true);
+        }
+      }
     }
+    if (qn > 0) slow_batch((int)queue[grp < qn ? grp : 0], grp < qn);
     __builtin_amdgcn_wave_barrier();
   }
 }

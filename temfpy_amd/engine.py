@@ -667,8 +667,7 @@ class Engine:
             # reduced-minor kernel (one Gauss-Jordan per bra row-set) whenever the sometimes-matrix has
             # <= 64 columns and 1 <= n <= 32; the direct kernel covers the rest
             use_red = (tcls >= 1) & (tcls <= 32) & (skv[tsite] <= 64) & (not self.force_direct_det)
-            lneed_red = (a16(sbv[tsite] * skv[tsite] * el) + a16(nsk_[tsec] * nq[tsec]) + a16(nsk_[tsec] * 8)
-                         + a16(ta[tsec] * nq[tsec]) + 4 * (((nq[tsec] | 1) * skv[tsite] + 264) * el + 64))
+            lneed_red = nat.reduced_det_lds(el, nq[tsec], sbv[tsite], skv[tsite], nsk_[tsec], ta[tsec]) - 16
             use_red &= lneed_red + 16 <= 160 * 1024
             lneed = np.where(use_red, lneed_red, lneed)
             if int(lneed.max()) > 160 * 1024:

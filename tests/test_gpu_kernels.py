@@ -323,13 +323,15 @@ def test_bcgs2_numerically_rank_deficient_square_slab(eng, cplx):
 @pytest.mark.parametrize("cplx", [True, False])
 @pytest.mark.parametrize("n,sk,mode", [(1, 5, "near"), (2, 9, "near"), (5, 12, "near"), (8, 20, "near"), (12, 30, "near"),
                                        (13, 31, "far"), (16, 40, "near"), (19, 45, "near"), (20, 64, "far"),
-                                       (32, 64, "near"), (12, 30, "rankdef"), (6, 14, "graded")])
+                                       (32, 64, "near"), (12, 30, "rankdef"), (6, 14, "graded"),
+                                       (12, 40, "mixed"), (7, 30, "mixed"), (24, 60, "mixed")])
 def test_det_reduced_matches_numpy(eng, cplx, n, sk, mode):
     """tmf_det_reduced_batched (one pivoted Gauss-Jordan per bra row-set, order-d minors) against
     numpy.linalg.det of every minor.  'near': ket sets differ from the first one in <= 3 columns
     (the situation of a sweep); 'far': random ket sets (up to n exchanged columns, the > 8 path);
     'rankdef': some bra row-sets select a rank-deficient slab (all their minors are 0);
-    'graded': rows scaled over 12 decades (weak orbitals)."""
+    'graded': rows scaled over 12 decades (weak orbitals); 'mixed': 150 ket sets, up to 6 exchanges
+    in sequence (fast lane-per-pair path and the queued > 3 path interleaved over several sweeps)."""
     setup(eng, cplx)
     nat = eng.nat
     rng = np.random.default_rng(100 + n)
@@ -339,7 +341,7 @@ def test_det_reduced_matches_numpy(eng, cplx, n, sk, mode):
         S *= np.logspace(0, -12, sb)[:, None]
     if mode == "rankdef":
         S[3] = 2.0 * S[1] - S[2]          # rows 1, 2, 3 linearly dependent
-    nsb, nsk = 23, 41
+    nsb, nsk = (23, 41) if mode != "mixed" else (9, 150)
     bra = np.stack([np.sort(rng.choice(sb, n, replace=False)) for _ in range(nsb)]).astype(np.uint8)
     if mode == "rankdef":
         for a_ in (0, 5):  # these row-sets contain the dependent rows 1, 2, 3
@@ -352,7 +354,7 @@ def test_det_reduced_matches_numpy(eng, cplx, n, sk, mode):
             ket.append(np.sort(rng.choice(sk, n, replace=False)))
         else:
             k = base.copy()
-            for _ in range(rng.integers(0, min(3, n, sk - n) + 1)):
+            for _ in range(rng.integers(0, min(6 if mode == "mixed" else 3, n, sk - n) + 1)):
                 free = np.setdiff1d(np.arange(sk), k)
                 k[rng.integers(n)] = rng.choice(free)
             ket.append(np.sort(k))
@@ -368,8 +370,7 @@ def test_det_reduced_matches_numpy(eng, cplx, n, sk, mode):
         dd[j] = (dS_[1], dsc[1], tb.data_ptr(), tk.data_ptr(), out.data_ptr(), sb, sk, sb, n, nsb, nsk, j * ta,
                  min(nsb, (j + 1) * ta))
     a16 = lambda x: (x + 15) & ~15  # noqa: E731
-    lds = (a16(sb * sk * eng.elem) + a16(nsk * n) + a16(nsk * 8) + a16(ta * n)
-           + 4 * (((n | 1) * sk + 264) * eng.elem + 64) + 16)
+    lds = nat.reduced_det_lds(eng.elem, n, sb, sk, nsk, ta)
     if lds > 160 * 1024:
         pytest.skip("tile exceeds the 160 KiB LDS; the engine uses tmf_det_gather_batched for it")
     t = eng._up(dd)
