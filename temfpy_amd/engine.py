@@ -272,6 +272,27 @@ class Engine:
 
     range_floor_tol = 1e-11
 
+    def _hbuf(self, name, shape, dtype, zero=False):
+        """Persistent host scratch (grow-only, pre-faulted).  Fresh ``np.zeros`` arrays of this size
+        are lazily mapped, and their first-touch page faults inside the 16 enumeration threads
+        serialise on the process's mmap lock (measured: 110 ms instead of 26 ms for the L = 1024
+        enumeration).  Contents are undefined unless ``zero`` is set; nothing handed to the caller
+        may alias these buffers."""
+        dt = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dt.itemsize
+        pool = getattr(self, "_hpool", None)
+        if pool is None:
+            pool = self._hpool = {}
+        raw = pool.get(name)
+        if raw is None or raw.nbytes < nbytes:
+            raw = np.empty(max(int(nbytes * 1.25), 4096), np.uint8)
+            raw.fill(0)
+            pool[name] = raw
+        out = raw[:nbytes].view(dt).reshape(shape)
+        if zero:
+            out.fill(0)
+        return out
+
     def _finish(self, mps):
         mps.info = {"range_finder_iterations": self.range_iterations_used,
                     "range_finder_smallest_sigma": self.range_floor}
@@ -460,9 +481,9 @@ class Engine:
             sec_arr = None if sectors is None else np.ascontiguousarray(sectors, np.int64)
             cap = int(trunc.chi_max) + 1 if trunc.chi_max else 4096
             while True:
-                c_sets = np.zeros((ncut, cap, 2), np.uint64)
-                c_lam = np.zeros((ncut, cap))
-                c_q = np.zeros((ncut, cap), np.int32)
+                c_sets = self._hbuf("c_sets", (ncut, cap, 2), np.uint64)
+                c_lam = self._hbuf("c_lam", (ncut, cap), np.float64)
+                c_q = self._hbuf("c_q", (ncut, cap), np.int32)
                 c_chi, c_chk = np.zeros(ncut, np.int64), np.zeros(ncut, np.int64)
                 st = self.lib.tmf_cut_vectors_batch(
                     ncut, nat._p(e_pool), nat._p(e_off), nat._p(kk_cut), nat._p(nfl), int(trunc.chi_max or 0),
@@ -476,16 +497,21 @@ class Engine:
                 break
             if np.any(c_chi == 0):
                 raise ValueError("No Schmidt vectors left after filtering by `trunc_par.sectors`!")  # slater.py:668
+            # compact copies of the kept vectors (the scratch above is reused by the next sweep)
+            kept = np.arange(cap)[None, :] < c_chi[:, None]
+            f_sets, f_lam, f_q = c_sets[kept], c_lam[kept], c_q[kept]
+            f_off = np.concatenate(([0], np.cumsum(c_chi)))
+            nrm_all = np.sqrt(np.add.reduceat(f_lam * f_lam, f_off[:-1]))
+            f_lamn = f_lam / np.repeat(nrm_all, c_chi)
+            info = logger.isEnabledFor(logging.INFO)
             bonds = [None] * (L + 1)
             for j, b in enumerate(my_cuts):
-                ch = int(c_chi[j])
-                lam_raw = c_lam[j, :ch]
-                nrm = float(np.sqrt(np.dot(lam_raw, lam_raw)))
-                if logger.isEnabledFor(logging.INFO):
+                lo, hi = int(f_off[j]), int(f_off[j + 1])
+                if info:
                     logger.info("bond %d: %d Schmidt modes, checked %d subsets, kept %d, norm %.12g", b, kk_cut[j],
-                                c_chk[j], ch, nrm)
+                                c_chk[j], hi - lo, nrm_all[j])
                 bonds[b] = BondData(x=b, e=e_left[j], n_filled_left=int(nfl[j]), n_filled_right=int(nfr[j]),
-                                    masks=c_sets[j, :ch], lam_raw=lam_raw, lam=lam_raw / nrm, q_left=c_q[j, :ch],
+                                    masks=f_sets[lo:hi], lam_raw=f_lam[lo:hi], lam=f_lamn[lo:hi], q_left=f_q[lo:hi],
                                     n_checked=int(c_chk[j]))
             self.timings["host_enumerate"] = time.perf_counter() - t0
 
@@ -518,9 +544,11 @@ class Engine:
             jobs["idx_cap"] = idx_cap
             row_sel, row_sign = np.zeros(rs_tot + 1, np.int32), np.zeros(rs_tot + 1, np.int8)
             col_sel, col_sign = np.zeros(cs_tot + 1, np.int32), np.zeros(cs_tot + 1, np.int8)
-            bra_p, bra_alpha = np.zeros(br_tot + 1, np.int32), np.zeros(br_tot + 1, np.int32)
+            # bra_p / bra_alpha end up in the returned SiteData -> fresh arrays, faulted in here
+            bra_p, bra_alpha = np.empty(br_tot + 1, np.int32), np.empty(br_tot + 1, np.int32)
+            bra_p.fill(0), bra_alpha.fill(0)
             sec_buf = np.zeros(sc_tot + 1, nat.sector)
-            pool = np.zeros(ix_tot + 1, np.uint8)
+            pool = self._hbuf("idx_pool", (ix_tot + 1,), np.uint8)
             souts = np.zeros(ns, nat.site_out)
             nat.check(self.lib.tmf_site_prepare_batch(
                 ns, nat._p(jobs), nat._p(c_sets), nat._p(c_q), nat._p(c_chi), cap, nat._p(row_sel), nat._p(row_sign),
