@@ -91,6 +91,13 @@ typedef struct {
 int tmf_jacobi_batched(int dtype, const tmf_jacobi_desc* d_desc, int nprob, int max_p, int32_t* d_sweeps,
                        void* stream);
 
+/* Same decomposition, left singular vectors only: desc.V is ignored, desc.U is required.  No
+ * rotation accumulator -> half the LDS (two workgroups per CU) and 40 % fewer flops.  Fed with
+ * the conjugate transpose of the triangular factor (columns graded by the singular values),
+ * which one-sided Jacobi diagonalises in far fewer sweeps than the factor itself. */
+int tmf_svd_left_batched(int dtype, const tmf_jacobi_desc* d_desc, int nprob, int max_p, int32_t* d_sweeps,
+                         void* stream);
+
 /* Blocked LU with partial pivoting restricted to the leading k x k "always" block of
  * W (mb x mk).  Returns det(W[:k,:k]) and leaves the Schur
  * complement W[k:,k:] - W[k:,:k] W[:k,:k]^-1 W[:k,k:] in S.  Replaces det/inv and the two

@@ -13,7 +13,7 @@
 
 namespace tmf {
 
-template <typename T>
+template <typename T, bool WITH_V>
 __global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __restrict__ desc,
                                                      int32_t* __restrict__ sweeps_out) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -21,8 +21,8 @@ __global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __re
   const int p = d.p;
   if (p <= 0) return;
   T* X = reinterpret_cast<T*>(smem);        // X[c * p + r]
-  T* V = X + (size_t)p * p;
-  double* nrm = reinterpret_cast<double*>(V + (size_t)p * p);  // p norms
+  T* V = X + (size_t)p * p;                 // only with WITH_V
+  double* nrm = reinterpret_cast<double*>(X + (WITH_V ? 2 : 1) * (size_t)p * p);  // p norms
   int* flag = reinterpret_cast<int*>(nrm + p);                 // rotation counter
 
   const int tid = threadIdx.x;
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __re
   for (int e = tid; e < p * p; e += 512) {
     const int r = e % p, c = e / p;
     X[e] = Xg[(size_t)r + (size_t)c * d.ldx];
-    V[e] = (r == c) ? sc<T>::one() : sc<T>::zero();
+    if (WITH_V) V[e] = (r == c) ? sc<T>::one() : sc<T>::zero();
   }
   if (tid == 0) *flag = 0;
   __syncthreads();
@@ -90,12 +90,14 @@ __global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __re
               xi[r] = sc<T>::sub(sc<T>::scale(a, c), sc<T>::mul(sph, b));
               xj[r] = sc<T>::add(sc<T>::scale(a, s), sc<T>::mul(cph, b));
             }
-            T* vi = V + (size_t)i * p;
-            T* vj = V + (size_t)j * p;
-            for (int r = pl; r < p; r += tpp) {
-              const T a = vi[r], b = vj[r];
-              vi[r] = sc<T>::sub(sc<T>::scale(a, c), sc<T>::mul(sph, b));
-              vj[r] = sc<T>::add(sc<T>::scale(a, s), sc<T>::mul(cph, b));
+            if (WITH_V) {
+              T* vi = V + (size_t)i * p;
+              T* vj = V + (size_t)j * p;
+              for (int r = pl; r < p; r += tpp) {
+                const T a = vi[r], b = vj[r];
+                vi[r] = sc<T>::sub(sc<T>::scale(a, c), sc<T>::mul(sph, b));
+                vj[r] = sc<T>::add(sc<T>::scale(a, s), sc<T>::mul(cph, b));
+              }
             }
             if (pl == 0) atomicAdd(flag, 1);
           }
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __re
     int rank = 0;
     for (int c2 = 0; c2 < p; ++c2) rank += (nrm[c2] > sc_) || (nrm[c2] == sc_ && c2 < c);
     const bool keep = !(d.thresh2 > 0.0) || sc_ * sc_ >= d.thresh2;
-    Vg[(size_t)r + (size_t)rank * d.ldv] = keep ? V[e] : sc<T>::zero();
+    if (WITH_V) Vg[(size_t)r + (size_t)rank * d.ldv] = keep ? V[e] : sc<T>::zero();
     if (Ug) Ug[(size_t)r + (size_t)rank * d.ldu] = sc<T>::scale(X[e], (keep && sc_ > 0.0) ? 1.0 / sc_ : 0.0);
     if (r == 0) sg[rank] = sc_;
   }
@@ -140,32 +142,45 @@ __global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __re
 
 }  // namespace tmf
 
-extern "C" int tmf_jacobi_batched(int dtype, const tmf_jacobi_desc* d_desc, int nprob, int max_p, int32_t* d_sweeps,
-                                  void* stream) {
+template <bool WITH_V>
+static int launch_jacobi(int dtype, const tmf_jacobi_desc* d_desc, int nprob, int max_p, int32_t* d_sweeps, void* stream,
+                         const char* who) {
   using namespace tmf;
   if (nprob <= 0) return TMF_OK;
   const size_t elem = (dtype == TMF_C128) ? 16 : 8;
-  const size_t lds = 2 * (size_t)max_p * max_p * elem + (size_t)max_p * 8 + 64;
+  const size_t lds = (WITH_V ? 2 : 1) * (size_t)max_p * max_p * elem + (size_t)max_p * 8 + 64;
   if (max_p <= 0 || max_p > 128 || lds > 160 * 1024) {
-    set_error("tmf_jacobi_batched: p = %d needs %zu B of LDS (limit 160 KiB: p <= 64 complex, p <= 96 real)", max_p,
-              lds);
+    set_error("%s: p = %d needs %zu B of LDS (limit 160 KiB)", who, max_p, lds);
     return TMF_E_LIMIT;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)jacobi_kernel<cd>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)jacobi_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)jacobi_kernel<cd, WITH_V>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    (void)hipFuncSetAttribute((const void*)jacobi_kernel<double, WITH_V>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     attr_done = true;
   }
   if (dtype == TMF_C128)
-    hipLaunchKernelGGL(jacobi_kernel<cd>, dim3(nprob), dim3(512), lds, s, d_desc, d_sweeps);
+    hipLaunchKernelGGL((jacobi_kernel<cd, WITH_V>), dim3(nprob), dim3(512), lds, s, d_desc, d_sweeps);
   else if (dtype == TMF_F64)
-    hipLaunchKernelGGL(jacobi_kernel<double>, dim3(nprob), dim3(512), lds, s, d_desc, d_sweeps);
+    hipLaunchKernelGGL((jacobi_kernel<double, WITH_V>), dim3(nprob), dim3(512), lds, s, d_desc, d_sweeps);
   else {
-    set_error("tmf_jacobi_batched: bad dtype %d", dtype);
+    set_error("%s: bad dtype %d", who, dtype);
     return TMF_E_ARG;
   }
-  return check_hip(hipGetLastError(), "tmf_jacobi_batched launch");
+  return check_hip(hipGetLastError(), who);
+}
+
+extern "C" int tmf_jacobi_batched(int dtype, const tmf_jacobi_desc* d_desc, int nprob, int max_p, int32_t* d_sweeps,
+                                  void* stream) {
+  return launch_jacobi<true>(dtype, d_desc, nprob, max_p, d_sweeps, stream, "tmf_jacobi_batched");
+}
+
+// Left singular vectors and singular values only (desc.V is ignored, desc.U must be set): no
+// rotation accumulator, half the LDS, two workgroups per CU.
+extern "C" int tmf_svd_left_batched(int dtype, const tmf_jacobi_desc* d_desc, int nprob, int max_p, int32_t* d_sweeps,
+                                    void* stream) {
+  return launch_jacobi<false>(dtype, d_desc, nprob, max_p, d_sweeps, stream, "tmf_svd_left_batched");
 }

@@ -178,19 +178,24 @@ class Engine:
             nat.check(self.lib.tmf_orth_panel_batched(self.dtype, dd.data_ptr(), act.size, max_rows, w, self.stream),
                       "tmf_orth_panel_batched")
 
-    def jacobi(self, X, V, s, count, thresh2, p, ldx, ldv):
+    def jacobi(self, X, V, s, count, thresh2, p, ldx, ldv, left_only=False):
+        """One-sided Jacobi per problem.  ``left_only``: ``V`` receives the normalised LEFT singular
+        vectors (tmf_svd_left_batched, no rotation accumulator) instead of the right ones."""
         p = np.asarray(p, np.int64)
         sel = np.nonzero(p > 0)[0]
         if sel.size == 0:
             return
         d = np.zeros(sel.size, nat.jacobi_desc)
-        for f, v in (("X", X), ("V", V), ("s", s), ("count", count), ("p", p), ("ldx", ldx), ("ldv", ldv)):
+        for f, v in (("X", X), ("U" if left_only else "V", V), ("s", s), ("count", count), ("p", p), ("ldx", ldx),
+                     ("ldu" if left_only else "ldv", ldv)):
             d[f] = np.broadcast_to(np.asarray(v), p.shape)[sel]
         d["thresh2"] = thresh2
-        d["ldu"] = 1
+        if not left_only:
+            d["ldu"] = 1
         dd = self._up(d)
-        nat.check(self.lib.tmf_jacobi_batched(self.dtype, dd.data_ptr(), sel.size, int(p.max()), None, self.stream),
-                  "tmf_jacobi_batched")
+        fn = self.lib.tmf_svd_left_batched if left_only else self.lib.tmf_jacobi_batched
+        nat.check(fn(self.dtype, dd.data_ptr(), sel.size, int(p.max()), None, self.stream),
+                  "tmf_svd_left_batched" if left_only else "tmf_jacobi_batched")
 
     def colcopy(self, src, dst, n, c, lds_, ldd, reverse=0, flip_odd=0):
         n, c = np.asarray(n, np.int64), np.asarray(c, np.int64)
@@ -254,9 +259,12 @@ class Engine:
             if it < iterations:
                 self.gemm(0, 1.0, 0.0, off, Q2p, Yp, n, p, m, L, np.maximum(m, 1), ld1)
                 self.bcgs2(Yp[doE], n[doE], n[doE], zero[doE], p[doE], scrp[doE], passes=3)
-        self.gemm(1, 1.0, 0.0, Q2p, Btp, Rp, p, p, m, np.maximum(m, 1), np.maximum(m, 1), np.maximum(p, 1))
-        # E4: Jacobi SVD of R: right singular vectors Z, sigma; columns below the threshold zeroed
-        self.jacobi(Rp, Zp, sigp, cntp, thr2, p, np.maximum(p, 1), np.maximum(p, 1))
+        # R^H = (F^H Q)^H Q2 (lower triangular; its columns are graded by the singular values, which is
+        # the form one-sided Jacobi diagonalises in few sweeps: 11.2 ms -> measured below for R itself)
+        self.gemm(1, 1.0, 0.0, Btp, Q2p, Rp, p, p, m, np.maximum(m, 1), np.maximum(m, 1), np.maximum(p, 1))
+        # E4: Jacobi SVD of R^H: left singular vectors Z (= right ones of R), sigma; columns below the
+        # threshold zeroed
+        self.jacobi(Rp, Zp, sigp, cntp, thr2, p, np.maximum(p, 1), np.maximum(p, 1), left_only=True)
         # E5: U0 = Q Z
         self.gemm(0, 1.0, 0.0, Yp, Zp, U0p, n, p, p, ld1, np.maximum(p, 1), ld1)
         # E6: T = U0^H (A U0), Jacobi eigen-decomposition
@@ -480,6 +488,7 @@ class Engine:
             e_pool = np.concatenate(e_left + [np.zeros(1)])
             sec_arr = None if sectors is None else np.ascontiguousarray(sectors, np.int64)
             cap = int(trunc.chi_max) + 1 if trunc.chi_max else 4096
+            self.timings["host_enum_setup"] = time.perf_counter() - t0
             while True:
                 c_sets = self._hbuf("c_sets", (ncut, cap, 2), np.uint64)
                 c_lam = self._hbuf("c_lam", (ncut, cap), np.float64)
@@ -495,24 +504,29 @@ class Engine:
                     continue
                 nat.check(st, "tmf_cut_vectors_batch")
                 break
+            self.timings["host_enum_native"] = time.perf_counter() - t0 - self.timings["host_enum_setup"]
             if np.any(c_chi == 0):
                 raise ValueError("No Schmidt vectors left after filtering by `trunc_par.sectors`!")  # slater.py:668
-            # compact copies of the kept vectors (the scratch above is reused by the next sweep)
-            kept = np.arange(cap)[None, :] < c_chi[:, None]
-            f_sets, f_lam, f_q = c_sets[kept], c_lam[kept], c_q[kept]
-            f_off = np.concatenate(([0], np.cumsum(c_chi)))
-            nrm_all = np.sqrt(np.add.reduceat(f_lam * f_lam, f_off[:-1]))
-            f_lamn = f_lam / np.repeat(nrm_all, c_chi)
-            info = logger.isEnabledFor(logging.INFO)
-            bonds = [None] * (L + 1)
-            for j, b in enumerate(my_cuts):
-                lo, hi = int(f_off[j]), int(f_off[j + 1])
-                if info:
-                    logger.info("bond %d: %d Schmidt modes, checked %d subsets, kept %d, norm %.12g", b, kk_cut[j],
-                                c_chk[j], hi - lo, nrm_all[j])
-                bonds[b] = BondData(x=b, e=e_left[j], n_filled_left=int(nfl[j]), n_filled_right=int(nfr[j]),
-                                    masks=f_sets[lo:hi], lam_raw=f_lam[lo:hi], lam=f_lamn[lo:hi], q_left=f_q[lo:hi],
-                                    n_checked=int(c_chk[j]))
+            def make_bonds(L=L):  # bind the chain length now: run() re-uses the name for the shard
+                # compact copies of the kept vectors (the scratch above is reused by the next sweep);
+                # runs on the main thread while the determinant kernels execute
+                kept = np.arange(cap)[None, :] < c_chi[:, None]
+                f_sets, f_lam, f_q = c_sets[kept], c_lam[kept], c_q[kept]
+                f_off = np.concatenate(([0], np.cumsum(c_chi)))
+                nrm_all = np.sqrt(np.add.reduceat(f_lam * f_lam, f_off[:-1]))
+                f_lamn = f_lam / np.repeat(nrm_all, c_chi)
+                info = logger.isEnabledFor(logging.INFO)
+                bonds = [None] * (L + 1)
+                for j, b in enumerate(my_cuts):
+                    lo, hi = int(f_off[j]), int(f_off[j + 1])
+                    if info:
+                        logger.info("bond %d: %d Schmidt modes, checked %d subsets, kept %d, norm %.12g", b,
+                                    kk_cut[j], c_chk[j], hi - lo, nrm_all[j])
+                    bonds[b] = BondData(x=b, e=e_left[j], n_filled_left=int(nfl[j]), n_filled_right=int(nfr[j]),
+                                        masks=f_sets[lo:hi], lam_raw=f_lam[lo:hi], lam=f_lamn[lo:hi],
+                                        q_left=f_q[lo:hi], n_checked=int(c_chk[j]))
+                return bonds
+
             self.timings["host_enumerate"] = time.perf_counter() - t0
 
             # ---- host: per-site integer preparation (one threaded C++ call) --------------------------
@@ -550,13 +564,15 @@ class Engine:
             sec_buf = np.zeros(sc_tot + 1, nat.sector)
             pool = self._hbuf("idx_pool", (ix_tot + 1,), np.uint8)
             souts = np.zeros(ns, nat.site_out)
+            t1 = time.perf_counter()
             nat.check(self.lib.tmf_site_prepare_batch(
                 ns, nat._p(jobs), nat._p(c_sets), nat._p(c_q), nat._p(c_chi), cap, nat._p(row_sel), nat._p(row_sign),
                 nat._p(col_sel), nat._p(col_sign), nat._p(bra_p), nat._p(bra_alpha), nat._p(sec_buf), nat._p(pool),
                 nat._p(souts), threads), "tmf_site_prepare_batch")
+            self.timings["host_site_native"] = time.perf_counter() - t1
             self.timings["host_site_prepare"] = time.perf_counter() - t0
 
-            return dict(bonds=bonds, jobs=jobs, souts=souts, row_sel=row_sel, row_sign=row_sign, col_sel=col_sel,
+            return dict(make_bonds=make_bonds, jobs=jobs, souts=souts, row_sel=row_sel, row_sign=row_sign, col_sel=col_sel,
                         col_sign=col_sign, bra_p=bra_p, bra_alpha=bra_alpha, sec_buf=sec_buf, pool=pool, mode=mode,
                         ib=ib, ik=ik, chi_b=chi_b, chi_k=chi_k, my_sites=my_sites, ns=ns, cut_idx=cut_idx)
 
@@ -609,7 +625,7 @@ class Engine:
         if "exc" in hp:
             raise hp["exc"]
         ho = hp["out"]
-        bonds, jobs, souts, pool, mode = ho["bonds"], ho["jobs"], ho["souts"], ho["pool"], ho["mode"]
+        jobs, souts, pool, mode = ho["jobs"], ho["souts"], ho["pool"], ho["mode"]
         row_sel, row_sign, col_sel, col_sign = ho["row_sel"], ho["row_sign"], ho["col_sel"], ho["col_sign"]
         bra_p, bra_alpha, sec_buf = ho["bra_p"], ho["bra_alpha"], ho["sec_buf"]
         ib, ik, chi_b, chi_k, my_sites, ns = ho["ib"], ho["ik"], ho["chi_b"], ho["chi_k"], ho["my_sites"], ho["ns"]
@@ -723,6 +739,9 @@ class Engine:
         self.n_det = n_det
         self._tick("S_determinants", t0)
         self.d_out = d_out  # device-resident result
+        t0 = time.perf_counter()
+        bonds = ho["make_bonds"]()
+        self._tick("host_bonds", t0)
 
         # ---- host round trip 2: tensors back -----------------------------------------------------
         if not download:

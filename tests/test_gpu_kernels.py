@@ -146,6 +146,43 @@ def test_jacobi_svd_and_threshold(eng, cplx):
 
 
 @pytest.mark.parametrize("cplx", [True, False])
+def test_svd_left_on_graded_triangular_factor(eng, cplx):
+    """tmf_svd_left_batched on R^H (R = triangular factor of a matrix with singular values down to
+    1e-15, as the range finder produces): singular values to relative accuracy, orthonormal left
+    vectors spanning the same directions as numpy's SVD, columns below the threshold zeroed."""
+    setup(eng, cplx)
+    rng = np.random.default_rng(14)
+    ps = [1, 5, 33, 64]
+    Xs = []
+    for p in ps:
+        sv = np.logspace(-0.3, -15, p)
+        B = (np.linalg.qr(rnd(rng, (3 * p, p), cplx))[0] * sv) @ np.linalg.qr(rnd(rng, (p, p), cplx))[0]
+        Xs.append(np.ascontiguousarray(np.linalg.qr(B)[1].conj().T))
+    dX = [dev(eng, x) for x in Xs]
+    dU = [dev(eng, np.zeros_like(x)) for x in Xs]
+    ds = [torch.zeros(p, dtype=torch.float64, device="cuda:0") for p in ps]
+    dc = torch.zeros(len(ps), dtype=torch.int32, device="cuda:0")
+    thr2 = 2.5e-13
+    eng.jacobi([d[1] for d in dX], [d[1] for d in dU], [s.data_ptr() for s in ds],
+               dc.data_ptr() + 4 * np.arange(len(ps)), thr2, ps, ps, ps, left_only=True)
+    torch.cuda.synchronize()
+    cnt = dc.cpu().numpy()
+    for p, X, du, s_, c in zip(ps, Xs, dU, ds, cnt):
+        U = back(du[0], (p, p))
+        s = s_.cpu().numpy()
+        Ur, sref, _ = np.linalg.svd(X)
+        c_ref = int(np.sum(sref**2 >= thr2))
+        assert c == c_ref
+        np.testing.assert_allclose(s[:c], sref[:c], rtol=1e-9)
+        Uk = U[:, :c]
+        np.testing.assert_allclose(Uk.conj().T @ Uk, np.eye(c), atol=1e-12)
+        assert np.all(U[:, c:] == 0)
+        # same directions up to a phase (the kept singular values are well separated)
+        ov = np.abs(np.einsum("ij,ij->j", Ur[:, :c].conj(), Uk))
+        np.testing.assert_allclose(ov, 1.0, atol=1e-9)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
 def test_jacobi_hermitian_eigenproblem(eng, cplx):
     setup(eng, cplx)
     rng = np.random.default_rng(5)
