@@ -41,7 +41,9 @@ __global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __re
   int tpp = 64;                     // lanes per pair: largest power of two with npairs*tpp <= 512
   while (tpp * npairs > 512) tpp >>= 1;
   const int pair = tid / tpp, pl = tid % tpp;
-  const double eps = 1.1e-16;
+  // rotate while |<x_i, x_j>| > sqrt(p) eps |x_i| |x_j| (the rounding level of the p-term inner product
+  // itself; a tighter bound makes pairs at that level rotate for ever: 18 of 1023 cuts hit the cap)
+  const double tol2 = 1.1e-16 * 1.1e-16 * (double)p;
 
   int sweep = 0;
   for (; sweep < 60; ++sweep) {
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __re
             ga = sc<T>::add(ga, shfl_xor_t<T>(ga, o, tpp));
           }
           const double g2 = sc<T>::abs2(ga);
-          if (g2 > eps * eps * al * be && g2 > 0.0) {
+          if (g2 > tol2 * al * be && g2 > 0.0) {
             const double g = sqrt(g2);
             const double zeta = (be - al) / (2.0 * g);
             const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));

@@ -194,8 +194,15 @@ class Engine:
             d["ldu"] = 1
         dd = self._up(d)
         fn = self.lib.tmf_svd_left_batched if left_only else self.lib.tmf_jacobi_batched
-        nat.check(fn(self.dtype, dd.data_ptr(), sel.size, int(p.max()), None, self.stream),
-                  "tmf_svd_left_batched" if left_only else "tmf_jacobi_batched")
+        d_sw = None
+        if os.environ.get("TMF_JACOBI_SWEEPS"):  # debugging aid: sweep statistics of every launch
+            d_sw = self.torch.zeros(sel.size, dtype=self.torch.int32, device=self.device)
+        nat.check(fn(self.dtype, dd.data_ptr(), sel.size, int(p.max()), None if d_sw is None else d_sw.data_ptr(),
+                     self.stream), "tmf_svd_left_batched" if left_only else "tmf_jacobi_batched")
+        if d_sw is not None:
+            h = d_sw.cpu().numpy()
+            print(f"jacobi(left_only={left_only}) p<= {int(p.max())}: sweeps min {h.min()} mean {h.mean():.1f} "
+                  f"max {h.max()}; hist {np.bincount(h).tolist()}", flush=True)
 
     def colcopy(self, src, dst, n, c, lds_, ldd, reverse=0, flip_odd=0):
         n, c = np.asarray(n, np.int64), np.asarray(c, np.int64)
