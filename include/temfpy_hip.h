@@ -209,6 +209,27 @@ typedef struct {
 } tmf_gather_desc;           /* 80 bytes */
 int tmf_gather_signed_batched(int dtype, const tmf_gather_desc* d_desc, int nprob, void* stream);
 
+/* Products of nested blocks of one D x D matrix C (column-major) with a shared block Omega whose
+ * rows are indexed by the GLOBAL orbital index: for every cut position x with dest[x] != 0
+ *
+ *     out_x[lr, c] = sum_{j in J(x)} C[r, j] * Omega[j, c],      c < ncol[x],
+ *     J(x) = { j < x } (suffix = 0) or { j >= x } (suffix = 1),
+ *     rows r < x, lr = r (rows_ge = 0)   or   rows r >= x, lr = r - x (rows_ge = 1),
+ *
+ * written to the column-major slab dest[x] with leading dimension ld[x].  One running sum over j
+ * serves all cuts (O(D^2 c) flops); it replaces the per-cut products A_x Omega / F_x Omega in the
+ * randomised replacement of numpy.linalg.eigh (slater.py:347):
+ *     A_x = C[:x,:x]: suffix 0, rows_ge 0        A_x = C[x:,x:]: suffix 1, rows_ge 1
+ *     F_x = C[:x,x:]: suffix 1, rows_ge 0        F_x = C[x:,:x]: suffix 0, rows_ge 1          */
+typedef struct {
+  uint64_t C, Omega;         /* device addresses, leading dimensions ldc / ldo        */
+  uint64_t dest;             /* uint64[D + 1]: slab of cut x, 0 = no cut there        */
+  uint64_t ncol;             /* int32[D + 1]                                          */
+  uint64_t ld;               /* int32[D + 1]                                          */
+  int32_t D, ldc, ldo, suffix, rows_ge, x_lo, x_hi, maxc;   /* x_lo..x_hi: cuts present; maxc = max ncol */
+} tmf_nested_desc;           /* 72 bytes */
+int tmf_nested_products_batched(int dtype, const tmf_nested_desc* d_desc, int ndesc, int D, int maxc, void* stream);
+
 /* out[j] = 2-norm of column j of src (n x c) */
 typedef struct {
   uint64_t src, out;

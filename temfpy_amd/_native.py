@@ -19,6 +19,10 @@ TMF_F64, TMF_C128 = 0, 1
 gemm_desc = np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"),
                       ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4")])
 panel_desc = np.dtype([("A", "<u8"), ("norms", "<u8"), ("n", "<i4"), ("w", "<i4"), ("lda", "<i4"), ("pad", "<i4")])
+nested_desc = np.dtype([("C", "<u8"), ("Omega", "<u8"), ("dest", "<u8"), ("ncol", "<u8"), ("ld", "<u8"), ("D", "<i4"),
+                        ("ldc", "<i4"), ("ldo", "<i4"), ("suffix", "<i4"), ("rows_ge", "<i4"), ("x_lo", "<i4"),
+                        ("x_hi", "<i4"), ("maxc", "<i4")])
+assert nested_desc.itemsize == 72
 norms_desc = np.dtype([("src", "<u8"), ("out", "<u8"), ("n", "<i4"), ("c", "<i4"), ("lds_", "<i4"), ("pad", "<i4")])
 jacobi_desc = np.dtype([("X", "<u8"), ("V", "<u8"), ("U", "<u8"), ("s", "<u8"), ("count", "<u8"),
                         ("thresh2", "<f8"), ("p", "<i4"), ("ldx", "<i4"), ("ldv", "<i4"), ("ldu", "<i4")])
@@ -59,7 +63,7 @@ assert colnorm_desc.itemsize == 40 and sector.itemsize == 48 and site_out.itemsi
 
 SYMBOLS = [
     "tmf_last_error", "tmf_version", "tmf_device_count", "tmf_gemm_batched", "tmf_orth_panel_batched",
-    "tmf_jacobi_batched", "tmf_svd_left_batched", "tmf_lu_schur_batched", "tmf_det_gather_batched", "tmf_transpose", "tmf_fill_normal",
+    "tmf_jacobi_batched", "tmf_svd_left_batched", "tmf_nested_products_batched", "tmf_lu_schur_batched", "tmf_det_gather_batched", "tmf_transpose", "tmf_fill_normal",
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_cut_vectors", "tmf_site_prepare",
     "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_column_norms_batched", "tmf_det_reduced_batched", "tmf_pf_gather_batched", "tmf_nambu_assemble_batched",
     "tmf_nambu_w_batched", "tmf_pf_matrix_batched",
@@ -89,6 +93,7 @@ def load():
     lib.tmf_orth_panel_batched.argtypes = [i32, vp, i32, i32, i32, vp]
     lib.tmf_jacobi_batched.argtypes = [i32, vp, i32, i32, vp, vp]
     lib.tmf_svd_left_batched.argtypes = [i32, vp, i32, i32, vp, vp]
+    lib.tmf_nested_products_batched.argtypes = [i32, vp, i32, i32, i32, vp]
     lib.tmf_lu_schur_batched.argtypes = [i32, vp, i32, i32, vp]
     lib.tmf_det_gather_batched.argtypes = [i32, i32, vp, i32, i32, vp]
     lib.tmf_det_reduced_batched.argtypes = [i32, i32, vp, i32, i32, vp]

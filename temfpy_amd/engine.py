@@ -204,6 +204,31 @@ class Engine:
             print(f"jacobi(left_only={left_only}) p<= {int(p.max())}: sweeps min {h.min()} mean {h.mean():.1f} "
                   f"max {h.max()}; hist {np.bincount(h).tolist()}", flush=True)
 
+    def nested_products(self, kind, D, Cp, Omp, ldo, x, side, dest, ncol, ld):
+        """Y_i = A_i Omega (kind "A") or F_i Omega (kind "F") for all cut sides at once through
+        running sums over the shared index (tmf_nested_products_batched).  x: cut position in matrix
+        indices, side 0: the block left of x, side 1: right of x; Omega rows carry global indices."""
+        x, side, dest, ncol, ld = (np.asarray(a) for a in (x, side, dest, ncol, ld))
+        descs = np.zeros(2, nat.nested_desc)
+        nd = 0
+        for sd_ in (0, 1):
+            sel = np.nonzero((side == sd_) & (ncol > 0))[0]
+            if sel.size == 0:
+                continue
+            tab_d, tab_n, tab_l = np.zeros(D + 1, np.uint64), np.zeros(D + 1, np.int32), np.ones(D + 1, np.int32)
+            tab_d[x[sel]], tab_n[x[sel]], tab_l[x[sel]] = dest[sel], ncol[sel], ld[sel]
+            t_d, t_n, t_l = self._up(tab_d), self._up(tab_n), self._up(tab_l)
+            suffix = (sd_ == 1) if kind == "A" else (sd_ == 0)
+            descs[nd] = (Cp, Omp, t_d.data_ptr(), t_n.data_ptr(), t_l.data_ptr(), D, D, ldo, int(suffix), sd_,
+                         int(x[sel].min()), int(x[sel].max()), int(ncol[sel].max()))
+            nd += 1
+        if nd == 0:
+            return
+        t_desc = self._up(descs[:nd])
+        nat.check(self.lib.tmf_nested_products_batched(self.dtype, t_desc.data_ptr(), nd, D,
+                                                       int(descs["maxc"][:nd].max()), self.stream),
+                  "tmf_nested_products_batched")
+
     def colcopy(self, src, dst, n, c, lds_, ldd, reverse=0, flip_odd=0):
         n, c = np.asarray(n, np.int64), np.asarray(c, np.int64)
         sel = np.nonzero((n > 0) & (c > 0))[0]
@@ -217,7 +242,7 @@ class Engine:
         nat.check(self.lib.tmf_normalise_columns_batched(self.dtype, dd.data_ptr(), sel.size, self.stream),
                   "tmf_normalise_columns_batched")
 
-    def entangled_stage(self, L, n, m, blk, off, omp, doE, p, thr2, P, iterations=0):
+    def entangled_stage(self, L, n, m, blk, off, omp, doE, p, thr2, P, iterations=0, nest=None):
         """Stages E1-E7 of the module docstring for a batch of cut sides: returns the device
         addresses of the Ritz vectors U_E (n x p per problem, leading dimension n), their Ritz values
         (descending, d_e at offsets oS) and the number of directions above the threshold (d_cnt).
@@ -251,8 +276,11 @@ class Engine:
         zero = np.zeros(ncs, np.int64)
         ld1 = np.maximum(n, 1)
 
-        # E1: Y = F Omega
-        self.gemm(0, 1.0, 0.0, off, omp, Yp, n, p, m, L, L, ld1)
+        # E1: Y = F Omega (nest = (x, side, C, Omega): running sums over the nested blocks)
+        if nest is not None:
+            self.nested_products("F", L, nest[2], nest[3], L, nest[0], nest[1], Yp, p, ld1)
+        else:
+            self.gemm(0, 1.0, 0.0, off, omp, Yp, n, p, m, L, L, ld1)
         # E2: Q = qr(Y)
         self.bcgs2(Yp[doE], n[doE], n[doE], zero[doE], p[doE], scrp[doE], passes=3)
         # E3: B^H = F^H Q  (m x p), R = Q2^H B^H.  One round of orthogonal (subspace) iteration first:
@@ -313,7 +341,7 @@ class Engine:
                     "range_finder_smallest_sigma": self.range_floor}
         return mps
 
-    def entangled_stage_adaptive(self, L, n, m, blk, off, omp, doE, p, thr2, P, cs_b):
+    def entangled_stage_adaptive(self, L, n, m, blk, off, omp, doE, p, thr2, P, cs_b, nest=None):
         """Runs the entangled stage; if for some cut the smallest singular value s_P captured by the
         P-column range finder exceeds ``self.range_floor_tol``, repeats it with one round of subspace
         iteration and then applies the (cubed-ratio) adequacy check.
@@ -325,14 +353,14 @@ class Engine:
         engine overrides the tolerance with the rounding floor because its pairing construction
         (filled = conj(empty)) needs the orbitals themselves, not only the state, to be accurate.
         Returns the stage dict plus host copies."""
-        st = self.entangled_stage(L, n, m, blk, off, omp, doE, p, thr2, P, iterations=0)
+        st = self.entangled_stage(L, n, m, blk, off, omp, doE, p, thr2, P, iterations=0, nest=nest)
         h_sig, oS = st["d_sig"].cpu().numpy(), st["oS"]
         full = doE & (p == P) & (P < np.minimum(n, m))
         worst = max((h_sig[oS[i] + P - 1] for i in np.nonzero(full)[0]), default=0.0)
         self.range_floor = float(worst)
         st["range_iterations"] = 0
         if worst > self.range_floor_tol:
-            st = self.entangled_stage(L, n, m, blk, off, omp, doE, p, thr2, P, iterations=1)
+            st = self.entangled_stage(L, n, m, blk, off, omp, doE, p, thr2, P, iterations=1, nest=nest)
             h_sig = st["d_sig"].cpu().numpy()
             st["range_iterations"] = 1
             self.check_range_finder(h_sig, st["oS"], p, P, n, m, doE, thr2, cs_b)
@@ -437,7 +465,8 @@ class Engine:
             return o[:-1], int(o[-1])
 
         t0 = time.perf_counter()
-        st = self.entangled_stage_adaptive(L, n, m, blk, off, omp, doE, p, thr2, P, cs_b)
+        st = self.entangled_stage_adaptive(L, n, m, blk, off, omp, doE, p, thr2, P, cs_b,
+                                           nest=(cs_b, cs_side, Cp, d_Om.data_ptr()))
         UEp, oS, ld1 = st["UEp"], st["oS"], st["ld1"]
         self._tick("E_entangled", t0)
 
@@ -611,17 +640,15 @@ class Engine:
                       [m[centre_R]], [L], [ld1[centre_L]], [ld1[centre_R]])
             self.colcopy([d_pair.data_ptr()], [Vp[centre_R]], [n[centre_R]], [k[centre_R]], [ld1[centre_R]],
                          [ld1[centre_R]], reverse=1, flip_odd=1)
-        # filled: Y2 = A (A Omega_f)
+        # filled: Y = A Omega_f, projected off U_E and orthonormalised below
         maxnf = int(nf.max()) if ncs else 0
         if maxnf > 0:
             d_OmF = self._alloc(L * maxnf)
             nat.check(self.lib.tmf_fill_normal(self.dtype, d_OmF.data_ptr(), L * maxnf, 0xF111ED, self.stream), "fill")
-            oY1, tY1 = offsets(n * nf)
-            d_Y1 = self._alloc(tY1)
-            Y1p = d_Y1.data_ptr() + oY1 * el
             Vf = Vp + k * ld1 * el
-            self.gemm(0, 1.0, 0.0, blk, d_OmF.data_ptr(), Y1p, n, nf, n, L, L, ld1)
-            self.gemm(0, 1.0, 0.0, blk, Y1p, Vf, n, nf, n, L, ld1, ld1)
+            # one multiplication by A: the filled space has eigenvalue >= 1 - 1e-12, everything that is
+            # not projected off with U_E below has eigenvalue <= 1e-12 (the reference's own cutoff)
+            self.nested_products("A", L, Cp, d_OmF.data_ptr(), L, cs_b, cs_side, Vf, nf, ld1)
             d_scr2 = self._alloc(int((ncolV.max() + 1) * PANEL_W) * ncs)
             scr2 = d_scr2.data_ptr() + np.arange(ncs) * int((ncolV.max() + 1) * PANEL_W) * el
             has = nf > 0

@@ -22,6 +22,7 @@ at most 31 entangled pairs per cut, sub-Pfaffians of order <= 32.
 from __future__ import annotations
 
 import logging
+import os
 import time
 
 import numpy as np
@@ -170,7 +171,8 @@ class PfEngine(Engine):
         p = np.where(doE, np.minimum(P, np.minimum(n, m)), 0)
 
         t0 = time.perf_counter()
-        st = self.entangled_stage_adaptive(D, n, m, blk, off, omp, doE, p, thr2, P, cs_b)
+        st = self.entangled_stage_adaptive(D, n, m, blk, off, omp, doE, p, thr2, P, cs_b,
+                                           nest=(2 * cs_b, cs_side, Cp, d_Om.data_ptr()))
         UEp, oS, ld1 = st["UEp"], st["oS"], st["ld1"]
         self._tick("E_entangled", t0)
 
@@ -219,12 +221,8 @@ class PfEngine(Engine):
         if maxnb > 0:
             d_OmF = self._alloc(D * maxnb)
             nat.check(self.lib.tmf_fill_normal(self.dtype, d_OmF.data_ptr(), D * maxnb, 0xF111EE, self.stream), "fill")
-            oY1, tY1 = offsets(n * nb_)
-            d_Y1 = self._alloc(tY1)
-            Y1p = d_Y1.data_ptr() + oY1 * el
             Vf = Vt + 2 * ke * ld1 * el
-            self.gemm(0, 1.0, 0.0, blk, d_OmF.data_ptr(), Y1p, n, nb_, n, D, D, ld1)
-            self.gemm(0, 1.0, 0.0, blk, Y1p, Vf, n, nb_, n, D, ld1, ld1)
+            self.nested_products("A", D, Cp, d_OmF.data_ptr(), D, 2 * cs_b, cs_side, Vf, nb_, ld1)  # Engine.run, stage F
             d_scr2 = self._alloc(int((ncol.max() + 1) * PANEL_W) * ncs)
             scr2 = d_scr2.data_ptr() + np.arange(ncs) * int((ncol.max() + 1) * PANEL_W) * el
             has = nb_ > 0

@@ -472,3 +472,44 @@ def test_pf_gather(eng, cplx, n1, n2):
     if m:  # Pf^2 = det on the GPU values as well
         ix = np.concatenate((ket[0], bra[0])).astype(int)
         np.testing.assert_allclose((got[0, 0] / scale[0]) ** 2, np.linalg.det(N[np.ix_(ix, ix)]), rtol=1e-8)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("kind", ["A", "F"])
+def test_nested_products_match_per_cut_gemm(eng, cplx, kind):
+    """tmf_nested_products_batched (running sums over nested blocks) against one NumPy product per
+    cut: both sides, ragged column counts, cuts at the matrix ends, a gap in the cut list."""
+    setup(eng, cplx)
+    rng = np.random.default_rng(77)
+    D, maxc = 150, 37
+    C = rnd(rng, (D, D), cplx)
+    Om = rnd(rng, (D, maxc), cplx)
+    dC, dOm = dev(eng, C), dev(eng, Om)
+    xs = [x for x in range(0, D + 1) if x not in (40, 41, 42)]
+    x = np.array(xs + xs)
+    side = np.array([0] * len(xs) + [1] * len(xs))
+    n = np.where(side == 0, x, D - x)
+    ncol = rng.integers(0, maxc + 1, size=len(x))
+    ncol[n == 0] = 0
+    if kind == "F":
+        ncol[(D - n) == 0] = 0
+    ld = np.maximum(n, 1) + rng.integers(0, 3, size=len(x))
+    sizes = ld * np.maximum(ncol, 1)
+    offs = np.concatenate(([0], np.cumsum(sizes)))
+    out = eng._alloc(int(offs[-1]), zero=True)
+    dest = out.data_ptr() + offs[:-1] * eng.elem
+    eng.nested_products(kind, D, dC[1], dOm[1], D, x, side, dest, ncol, ld)
+    torch.cuda.synchronize()
+    h = out.cpu().numpy()
+    for i in range(len(x)):
+        if ncol[i] == 0:
+            continue
+        xi, ni = int(x[i]), int(n[i])
+        rows = slice(0, xi) if side[i] == 0 else slice(xi, D)
+        if kind == "A":
+            cols = rows
+        else:
+            cols = slice(xi, D) if side[i] == 0 else slice(0, xi)
+        ref = C[rows, cols] @ Om[cols, : ncol[i]]
+        got = h[offs[i]: offs[i] + ld[i] * ncol[i]].reshape(ncol[i], ld[i]).T[:ni]
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * max(1.0, np.abs(ref).max()), err_msg=f"cut {xi} side {side[i]}")
