@@ -175,11 +175,9 @@ def main():
             kname = (f"tmf::reduced_det_kernel<tmf::cd, {str(dom)[:-1]}>" if str(dom).endswith("r")
                      else f"tmf::det_kernel<tmf::cd, {dom}, G>")
             traffic = None  # HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)
-            pmc = os.path.join(ROOT, "profiles", "r01", "pmc_reduced_det_n12.json")
-            if os.path.exists(pmc):
-                pj = json.load(open(pmc))
-                if pj.get("kernel") == kname and L == 1024 and chi == 512 and world == 1:
-                    traffic = pj["hbm_bytes_per_launch"]
+            pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")  # made by tools/pmc_traffic.py
+            if os.path.exists(pmc) and L == 1024 and chi == 512 and world == 1:
+                traffic = json.load(open(pmc))["kernels"].get(kname, {}).get("hbm_bytes_per_launch")
             all_ms = sum(float(np.mean(v)) for v in det_ms.values())
             all_fl = sum(det_flops.values())
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 4),
