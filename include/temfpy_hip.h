@@ -230,6 +230,20 @@ typedef struct {
 } tmf_nested_desc;           /* 72 bytes */
 int tmf_nested_products_batched(int dtype, const tmf_nested_desc* d_desc, int ndesc, int D, int maxc, void* stream);
 
+/* Self-check of the Schmidt decomposition (testing.check_schmidt_decomposition, testing.py:131-177):
+ * largest absolute deviation between a block T of the correlation matrix and its reconstruction,
+ * folded into *out (double, must be zeroed by the caller) with an atomic max; NaN is reported as +inf.
+ *   mode 0: | T[r,c] - sum_{j<q} X[r,j] w[j] conj(Y[c,j']) |,  j' = j, or q-1-j when y_reverse
+ *           (testing.py:158-159 "vL does not diagonalise C_LL", :170-171, :176-177 "do not SVD C_LR")
+ *   mode 1: | T[r,c] - sum_{i<inner} conj(X[i,r]) Y[i,c] |,  T = identity when T == 0
+ *           (testing.py:155-156 "vL is not unitary", evaluated on the kept columns as V^H V = 1)
+ * `tiles`: int32[ntiles][3] = (problem, tile_row, tile_col) over 64 x 64 tiles of the rows x cols output. */
+typedef struct {
+  uint64_t T, X, Y, w, out;  /* w: q doubles (0 = all ones); out: one double per problem           */
+  int32_t rows, cols, q, inner, ldt, ldx, ldy, mode, y_reverse, pad;
+} tmf_recon_desc;            /* 80 bytes */
+int tmf_recon_error_batched(int dtype, const tmf_recon_desc* d_desc, const int32_t* d_tiles, int ntiles, void* stream);
+
 /* out[j] = 2-norm of column j of src (n x c) */
 typedef struct {
   uint64_t src, out;

@@ -56,6 +56,8 @@ class Engine:
         self.device = torch.device(device)
         self.lib = nat.load()
         self.profile = bool(int(os.environ.get("TMF_PROFILE", "0"))) if profile is None else profile
+        self.checks = True          # evaluate testing.check_schmidt_decomposition's deviations on the device
+        self.check_results = {}
         self.timings = {}
         self._keep = []  # descriptor tensors must outlive the launches that read them
         self._pin_t = self._pin_np = self._dev_arena = None
@@ -229,6 +231,41 @@ class Engine:
                                                        int(descs["maxc"][:nd].max()), self.stream),
                   "tmf_nested_products_batched")
 
+    def recon_errors(self, items):
+        """Launches tmf_recon_error_batched for a list of checks; returns the device tensor that will
+        hold one deviation per item.  item = dict(T, X, Y, w (host float64 array or None), rows, cols,
+        q, inner, ldt, ldx, ldy, mode, y_reverse)."""
+        nchk = len(items)
+        d_dev = self.torch.zeros(max(nchk, 1), dtype=self.torch.float64, device=self.device)
+        self._keep.append(d_dev)
+        if nchk == 0:
+            return d_dev
+        ws = [np.asarray(it["w"], np.float64) for it in items if it.get("w") is not None]
+        w_off, t_w = {}, None
+        if ws:
+            o = 0
+            for i, it in enumerate(items):
+                if it.get("w") is not None:
+                    w_off[i] = o
+                    o += len(it["w"])
+            t_w = self._up(np.concatenate(ws + [np.zeros(1)]))
+        d = np.zeros(nchk, nat.recon_desc)
+        tiles = []
+        for i, it in enumerate(items):
+            d[i] = (it["T"], it["X"], it["Y"], 0 if i not in w_off else t_w.data_ptr() + 8 * w_off[i],
+                    d_dev.data_ptr() + 8 * i, it["rows"], it["cols"], it["q"], it.get("inner", 0), it.get("ldt", 1),
+                    it["ldx"], it["ldy"], it["mode"], it.get("y_reverse", 0), 0)
+            tr, tc = _cdiv(it["rows"], 64), _cdiv(it["cols"], 64)
+            g = np.stack(np.meshgrid(np.arange(tr), np.arange(tc), indexing="ij"), -1).reshape(-1, 2)
+            tiles.append(np.concatenate((np.full((len(g), 1), i), g), axis=1))
+        tiles = np.ascontiguousarray(np.concatenate(tiles), np.int32)
+        if len(tiles) == 0:
+            return d_dev
+        t_d, t_t = self._up(d), self._up(tiles)
+        nat.check(self.lib.tmf_recon_error_batched(self.dtype, t_d.data_ptr(), t_t.data_ptr(), len(tiles), self.stream),
+                  "tmf_recon_error_batched")
+        return d_dev
+
     def colcopy(self, src, dst, n, c, lds_, ldd, reverse=0, flip_odd=0):
         n, c = np.asarray(n, np.int64), np.asarray(c, np.int64)
         sel = np.nonzero((n > 0) & (c > 0))[0]
@@ -338,7 +375,8 @@ class Engine:
 
     def _finish(self, mps):
         mps.info = {"range_finder_iterations": self.range_iterations_used,
-                    "range_finder_smallest_sigma": self.range_floor}
+                    "range_finder_smallest_sigma": self.range_floor,
+                    "checks": dict(getattr(self, "check_results", {}))}
         return mps
 
     def entangled_stage_adaptive(self, L, n, m, blk, off, omp, doE, p, thr2, P, cs_b, nest=None):
@@ -638,8 +676,28 @@ class Engine:
             d_pair = self._alloc(n[centre_R] * k[centre_L])
             self.gemm(0, 1.0, 0.0, [off[centre_R]], [Vp[centre_L]], [d_pair.data_ptr()], [n[centre_R]], [k[centre_L]],
                       [m[centre_R]], [L], [ld1[centre_L]], [ld1[centre_R]])
-            self.colcopy([d_pair.data_ptr()], [Vp[centre_R]], [n[centre_R]], [k[centre_R]], [ld1[centre_R]],
-                         [ld1[centre_R]], reverse=1, flip_odd=1)
+            # The partners of weak orbitals (sigma -> 1e-6) carry errors ~1e-7 from the division by sigma
+            # (measured: |V_R^H V_R - 1| = 3.7e-7 on spinful chains), so they are Gram-Schmidt
+            # orthonormalised in order of DECREASING sigma: strong partners stay as computed, weak ones
+            # are corrected against them.  Column permutations are k x k (signed) permutation GEMMs.
+            kc, nR, ldR = int(k[centre_L]), int(n[centre_R]), int(ld1[centre_R])
+            eL_ = e_side[centre_L]
+            order = np.argsort(-(eL_ * (1.0 - eL_)), kind="stable")
+            cdt = np.complex128 if cplx else np.float64
+            Pm, Sm = np.zeros((kc, kc), cdt), np.zeros((kc, kc), cdt)
+            for a_, j_ in enumerate(order):
+                Pm[j_, a_] = 1.0                                        # T[:, a] = pair[:, order[a]]
+                Sm[a_, kc - 1 - j_] = -1.0 if (kc - 1 - j_) & 1 else 1.0  # slater.py:410 reversal + signs
+            t_P = self._up(np.ascontiguousarray(Pm.T).reshape(-1))       # column-major upload
+            t_S = self._up(np.ascontiguousarray(Sm.T).reshape(-1))
+            d_T = self._alloc(nR * kc)
+            self.gemm(0, 1.0, 0.0, [d_pair.data_ptr()], [t_P.data_ptr()], [d_T.data_ptr()], [nR], [kc], [kc], [ldR],
+                      [kc], [ldR])
+            d_scrc = self._alloc((kc + 1) * PANEL_W)
+            self.bcgs2(np.array([d_T.data_ptr()]), np.array([nR]), np.array([ldR]), np.array([0]), np.array([kc]),
+                       np.array([d_scrc.data_ptr()]))
+            self.gemm(0, 1.0, 0.0, [d_T.data_ptr()], [t_S.data_ptr()], [Vp[centre_R]], [nR], [kc], [kc], [ldR], [kc],
+                      [ldR])
         # filled: Y = A Omega_f, projected off U_E and orthonormalised below
         maxnf = int(nf.max()) if ncs else 0
         if maxnf > 0:
@@ -653,6 +711,31 @@ class Engine:
             scr2 = d_scr2.data_ptr() + np.arange(ncs) * int((ncolV.max() + 1) * PANEL_W) * el
             has = nf > 0
             self.bcgs2(Vp[has], n[has], ld1[has], k[has], ncolV[has], scr2[has])
+        # self-check of the centre cut (testing.py:131-177; slater.py:419-420 runs it only there)
+        chk_names, d_chk = [], None
+        if self.checks and has_centre and doE[centre_L]:
+            iL, iR = centre_L, centre_R
+            qL, qR, kc = int(ncolV[iL]), int(ncolV[iR]), int(k[iL])
+            wL = np.concatenate((e_side[iL], np.ones(int(nf[iL]))))
+            wR = np.concatenate((e_side[iR], np.ones(int(nf[iR]))))
+            eL = e_side[iL]
+            sv = np.sqrt(eL * (1.0 - eL)) * (-1.0) ** (np.arange(kc)[::-1])  # slater.py:266-268
+            mk = lambda **kw: kw  # noqa: E731
+            items = [
+                mk(T=0, X=Vp[iL], Y=Vp[iL], w=None, rows=qL, cols=qL, q=0, inner=int(n[iL]), ldx=int(ld1[iL]),
+                   ldy=int(ld1[iL]), mode=1),
+                mk(T=blk[iL], X=Vp[iL], Y=Vp[iL], w=wL, rows=int(n[iL]), cols=int(n[iL]), q=qL, ldt=L,
+                   ldx=int(ld1[iL]), ldy=int(ld1[iL]), mode=0),
+                mk(T=0, X=Vp[iR], Y=Vp[iR], w=None, rows=qR, cols=qR, q=0, inner=int(n[iR]), ldx=int(ld1[iR]),
+                   ldy=int(ld1[iR]), mode=1),
+                mk(T=blk[iR], X=Vp[iR], Y=Vp[iR], w=wR, rows=int(n[iR]), cols=int(n[iR]), q=qR, ldt=L,
+                   ldx=int(ld1[iR]), ldy=int(ld1[iR]), mode=0),
+                mk(T=off[iL], X=Vp[iL], Y=Vp[iR], w=sv, rows=int(n[iL]), cols=int(n[iR]), q=kc, ldt=L,
+                   ldx=int(ld1[iL]), ldy=int(ld1[iR]), mode=0, y_reverse=1),
+            ]
+            chk_names = ["vL is not unitary", "vL does not diagonalise C_LL", "vR is not unitary",
+                         "vR does not diagonalise C_RR", "vL and vR do not SVD C_LR"]
+            d_chk = self.recon_errors(items)
         self._tick("F_filled", t0)
 
         th.join()
@@ -776,6 +859,9 @@ class Engine:
         t0 = time.perf_counter()
         bonds = ho["make_bonds"]()
         self._tick("host_bonds", t0)
+        self.check_results = {}
+        if d_chk is not None:
+            self.check_results = dict(zip(chk_names, (float(v) for v in d_chk.cpu().numpy())))
 
         # ---- host round trip 2: tensors back -----------------------------------------------------
         if not download:

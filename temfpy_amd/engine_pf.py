@@ -181,6 +181,7 @@ class PfEngine(Engine):
         h_e, h_cnt = st["h_e"], st["h_cnt"]
         ke = np.zeros(ncs, np.int64)
         e_cut = [np.zeros(0)] * ncs
+        lam_side = [np.zeros(0)] * ncs                 # eigenvalue of every entangled column of Vt
         for i in range(ncs):
             if not doE[i]:
                 continue
@@ -194,8 +195,12 @@ class PfEngine(Engine):
                 raise NotImplementedError("eigenvalue-1/2 modes (Majorana zero modes at a cut) are not supported yet")
             ke[i] = cnt // 2
             e_cut[i] = lam[ke[i]:][::-1].copy()     # lower half, ascending (pfaffian.py:839)
+            lam_side[i] = lam.copy()
         ke[centre_R] = ke[centre_L]
         e_cut[centre_R] = e_cut[centre_L]
+        kc_ = int(ke[centre_L])
+        # centre-right columns (built below): [partners of the left LOWER modes, reversed | their conjugates]
+        lam_side[centre_R] = np.concatenate(((1.0 - lam_side[centre_L][kc_:])[::-1], lam_side[centre_L][kc_:]))
         nb_ = ns - ke                                  # filled / empty basis vectors
         self._tick("host_classify", t0)
 
@@ -213,10 +218,27 @@ class PfEngine(Engine):
             d_pair = self._alloc(n[centre_R] * kc)
             self.gemm(0, 1.0, 0.0, [off[centre_R]], [Vt[centre_L] + kc * ld1[centre_L] * el], [d_pair.data_ptr()],
                       [n[centre_R]], [kc], [m[centre_R]], [D], [ld1[centre_L]], [ld1[centre_R]])
-            self.colcopy([d_pair.data_ptr()], [Vt[centre_R]], [n[centre_R]], [kc], [ld1[centre_R]], [ld1[centre_R]],
-                         reverse=1)
-            self.colcopy([d_pair.data_ptr()], [Vt[centre_R] + kc * ld1[centre_R] * el], [n[centre_R]], [kc],
-                         [ld1[centre_R]], [ld1[centre_R]], reverse=2)
+            # ordered Gram-Schmidt of the partners (strongest singular value first), as in Engine.run:
+            # partners of weak modes carry errors ~1e-6 from the division by sigma
+            nR, ldR = int(n[centre_R]), int(ld1[centre_R])
+            lamL = lam_side[centre_L][kc:]
+            order = np.argsort(-(lamL * (1.0 - lamL)), kind="stable")
+            Pm, Sm = np.zeros((kc, kc), np.complex128), np.zeros((kc, kc), np.complex128)
+            for a_, j_ in enumerate(order):
+                Pm[j_, a_] = 1.0
+                Sm[a_, kc - 1 - j_] = 1.0                       # reversal only (no anticommutation signs here)
+            t_P = self._up(np.ascontiguousarray(Pm.T).reshape(-1))
+            t_S = self._up(np.ascontiguousarray(Sm.T).reshape(-1))
+            d_T = self._alloc(nR * kc)
+            self.gemm(0, 1.0, 0.0, [d_pair.data_ptr()], [t_P.data_ptr()], [d_T.data_ptr()], [nR], [kc], [kc], [ldR],
+                      [kc], [ldR])
+            d_scrc = self._alloc((kc + 1) * PANEL_W)
+            self.bcgs2(np.array([d_T.data_ptr()]), np.array([nR]), np.array([ldR]), np.array([0]), np.array([kc]),
+                       np.array([d_scrc.data_ptr()]))
+            self.gemm(0, 1.0, 0.0, [d_T.data_ptr()], [t_S.data_ptr()], [Vt[centre_R]], [nR], [kc], [kc], [ldR], [kc],
+                      [ldR])
+            # conjugate partners: column kc + c = conj(column kc - 1 - c)
+            self.colcopy([Vt[centre_R]], [Vt[centre_R] + kc * ldR * el], [nR], [kc], [ldR], [ldR], reverse=3)
         maxnb = int(nb_.max())
         if maxnb > 0:
             d_OmF = self._alloc(D * maxnb)
@@ -227,6 +249,24 @@ class PfEngine(Engine):
             scr2 = d_scr2.data_ptr() + np.arange(ncs) * int((ncol.max() + 1) * PANEL_W) * el
             has = nb_ > 0
             self.bcgs2(Vt[has], n[has], ld1[has], 2 * ke[has], ncol[has], scr2[has])
+        # ---- self-check of every cut side (pfaffian.py:919 -> testing.py:131-177): kept columns
+        # orthonormal, and A = V diag(lambda | 1) V^H (the empty modes, conj(filled), carry eigenvalue 0)
+        chk_names, d_chk = [], None
+        if self.checks:
+            items = []
+            for i in range(ncs):
+                if n[i] == 0 or ncol[i] == 0:
+                    continue
+                q_ = int(ncol[i])
+                sdn = "L" if cs_side[i] == 0 else "R"
+                items.append(dict(T=0, X=Vt[i], Y=Vt[i], w=None, rows=q_, cols=q_, q=0, inner=int(n[i]),
+                                  ldx=int(ld1[i]), ldy=int(ld1[i]), mode=1))
+                chk_names.append(f"v{sdn} is not unitary (cut {cs_b[i]})")
+                items.append(dict(T=blk[i], X=Vt[i], Y=Vt[i], w=np.concatenate((lam_side[i], np.ones(int(nb_[i])))),
+                                  rows=int(n[i]), cols=int(n[i]), q=q_, ldt=D, ldx=int(ld1[i]), ldy=int(ld1[i]),
+                                  mode=0))
+                chk_names.append(f"v{sdn} does not diagonalise C_{sdn}{sdn} (cut {cs_b[i]})")
+            d_chk = self.recon_errors(items)
         # ---- Bogoliubov matrices v = [a | a^dag] in the complex-fermion basis (pfaffian.py:880-895) ----
         oVC, tVC = offsets(n * n)
         d_VC, d_VW = self._alloc(tVC), self._alloc(tVC)
@@ -484,6 +524,15 @@ class PfEngine(Engine):
             sites.append(PfSite("left" if r["mode"] == 0 else "right", float(norms[i].real), qtotal, r["leg_idx"],
                                 blocks, r["chi_b"], r["chi_k"]))
         self._tick("download", t0)
+        self.check_results = {}
+        if d_chk is not None:
+            h_chk = d_chk.cpu().numpy()
+            # one entry per message: the worst cut
+            for nm, v in zip(chk_names, h_chk):
+                key = nm.split(" (cut")[0]
+                if not v <= self.check_results.get(key, (-1.0, ""))[0]:
+                    self.check_results[key] = (float(v), nm)
+            self.check_results = {nm: v for v, nm in self.check_results.values()}
         self.timings["total"] = time.perf_counter() - t_all
         self._keep.clear()
         return self._finish(PfMPSData(bonds, sites, oc, unit_cell_width, dict(self.timings)))

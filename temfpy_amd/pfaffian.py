@@ -12,6 +12,7 @@ import logging
 import numpy as np
 
 from .schmidt_utils import StoppingCondition, to_stopping_condition
+from . import testing
 from .testing import _DIAG_TOL, assert_allclose, assert_array_less
 from .utils import HT
 
@@ -119,7 +120,11 @@ def C_to_MPS(C: np.ndarray, trunc_par: dict | StoppingCondition, *, basis: str, 
     logger.info("Central bond %d", ortho_center)
     if device not in _ENGINES:
         _ENGINES[device] = PfEngine(device)
-    return _ENGINES[device].run(C, trunc_par, ortho_center, unit_cell_width)
+    eng = _ENGINES[device]
+    eng.checks = testing.TEST_ACTION != "pass"
+    mps = eng.run(C, trunc_par, ortho_center, unit_cell_width)
+    testing.report_schmidt_checks(mps.info["checks"], diag_tol)  # pfaffian.py:919
+    return mps
 
 
 def H_to_MPS(H: np.ndarray, trunc_par: dict | StoppingCondition, *, basis: str, diag_tol: float = _DIAG_TOL,

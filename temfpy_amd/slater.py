@@ -13,6 +13,7 @@ from typing import Literal
 import numpy as np
 
 from .schmidt_utils import StoppingCondition, to_stopping_condition
+from . import testing
 from .testing import _DIAG_TOL
 from .utils import HT
 from .mps_data import MPSData
@@ -86,7 +87,10 @@ def C_to_MPS(
     assert C.shape == (L, L), f"Got non-square {C.shape} correlation matrix"
     ortho_center = ortho_center or L // 2  # slater.py:1291
     logger.info("Central bond %d", ortho_center)
-    mps = _engine(device).run(C, trunc_par, ortho_center, unit_cell_width)
+    eng = _engine(device)
+    eng.checks = testing.TEST_ACTION != "pass"  # testing.py:146-147
+    mps = eng.run(C, trunc_par, ortho_center, unit_cell_width)
+    testing.report_schmidt_checks(mps.info["checks"], diag_tol)  # slater.py:419-420
     if as_tenpy is False:
         return mps
     try:

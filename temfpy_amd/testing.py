@@ -33,3 +33,22 @@ def assert_allclose(actual, desired, rtol=1e-7, atol=0.0, equal_nan=True, err_ms
 
 def assert_array_less(x, y, err_msg="", verbose=False):
     _report(np.testing.assert_array_less, err_msg, x, y, verbose=verbose)
+
+
+def report_schmidt_checks(deviations, diag_tol=_DIAG_TOL):
+    """Outcome of ``check_schmidt_decomposition`` (testing.py:131-177) from deviations that were
+    evaluated on the device: ``deviations`` maps the reference's error message to the largest
+    absolute difference between a block of the correlation matrix and its reconstruction.
+    Raises / warns / ignores according to :data:`TEST_ACTION`, like the reference."""
+    if TEST_ACTION == "pass":
+        return
+    if TEST_ACTION not in ("raise", "warn"):
+        raise ValueError(f"Invalid value {TEST_ACTION!r} of `temfpy_amd.testing.TEST_ACTION`,\n"
+                         "must be one of 'raise', 'warn', 'pass'.")
+    for err_msg, dev in deviations.items():
+        if not dev <= diag_tol:
+            text = (f"\n{err_msg}\nNot equal to tolerance rtol=0, atol={diag_tol:g}\n"
+                    f"Max absolute difference among violations: {dev:.8g}")
+            if TEST_ACTION == "raise":
+                raise AssertionError(text)
+            warnings.warn(text, category=ComparisonWarning)

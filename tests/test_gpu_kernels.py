@@ -513,3 +513,34 @@ def test_nested_products_match_per_cut_gemm(eng, cplx, kind):
         ref = C[rows, cols] @ Om[cols, : ncol[i]]
         got = h[offs[i]: offs[i] + ld[i] * ncol[i]].reshape(ncol[i], ld[i]).T[:ni]
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * max(1.0, np.abs(ref).max()), err_msg=f"cut {xi} side {side[i]}")
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_recon_error_kernel(eng, cplx):
+    """tmf_recon_error_batched: max |T - X diag(w) Y^H| (with and without column reversal of Y),
+    max |1 - X^H Y|, ragged sizes across tile borders, and NaN reported as +inf."""
+    setup(eng, cplx)
+    rng = np.random.default_rng(5)
+    items, refs, keep = [], [], []
+    for rows, cols, q, rev in [(70, 130, 9, 0), (64, 64, 64, 1), (1, 3, 2, 1), (129, 65, 33, 0)]:
+        X, Y, T = rnd(rng, (rows, q), cplx), rnd(rng, (cols, q), cplx), rnd(rng, (rows, cols), cplx)
+        w = rng.standard_normal(q)
+        dX, dY, dT = dev(eng, X), dev(eng, Y), dev(eng, T)
+        keep += [dX, dY, dT]
+        Yu = Y[:, ::-1] if rev else Y
+        refs.append(np.abs(T - (X * w) @ Yu.conj().T).max())
+        items.append(dict(T=dT[1], X=dX[1], Y=dY[1], w=w, rows=rows, cols=cols, q=q, ldt=rows, ldx=rows, ldy=cols,
+                          mode=0, y_reverse=rev))
+    for inner, r_, c_ in [(100, 70, 70), (5, 3, 66)]:
+        X, Y = rnd(rng, (inner, r_), cplx), rnd(rng, (inner, c_), cplx)
+        dX, dY = dev(eng, X), dev(eng, Y)
+        keep += [dX, dY]
+        refs.append(np.abs(np.eye(r_, c_) - X.conj().T @ Y).max())
+        items.append(dict(T=0, X=dX[1], Y=dY[1], w=None, rows=r_, cols=c_, q=0, inner=inner, ldx=inner, ldy=inner, mode=1))
+    Xn = rnd(rng, (10, 4), cplx)
+    Xn[3, 2] = np.nan
+    dXn, dTn = dev(eng, Xn), dev(eng, rnd(rng, (10, 10), cplx))
+    items.append(dict(T=dTn[1], X=dXn[1], Y=dXn[1], w=None, rows=10, cols=10, q=4, ldt=10, ldx=10, ldy=10, mode=0))
+    got = eng.recon_errors(items).cpu().numpy()
+    np.testing.assert_allclose(got[:-1], refs, rtol=1e-12)
+    assert np.isinf(got[-1])

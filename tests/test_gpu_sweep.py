@@ -278,3 +278,73 @@ def test_spinful_ph_chain_block_decoupled_spectra(L, chi):
     dS = np.abs(orc.entropies(cuts) - mps.entanglement_entropy(all_bonds=True)).max()
     assert dS < 2e-3
     assert abs(1 - overlap(cuts, sites, mps, L)) < 1e-3
+
+
+def test_schmidt_decomposition_self_check_on_device():
+    """testing.check_schmidt_decomposition (testing.py:131-177) evaluated by tmf_recon_error_batched:
+    deviations of the centre cut far below diag_tol for a proper Slater determinant, reported as
+    ComparisonWarning / AssertionError / ignored according to TEST_ACTION when C is not a projector."""
+    import warnings
+    from tests_inputs import random_hopping
+    from temfpy_amd import slater, testing
+
+    C, _ = slater.correlation_matrix(random_hopping(32, 3))
+    mps = run_hip(C, 64)
+    chk = mps.info["checks"]
+    assert set(chk) == {"vL is not unitary", "vL does not diagonalise C_LL", "vR is not unitary",
+                        "vR does not diagonalise C_RR", "vL and vR do not SVD C_LR"}
+    assert max(chk.values()) <= 1e-11, chk
+    # an oracle-side cross-check of the same quantities
+    e, v = np.linalg.eigh(C[:16, :16])
+    assert abs(np.abs((v * e) @ v.conj().T - C[:16, :16]).max() - 0.0) <= 1e-13
+
+    rng = np.random.default_rng(0)
+    N = rng.standard_normal((32, 32)) + 1j * rng.standard_normal((32, 32))
+    Cbad = C + 1e-7 * (N + N.conj().T)          # not idempotent any more: reconstructions are off by > 1e-8
+    old = testing.TEST_ACTION
+    try:
+        testing.TEST_ACTION = "warn"
+        with pytest.warns(testing.ComparisonWarning, match="does not diagonalise"):
+            bad = run_hip(Cbad, 64)
+        assert max(bad.info["checks"].values()) > 1e-8
+        testing.TEST_ACTION = "raise"
+        with pytest.raises(AssertionError, match="Max absolute difference"):
+            run_hip(Cbad, 64)
+        testing.TEST_ACTION = "pass"
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            quiet = run_hip(Cbad, 64)
+        assert quiet.info["checks"] == {}
+        # a looser diag_tol accepts it (slater.py:1216-1224 keyword)
+        testing.TEST_ACTION = "raise"
+        run_hip(Cbad, 64, diag_tol=1e-2)
+    finally:
+        testing.TEST_ACTION = old
+
+
+def test_self_check_deviations_match_the_reference():
+    """The device-evaluated deviations of check_schmidt_decomposition against the values the reference's
+    own SchmidtModes give at the centre cut (tests/golden/ref_checks.json, make_golden_checks.py):
+    the C_LR reconstruction error is dominated by the discarded modes (sigma < 1e-6) and agrees to 3
+    digits - the reference warns for exactly the same inputs; everything else is at rounding level."""
+    import json
+    import warnings
+    from tests_inputs import random_hopping
+    from temfpy_amd import slater, testing
+
+    ref = json.load(open(os.path.join(GOLDEN, "ref_checks.json")))
+    for case in ref.values():
+        C, _ = slater.correlation_matrix(random_hopping(case["L"], case["seed"]))
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            mps = run_hip(C, case["chi"])
+        got, want = mps.info["checks"], case["deviations"]
+        lr = "vL and vR do not SVD C_LR"
+        if want[lr] > 1e-10:
+            assert abs(got[lr] - want[lr]) <= 2e-3 * want[lr], (got[lr], want[lr])
+        for key in want:
+            if key != lr or want[lr] <= 1e-10:
+                assert got[key] <= max(10 * want[key], 1e-9), (key, got[key], want[key])
+        warned = sorted({str(w.message).strip().split("\n")[0] for w in rec
+                         if isinstance(w.message, testing.ComparisonWarning)})
+        assert warned == case["warned"], (warned, case["warned"])

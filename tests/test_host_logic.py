@@ -142,3 +142,31 @@ def test_site_prepare_matches_oracle(name):
             kl = r["idx_pool"][sec["ket_off"]: sec["ket_off"] + (c1 - c0) * n].reshape(c1 - c0, n)
             np.testing.assert_array_equal(bl, np.nonzero(s.sets_bra[r0:r1])[1].reshape(r1 - r0, n))
             np.testing.assert_array_equal(kl, np.nonzero(s.sets_ket[c0:c1])[1].reshape(c1 - c0, n))
+
+
+def test_report_schmidt_checks_follows_test_action():
+    """testing.report_schmidt_checks mirrors the reference's TEST_ACTION switch (testing.py:15-128)."""
+    import warnings
+    from temfpy_amd import testing
+
+    old = testing.TEST_ACTION
+    try:
+        dev = {"vL does not diagonalise C_LL": 3e-7, "vL is not unitary": 1e-15}
+        testing.TEST_ACTION = "warn"
+        with pytest.warns(testing.ComparisonWarning, match="vL does not diagonalise C_LL"):
+            testing.report_schmidt_checks(dev, 1e-8)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            testing.report_schmidt_checks(dev, 1e-6)           # within tolerance: silent
+        testing.TEST_ACTION = "raise"
+        with pytest.raises(AssertionError, match="3e-07"):
+            testing.report_schmidt_checks(dev, 1e-8)
+        with pytest.raises(AssertionError):
+            testing.report_schmidt_checks({"x": float("nan")}, 1e-8)   # NaN never passes
+        testing.TEST_ACTION = "pass"
+        testing.report_schmidt_checks(dev, 1e-8)
+        testing.TEST_ACTION = "bogus"
+        with pytest.raises(ValueError, match="TEST_ACTION"):
+            testing.report_schmidt_checks(dev, 1e-8)
+    finally:
+        testing.TEST_ACTION = old
