@@ -253,7 +253,8 @@ int tmf_column_norms_batched(int dtype, const tmf_norms_desc* d_desc, int nprob,
 
 /* normalise each column of A (n x c) by its 2-norm; optionally reverse column order
  * and flip the sign of odd columns (slater.py:410) while copying into dst;
- * reverse & 2: also take the complex conjugate                                        */
+ * reverse & 2: also take the complex conjugate;  reverse & 4: keep the real part only
+ * (before normalising: the real basis of the eigenvalue-1/2 modes, pfaffian.py:807-816)      */
 typedef struct {
   uint64_t src, dst;
   int32_t n, c, lds_, ldd, reverse, flip_odd;

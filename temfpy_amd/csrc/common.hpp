@@ -28,6 +28,7 @@ struct sc<double> {
   __device__ static inline double zero() { return 0.0; }
   __device__ static inline double one() { return 1.0; }
   __device__ static inline double conj(double a) { return a; }
+  __device__ static inline double real_only(double a) { return a; }
   __device__ static inline double mul(double a, double b) { return a * b; }
   __device__ static inline double cmul(double a, double b) { return a * b; }  // conj(a)*b
   __device__ static inline double add(double a, double b) { return a + b; }
@@ -55,6 +56,7 @@ struct sc<cd> {
   __device__ static inline cd zero() { return make_cd(0.0, 0.0); }
   __device__ static inline cd one() { return make_cd(1.0, 0.0); }
   __device__ static inline cd conj(cd a) { return make_cd(a.x, -a.y); }
+  __device__ static inline cd real_only(cd a) { return make_cd(a.x, 0.0); }
   __device__ static inline cd mul(cd a, cd b) { return make_cd(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x)); }
   __device__ static inline cd cmul(cd a, cd b) { return make_cd(fma(a.x, b.x, a.y * b.y), fma(a.x, b.y, -a.y * b.x)); }
   __device__ static inline cd add(cd a, cd b) { return make_cd(a.x + b.x, a.y + b.y); }

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void gather_kernel(const tmf_gather_desc* __re
   }
 }
 
-// ---- column normalise (+ optional reversal / odd sign flip, slater.py:410) -------------
+// ---- column normalise (+ optional reversal / conjugation / real part / odd sign flip, slater.py:410,
+//      pfaffian.py:807-816) -------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void colnorm_kernel(const tmf_colnorm_desc* __restrict__ desc) {
   const tmf_colnorm_desc d = desc[blockIdx.x];
@@ -94,7 +95,11 @@ __global__ __launch_bounds__(256) void colnorm_kernel(const tmf_colnorm_desc* __
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int c = 0; c < d.c; ++c) {
     double s = 0.0;
-    for (int r = threadIdx.x; r < d.n; r += 256) s += sc<T>::abs2(src[(size_t)r + (size_t)c * d.lds_]);
+    for (int r = threadIdx.x; r < d.n; r += 256) {
+      T v = src[(size_t)r + (size_t)c * d.lds_];
+      if (d.reverse & 4) v = sc<T>::real_only(v);
+      s += sc<T>::abs2(v);
+    }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     __syncthreads();
     if (lane == 0) red[wave] = s;
@@ -105,6 +110,7 @@ __global__ __launch_bounds__(256) void colnorm_kernel(const tmf_colnorm_desc* __
     if (d.flip_odd && (cd_ & 1)) f = -f;
     for (int r = threadIdx.x; r < d.n; r += 256) {
       T v = src[(size_t)r + (size_t)c * d.lds_];
+      if (d.reverse & 4) v = sc<T>::real_only(v);
       if (d.reverse & 2) v = sc<T>::conj(v);
       dst[(size_t)r + (size_t)cd_ * d.ldd] = sc<T>::scale(v, f);
     }

@@ -180,6 +180,7 @@ class PfEngine(Engine):
         t0 = time.perf_counter()
         h_e, h_cnt = st["h_e"], st["h_cnt"]
         ke = np.zeros(ncs, np.int64)
+        kh = np.zeros(ncs, np.int64)                   # pairs of eigenvalue-1/2 modes (included in ke)
         e_cut = [np.zeros(0)] * ncs
         lam_side = [np.zeros(0)] * ncs                 # eigenvalue of every entangled column of Vt
         for i in range(ncs):
@@ -191,12 +192,17 @@ class PfEngine(Engine):
             lam = h_e[oS[i]: oS[i] + cnt]
             if cnt % 2 or np.abs(lam + lam[::-1] - 1.0).max(initial=0.0) > 1e-8:
                 raise ValueError("Eigenvalues break Nambu symmetry")  # pfaffian.py:799-800
-            if np.any(np.abs(lam - 0.5) <= deg_tol):
-                raise NotImplementedError("eigenvalue-1/2 modes (Majorana zero modes at a cut) are not supported yet")
             ke[i] = cnt // 2
+            half = np.abs(lam - 0.5) <= deg_tol              # pfaffian.py:803-805
+            if half.any():
+                nh = int(half.sum())
+                assert nh % 2 == 0 and half[ke[i] - nh // 2: ke[i] + nh // 2].all(), \
+                    "1/2 eigenvalues asymmetrical in spectrum"
+                kh[i] = nh // 2
             e_cut[i] = lam[ke[i]:][::-1].copy()     # lower half, ascending (pfaffian.py:839)
             lam_side[i] = lam.copy()
         ke[centre_R] = ke[centre_L]
+        kh[centre_R] = kh[centre_L]
         e_cut[centre_R] = e_cut[centre_L]
         kc_ = int(ke[centre_L])
         # centre-right columns (built below): [partners of the left LOWER modes, reversed | their conjugates]
@@ -212,6 +218,47 @@ class PfEngine(Engine):
         Vt = d_Vt.data_ptr() + oV * el
         cp = doE.copy()
         self.colcopy(UEp[cp], Vt[cp], n[cp], 2 * ke[cp], ld1[cp], ld1[cp])
+        # ---- eigenvalue-1/2 modes (pfaffian.py:807-816, :867-874, :883-889) ---------------------------
+        # The Ritz vectors of the degenerate 1/2 eigenspace are an arbitrary orthonormal basis; the rest of
+        # the sweep needs conjugate pairs (u, conj u) like every other mode.  The eigenspace is closed
+        # under conjugation, so Re(U_h G) (G random) spans its real form; it is orthonormalised to a real
+        # basis w, shuffled with the reference's fixed-seed orthogonal matrix O, and combined as
+        # (w_j + i w_(kh+j)) / sqrt(2) (left) resp. (-i w_j + w_(kh+j)) / sqrt(2) (right).
+        hm = np.nonzero((kh > 0) & doE)[0]
+        if hm.size:
+            from scipy.stats import ortho_group
+
+            khm = kh[hm]
+            mx = int(2 * khm.max())
+            rng = np.random.default_rng(4321)
+            t_G = self._up(np.ascontiguousarray((rng.standard_normal((mx, mx)) + 1j * rng.standard_normal((mx, mx))).T))
+            oT, tT = offsets(n[hm] * 2 * khm)
+            d_Th = self._alloc(tT)
+            Tp = d_Th.data_ptr() + oT * el
+            Uh = Vt[hm] + (ke[hm] - khm) * ld1[hm] * el          # the 2 kh contiguous 1/2 columns
+            self.gemm(0, 1.0, 0.0, Uh, np.full(hm.size, t_G.data_ptr()), Tp, n[hm], 2 * khm, 2 * khm, ld1[hm],
+                      np.full(hm.size, mx), ld1[hm])
+            self.colcopy(Tp, Tp, n[hm], 2 * khm, ld1[hm], ld1[hm], reverse=4)      # real part, normalised
+            d_scrh = self._alloc(hm.size * (mx + 1) * PANEL_W)
+            self.bcgs2(Tp, n[hm], ld1[hm], np.zeros(hm.size, np.int64), 2 * khm,
+                       d_scrh.data_ptr() + np.arange(hm.size) * (mx + 1) * PANEL_W * el)
+            Mp = np.zeros(hm.size, np.int64)
+            cache = {}
+            for t_, i in enumerate(hm):
+                key = (int(kh[i]), int(cs_side[i]))
+                if key not in cache:
+                    k_ = key[0]
+                    O = ortho_group.rvs(2 * k_, random_state=1234)                 # pfaffian.py:870
+                    if key[1] == 0:      # lower 1/2 column ke + j
+                        M_ = (O[:, :k_] + 1j * O[:, k_:]) / 2**0.5
+                    else:                # upper 1/2 column ke - 1 - j  ->  block column kh - 1 - j
+                        M_ = ((-1j * O[:, :k_] + O[:, k_:]) / 2**0.5)[:, ::-1]
+                    cache[key] = self._up(np.ascontiguousarray(M_.T))
+                Mp[t_] = cache[key].data_ptr()
+            prim = Vt[hm] + np.where(cs_side[hm] == 0, ke[hm], ke[hm] - khm) * ld1[hm] * el
+            conj_ = Vt[hm] + np.where(cs_side[hm] == 0, ke[hm] - khm, ke[hm]) * ld1[hm] * el
+            self.gemm(0, 1.0, 0.0, Tp, Mp, prim, n[hm], khm, 2 * khm, ld1[hm], 2 * khm, ld1[hm])
+            self.colcopy(prim, conj_, n[hm], khm, ld1[hm], ld1[hm], reverse=3)      # reversed + conjugated
         kc = int(ke[centre_L])
         if kc > 0 and n[centre_R] > 0:
             # paired upper modes of the centre's right side: normalise(C_RL v_L,i) (block_svd, pfaffian.py:855)

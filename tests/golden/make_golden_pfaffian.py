@@ -83,12 +83,31 @@ def kitaev_majorana_H(L, t1, t2):
     return M + M.T.conj()
 
 
+def half_mode_majorana_H(L, lefts, seed):
+    """Majorana Hamiltonian whose entanglement cuts carry exact eigenvalue-1/2 modes (pfaffian.py:807-874):
+    every Majorana j in `lefts` is dimerised with its mirror image 2L-1-j across the chain (the
+    situation of a topological chain whose end modes are paired) and decoupled from a random BdG
+    system on all the other Majoranas.  Every cut that separates a dimer sees its left member as an
+    isolated 1/2 mode, and the remaining odd number of Majoranas forces a second one."""
+    M = np.zeros((2 * L, 2 * L))
+    out = sorted(set(lefts) | {2 * L - 1 - j for j in lefts})
+    inner = np.array([j for j in range(2 * L) if j not in out])
+    rng = np.random.default_rng(seed)
+    x, y = np.meshgrid(inner, inner, indexing="ij")
+    M[np.ix_(inner, inner)] = rng.normal(size=(len(inner), len(inner))) * np.exp(-abs(x - y) / 3.0)
+    for i, j in enumerate(lefts):
+        M[j, 2 * L - 1 - j] = 1.0 + 0.5 * i
+    return 1j * (M - M.T)
+
+
 CASES = [
     ("pf_rand_L6_s0_chi16", lambda: random_majorana_H(6, 0), dict(chi_max=16)),
     ("pf_rand_L8_s1_chi32", lambda: random_majorana_H(8, 1), dict(chi_max=32)),
     ("pf_rand_L10_s2_chi24", lambda: random_majorana_H(10, 2), dict(chi_max=24)),
     ("pf_rand_L9_s3_oc3_chi20", lambda: random_majorana_H(9, 3), dict(chi_max=20, ortho_center=3)),
     ("pf_kitaev_L8_trivial_chi16", lambda: kitaev_majorana_H(8, 1.5j, 1j), dict(chi_max=16)),
+    ("pf_half_L8_p1_s0_chi32", lambda: half_mode_majorana_H(8, [0], 0), dict(chi_max=32)),
+    ("pf_half_L9_p1_s1_oc3_chi24", lambda: half_mode_majorana_H(9, [1], 1), dict(chi_max=24, ortho_center=3)),
 ]
 
 
@@ -152,7 +171,10 @@ def replay(pf, C, chi_max, ortho_center=None):
 def main():
     pf, testing = load_reference_pfaffian()
     warnings.simplefilter("ignore")
+    only = sys.argv[1] if len(sys.argv) > 1 else ""   # optional name prefix: regenerate a subset
     for name, builder, kw in CASES:
+        if not name.startswith(only):
+            continue
         H = builder()
         C = pf.correlation_matrix(H, "M->M")
         data = replay(pf, C, **kw)

@@ -32,7 +32,11 @@ def oracle_dense(cuts, sites):
     return T
 
 
-def check_against_oracle(C, chi, oc=None, tol=1e-9, elem_tol=1e-7):
+def check_against_oracle(C, chi, oc=None, tol=1e-9, elem_tol=1e-7, degenerate=False):
+    """degenerate: exact eigenvalue-1/2 modes make the Schmidt spectrum 2^kh-fold degenerate, so the
+    basis inside a multiplet (and with it the vacuum parities, the occupation patterns and the tensor
+    entries) is a gauge choice - also in the reference, which fixes it with a seeded random rotation
+    (pfaffian.py:867-874).  Then only gauge-invariant quantities are compared."""
     from temfpy_amd import pfaffian
 
     mps = pfaffian.C_to_MPS(C, {"chi_max": chi}, basis="M", ortho_center=oc)
@@ -41,10 +45,14 @@ def check_against_oracle(C, chi, oc=None, tol=1e-9, elem_tol=1e-7):
     o = oc or L // 2
     for b in range(L + 1):
         np.testing.assert_allclose(mps.bonds[b].e, cuts[b].e, rtol=0, atol=1e-13)
+        if degenerate:
+            assert (mps.bonds[b].pL + mps.bonds[b].pR) % 2 == (cuts[b].pL + cuts[b].pR) % 2   # total parity
+            np.testing.assert_allclose(np.sort(mps.bonds[b].lam), np.sort(cuts[b].lam), rtol=0, atol=1e-10)
+            continue
         np.testing.assert_array_equal(mps.bonds[b].sets, cuts[b].sets)
         assert (mps.bonds[b].pL, mps.bonds[b].pR) == (cuts[b].pL, cuts[b].pR)
         np.testing.assert_allclose(mps.bonds[b].lam, cuts[b].lam, rtol=0, atol=1e-10)
-    for i in range(L):
+    for i in range(L if not degenerate else 0):
         assert abs(mps.sites[i].norm - abs(sites[i].norm)) < 1e-9
         assert sorted(mps.sites[i].blocks) == sorted(sites[i].blocks)
         np.testing.assert_array_equal(mps.sites[i].leg_idx_bra, sites[i].leg_idx_bra)
@@ -63,6 +71,12 @@ def check_against_oracle(C, chi, oc=None, tol=1e-9, elem_tol=1e-7):
 def test_pfaffian_sweep_matches_reference_fixture(name):
     g = load(name)
     oc = int(g["kw_ortho_center"]) if "kw_ortho_center" in g else None
+    if "half" in name:   # exact 1/2 modes: gauge-invariant comparison only (see check_against_oracle)
+        mps = check_against_oracle(g["C"], int(g["chi_max"]), oc, degenerate=True)
+        assert max(len(bd.e) for bd in mps.bonds) >= 3
+        assert any(np.any(np.abs(bd.e - 0.5) < 1e-12) for bd in mps.bonds)
+        assert max(mps.info["checks"].values()) < 1e-8
+        return
     mps = check_against_oracle(g["C"], int(g["chi_max"]), oc)
     L = int(g["L"])
     for b in range(L + 1):
@@ -97,3 +111,20 @@ def test_pfaffian_api_errors():
         pfaffian.C_to_MPS(np.eye(8) * 0.5, {"chi_max": 4}, basis="M", unit_cell_width=3)
     with pytest.raises(AssertionError):
         pfaffian.correlation_matrix(np.eye(4), "Q->M")
+
+
+@pytest.mark.parametrize("L,lefts,chi,seed", [(14, [0], 64, 5), (20, [1], 48, 6)])
+def test_pfaffian_sweep_with_half_modes(L, lefts, chi, seed):
+    """Chains whose end Majoranas are paired across the system: every cut between them carries one
+    exact eigenvalue-1/2 pair (pfaffian.py:803-816) next to generic modes."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_golden_pfaffian import half_mode_majorana_H
+
+    C = porc.correlation_matrix(half_mode_majorana_H(L, lefts, seed))
+    mps = check_against_oracle(C, chi, degenerate=True, tol=1e-8)
+    S = mps.entanglement_entropy(all_bonds=True)
+    cuts, _ = porc.c_to_mps(C, {"chi_max": chi})
+    Sref = np.array([-(c.lam**2 * np.log(c.lam**2)).sum() for c in cuts])
+    assert np.abs(S - Sref).max() < 1e-9
+    assert S[L // 2] > np.log(2) - 1e-9          # at least the shared fermion
