@@ -8,9 +8,12 @@ HBM (the PCIe-inclusive rate is printed as `value_pcie` and discussed in DESIGN.
 
 N = 1  : workload = BASELINE config 3 sizes on one GPU, L=1024, chi_max=512, random complex
          hopping seed 0 (the configuration the metric is quoted on; it fits one GPU).
-N > 1  : the same chain, sites sharded over the ranks (contiguous, cost-balanced ranges);
-         cuts on a shard boundary are recomputed by both neighbours (the kernels are
-         deterministic), so there is no data-path collective.  scaling = "strong".
+N > 1  : conversions are independent objects: every rank converts its own chain of the SAME
+         configuration (seed = rank), no data-path collective; value = N * L / t, scaling = "weak".
+         The same run also times the strong-scaling variant - the seed-0 chain with its sites
+         sharded over the ranks (contiguous, cost-balanced ranges; cuts on a shard boundary are
+         recomputed by both neighbours, the kernels are deterministic) - and reports it as the
+         extra object "strong_scaling" (not the headline value).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task description).
 """
@@ -85,10 +88,15 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    # rehearsal aid for a one-GPU box: all ranks on device 0, gloo for the barrier / max (RCCL refuses two
+    # ranks on one device); the driver's multi-GPU runs never set it
+    same_dev = os.environ.get("TMF_BENCH_SAME_DEVICE") == "1"
+    if same_dev:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if same_dev else "nccl", rank=rank, world_size=world)
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
 
@@ -98,12 +106,12 @@ def main():
     from temfpy_amd.schmidt_utils import to_stopping_condition
 
     L, chi = a.L, a.chi
-    C, N = slater.correlation_matrix(random_hopping(L, 0))  # H -> C is outside the metric
+    # H -> C is outside the metric.  Rank r converts the chain with seed r.
+    C, N = slater.correlation_matrix(random_hopping(L, rank))
     oc = L // 2
     trunc = to_stopping_condition({"chi_max": chi})
     eng = Engine(dev, profile=False)
     d_C = torch.from_numpy(np.ascontiguousarray(C).reshape(-1)).to(dev)
-    rng_sites = shard_sites(L, oc, world)[rank]
 
     def barrier():
         torch.cuda.synchronize()
@@ -113,19 +121,19 @@ def main():
     engines = [eng] + [Engine(dev, profile=False) for _ in range(a.streams - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(a.streams)]
 
-    def step():
+    def convert(d_mat, rng_sites):
         if a.streams == 1:
-            return eng.run(d_C, trunc, oc, L, download=False, site_range=rng_sites if world > 1 else None)
+            return eng.run(d_mat, trunc, oc, L, download=False, site_range=rng_sites)
         # several shards of this rank's range in flight on separate HIP streams: the host phases of
         # one shard (enumeration, descriptors) overlap the kernels of the others
         import threading
-        lo, hi = rng_sites if world > 1 else (0, L)
+        lo, hi = rng_sites if rng_sites is not None else (0, L)
         sub = [(lo + a_ - 0, lo + b_) for a_, b_ in shard_sites(hi - lo, max(min(oc - lo, hi - lo), 0), a.streams)]
         res = [None] * a.streams
 
         def work(j):
             with torch.cuda.stream(streams[j]):
-                res[j] = engines[j].run(d_C, trunc, oc, L, download=False, site_range=sub[j])
+                res[j] = engines[j].run(d_mat, trunc, oc, L, download=False, site_range=sub[j])
                 streams[j].synchronize()
 
         th = [threading.Thread(target=work, args=(j,)) for j in range(a.streams)]
@@ -134,28 +142,44 @@ def main():
         eng.det_events = [e for en in engines for e in en.det_events]
         return res[0]
 
-    for _ in range(a.warmup):
-        step()
-    barrier()
     det_ms, det_flops, det_n = {}, {}, {}
     gemm_ms, gemm_fl = [], []
-    for e_ in engines:
-        e_.time_gemm = True
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        mps = step()
-        torch.cuda.synchronize()
-        for cls, e0, e1, fl, nd in eng.det_events:
-            det_ms.setdefault(cls, []).append(e0.elapsed_time(e1))
-            det_flops[cls], det_n[cls] = fl, nd
-        gemm_ms.append(sum(e0.elapsed_time(e1) for e0, e1, _ in eng.gemm_events))
-        gemm_fl.append(sum(fl for _, _, fl in eng.gemm_events))
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+
+    def timed(step, collect):
+        """W untimed + exactly K timed steps between barrier + synchronize; max over ranks."""
+        for _ in range(a.warmup):
+            step()
+        barrier()
+        for e_ in engines:
+            e_.time_gemm = collect
+        t0 = time.perf_counter()
+        last = None
+        for _ in range(a.steps):
+            last = step()
+            torch.cuda.synchronize()
+            if collect:
+                for cls, e0, e1, fl, nd in eng.det_events:
+                    det_ms.setdefault(cls, []).append(e0.elapsed_time(e1))
+                    det_flops[cls], det_n[cls] = fl, nd
+                gemm_ms.append(sum(e0.elapsed_time(e1) for e0, e1, _ in eng.gemm_events))
+                gemm_fl.append(sum(fl for _, _, fl in eng.gemm_events))
+        barrier()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt_], dtype=torch.float64, device="cpu" if same_dev else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        return dt_, last
+
+    dt, mps = timed(lambda: convert(d_C, None), True)   # headline: one whole chain per rank
+    strong = None
+    if world > 1:                                        # extra: the seed-0 chain, sites sharded over the ranks
+        C0, _ = slater.correlation_matrix(random_hopping(L, 0))
+        d_C0 = torch.from_numpy(np.ascontiguousarray(C0).reshape(-1)).to(dev)
+        my_sites = shard_sites(L, oc, world)[rank]
+        dt_s, _ = timed(lambda: convert(d_C0, my_sites), False)
+        strong = {"value": round(L / (dt_s / a.steps), 2), "unit": "sites/s", "ms_per_step": round(dt_s / a.steps * 1e3, 3),
+                  "workload": f"one L={L} chain (seed 0), sites sharded over {world} ranks, no collective"}
 
     # PCIe-inclusive variant (host C in, host tensors out), N = 1 only, one repetition
     value_pcie = None
@@ -190,22 +214,25 @@ def main():
                                   "achieved": round(float(np.mean(gemm_fl)) / (float(np.mean(gemm_ms)) * 1e-3) / 1e12, 3),
                                   "frac": round(float(np.mean(gemm_fl)) / (float(np.mean(gemm_ms)) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4)}}
         out = {
-            "metric": "sites/sec (Slater->MPS, L=%d chi=%d fp64)" % (L, chi), "value": round(L / (dt / a.steps), 2),
+            "metric": "sites/sec (Slater->MPS, L=%d chi=%d fp64)" % (L, chi), "value": round(world * L / (dt / a.steps), 2),
             "unit": "sites/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "c128 (fp64 complex)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "c128 (fp64 complex)",
             "data": "synthetic",
-            "config": {"workload": f"L={L} random complex hopping (seed 0, range 3) Slater->MPS, chi_max={chi}, "
-                                   f"svd_min=1e-6; sites sharded over {world} rank(s)", "N_fermions": N,
+            "config": {"workload": f"L={L} random complex hopping (range 3) Slater->MPS, chi_max={chi}, svd_min=1e-6; "
+                                   f"{world} rank(s), each converts one whole chain per step (seed = rank)",
+                       "N_fermions": N,
                        "stage_ms": {k: round(v * 1e3, 1) for k, v in mps.timings.items()},
                        "range_finder": {"subspace_iterations": eng.range_iterations_used,
                                         "smallest_captured_sigma": eng.range_floor}},
             "roofline": roof, "value_pcie": None if value_pcie is None else round(value_pcie, 2),
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
         if world == 1 and a.cpu_sample > 0:
             v, sites, S_ref, t_cpu = cpu_baseline(C, chi, L, oc, a.cpu_sample)
             S_hip = full.entanglement_entropy(all_bonds=True)
             dS = max(abs(S_hip[b] - s) for b, s in S_ref.items())
-            out["cpu_baseline"] = {"value": round(v, 3), "unit": "sites/s", "cores": os.cpu_count(), "kind": "port",
+            out["cpu_baseline"] = {"value": round(v, 3), "unit": "sites/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
                                    "sample": f"{len(sites)} of {L} sites evenly spaced along the chain, "
                                              f"{t_cpu:.1f} s of oracle time (NumPy/OpenBLAS threads = all cores)"}
             out["max_abs_dS_vs_oracle"] = float(dS)
