@@ -98,6 +98,14 @@ int tmf_jacobi_batched(int dtype, const tmf_jacobi_desc* d_desc, int nprob, int 
 int tmf_svd_left_batched(int dtype, const tmf_jacobi_desc* d_desc, int nprob, int max_p, int32_t* d_sweeps,
                          void* stream);
 
+/* Block variant of the two entry points above for 64 < p <= 512 (a cut whose entanglement rank
+ * exceeds the 64-column range finder): X and the rotation accumulator stay in global memory, pairs of
+ * column blocks are staged in LDS.  X is DESTROYED.  with_v = 0: desc.U receives the sorted,
+ * normalised left singular vectors (desc.V unused).  with_v = 1: desc.V is a p x p workspace and
+ * desc.U receives the sorted right singular vectors / eigenvectors. */
+int tmf_jacobi_block_batched(int dtype, int with_v, const tmf_jacobi_desc* d_desc, int nprob, int max_p,
+                             int32_t* d_sweeps, void* stream);
+
 /* Blocked LU with partial pivoting restricted to the leading k x k "always" block of
  * W (mb x mk).  Returns det(W[:k,:k]) and leaves the Schur
  * complement W[k:,k:] - W[k:,:k] W[:k,:k]^-1 W[:k,k:] in S.  Replaces det/inv and the two

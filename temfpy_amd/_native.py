@@ -67,7 +67,7 @@ assert colnorm_desc.itemsize == 40 and sector.itemsize == 48 and site_out.itemsi
 
 SYMBOLS = [
     "tmf_last_error", "tmf_version", "tmf_device_count", "tmf_gemm_batched", "tmf_orth_panel_batched",
-    "tmf_jacobi_batched", "tmf_svd_left_batched", "tmf_nested_products_batched", "tmf_recon_error_batched", "tmf_lu_schur_batched", "tmf_det_gather_batched", "tmf_transpose", "tmf_fill_normal",
+    "tmf_jacobi_batched", "tmf_svd_left_batched", "tmf_nested_products_batched", "tmf_recon_error_batched", "tmf_jacobi_block_batched", "tmf_lu_schur_batched", "tmf_det_gather_batched", "tmf_transpose", "tmf_fill_normal",
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_cut_vectors", "tmf_site_prepare",
     "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_column_norms_batched", "tmf_det_reduced_batched", "tmf_pf_gather_batched", "tmf_nambu_assemble_batched",
     "tmf_nambu_w_batched", "tmf_pf_matrix_batched",
@@ -99,6 +99,7 @@ def load():
     lib.tmf_svd_left_batched.argtypes = [i32, vp, i32, i32, vp, vp]
     lib.tmf_nested_products_batched.argtypes = [i32, vp, i32, i32, i32, vp]
     lib.tmf_recon_error_batched.argtypes = [i32, vp, vp, i32, vp]
+    lib.tmf_jacobi_block_batched.argtypes = [i32, i32, vp, i32, i32, vp, vp]
     lib.tmf_lu_schur_batched.argtypes = [i32, vp, i32, i32, vp]
     lib.tmf_det_gather_batched.argtypes = [i32, i32, vp, i32, i32, vp]
     lib.tmf_det_reduced_batched.argtypes = [i32, i32, vp, i32, i32, vp]

@@ -186,3 +186,203 @@ extern "C" int tmf_svd_left_batched(int dtype, const tmf_jacobi_desc* d_desc, in
                                     void* stream) {
   return launch_jacobi<false>(dtype, d_desc, nprob, max_p, d_sweeps, stream, "tmf_svd_left_batched");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Block variant for p > 64: X (and V) stay in global memory (L2), two column blocks of width bw are
+// staged in LDS at a time and swept against each other (block one-sided Jacobi).  One workgroup per
+// problem, no inter-workgroup synchronisation.  Used only when a cut's entanglement rank exceeds
+// what the 64-column range finder resolves (the engine then repeats the stage with 128 or 256
+// columns), so it is built for generality, not speed.
+// X is destroyed; WITH_V: V is the workspace of the accumulated rotations and the sorted right
+// vectors are written to U; otherwise U receives the sorted, normalised left vectors.
+// ---------------------------------------------------------------------------------------------
+namespace tmf {
+
+template <typename T, bool WITH_V>
+__global__ __launch_bounds__(512) void jacobi_block_kernel(const tmf_jacobi_desc* __restrict__ desc, int bw,
+                                                           int32_t* __restrict__ sweeps_out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const tmf_jacobi_desc d = desc[blockIdx.x];
+  const int p = d.p;
+  if (p <= 0) return;
+  const int nc = 2 * bw;                               // columns resident in LDS
+  T* Xs = reinterpret_cast<T*>(smem);                  // Xs[c * p + r], c < nc
+  T* Vs = Xs + (size_t)nc * p;                         // only WITH_V
+  int* flag = reinterpret_cast<int*>(Xs + (WITH_V ? 2 : 1) * (size_t)nc * p);
+  T* __restrict__ Xg = reinterpret_cast<T*>(d.X);
+  T* __restrict__ Vg = reinterpret_cast<T*>(d.V);
+  const int tid = threadIdx.x;
+  if (WITH_V)
+    for (int e = tid; e < p * p; e += 512) {
+      const int r = e % p, c = e / p;
+      Vg[(size_t)r + (size_t)c * d.ldv] = (r == c) ? sc<T>::one() : sc<T>::zero();
+    }
+  if (tid == 0) *flag = 0;
+  __syncthreads();
+
+  const int nb = (p + bw - 1) / bw;
+  const int m = nc - 1, npairs = nc / 2;               // round-robin over nc players
+  int tpp = 64;
+  while (tpp * npairs > 512) tpp >>= 1;
+  const int pair = tid / tpp, pl = tid % tpp;
+  const double tol2 = 1.1e-16 * 1.1e-16 * (double)p;
+
+  int sweep = 0;
+  for (; sweep < 60; ++sweep) {
+    for (int I = 0; I < nb; ++I) {
+      for (int J = (nb == 1 ? 0 : I + 1); J < (nb == 1 ? 1 : nb); ++J) {
+        // global column of LDS column c: block I for c < bw, block J after (J == I: second half unused)
+        auto gcol = [&](int c) { return c < bw ? I * bw + c : (J == I ? p : J * bw + (c - bw)); };
+        for (int e = tid; e < nc * p; e += 512) {
+          const int r = e % p, c = e / p, g = gcol(c);
+          Xs[e] = g < p ? Xg[(size_t)r + (size_t)g * d.ldx] : sc<T>::zero();
+          if (WITH_V) Vs[e] = g < p ? Vg[(size_t)r + (size_t)g * d.ldv] : sc<T>::zero();
+        }
+        __syncthreads();
+        for (int rho = 0; rho < m; ++rho) {
+          if (pair < npairs) {
+            int i, j;
+            if (pair == 0) {
+              i = m;
+              j = rho;
+            } else {
+              i = (rho + pair) % m;
+              j = (rho - pair + m) % m;
+            }
+            if (i > j) {
+              const int t = i;
+              i = j;
+              j = t;
+            }
+            if (gcol(i) < p && gcol(j) < p) {
+              T* xi = Xs + (size_t)i * p;
+              T* xj = Xs + (size_t)j * p;
+              double al = 0.0, be = 0.0;
+              T ga = sc<T>::zero();
+              for (int r = pl; r < p; r += tpp) {
+                const T a = xi[r], b = xj[r];
+                al += sc<T>::abs2(a);
+                be += sc<T>::abs2(b);
+                ga = sc<T>::fmacc(ga, a, b);
+              }
+              for (int o = tpp >> 1; o > 0; o >>= 1) {
+                al += __shfl_xor(al, o, tpp);
+                be += __shfl_xor(be, o, tpp);
+                ga = sc<T>::add(ga, shfl_xor_t<T>(ga, o, tpp));
+              }
+              const double g2 = sc<T>::abs2(ga);
+              if (g2 > tol2 * al * be && g2 > 0.0) {
+                const double g = sqrt(g2);
+                const double zeta = (be - al) / (2.0 * g);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                const T ph = sc<T>::scale(sc<T>::conj(ga), 1.0 / g);
+                const T sph = sc<T>::scale(ph, s), cph = sc<T>::scale(ph, c);
+                for (int r = pl; r < p; r += tpp) {
+                  const T a = xi[r], b = xj[r];
+                  xi[r] = sc<T>::sub(sc<T>::scale(a, c), sc<T>::mul(sph, b));
+                  xj[r] = sc<T>::add(sc<T>::scale(a, s), sc<T>::mul(cph, b));
+                }
+                if (WITH_V) {
+                  T* vi = Vs + (size_t)i * p;
+                  T* vj = Vs + (size_t)j * p;
+                  for (int r = pl; r < p; r += tpp) {
+                    const T a = vi[r], b = vj[r];
+                    vi[r] = sc<T>::sub(sc<T>::scale(a, c), sc<T>::mul(sph, b));
+                    vj[r] = sc<T>::add(sc<T>::scale(a, s), sc<T>::mul(cph, b));
+                  }
+                }
+                if (pl == 0) atomicAdd(flag, 1);
+              }
+            }
+          }
+          __syncthreads();
+        }
+        for (int e = tid; e < nc * p; e += 512) {
+          const int r = e % p, c = e / p, g = gcol(c);
+          if (g < p) {
+            Xg[(size_t)r + (size_t)g * d.ldx] = Xs[e];
+            if (WITH_V) Vg[(size_t)r + (size_t)g * d.ldv] = Vs[e];
+          }
+        }
+        __syncthreads();
+      }
+    }
+    const int rot = *flag;
+    __syncthreads();
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    if (rot == 0) break;
+  }
+  if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sweep;
+
+  // column norms (reusing the LDS image as scratch), rank by descending norm, sorted output
+  double* nrm = reinterpret_cast<double*>(smem);
+  __syncthreads();
+  for (int c = tid; c < p; c += 512) {
+    double s = 0.0;
+    for (int r = 0; r < p; ++r) s += sc<T>::abs2(Xg[(size_t)r + (size_t)c * d.ldx]);
+    nrm[c] = sqrt(s);
+  }
+  __syncthreads();
+  T* __restrict__ Ug = reinterpret_cast<T*>(d.U);
+  double* __restrict__ sg = reinterpret_cast<double*>(d.s);
+  for (int e = tid; e < p * p; e += 512) {
+    const int r = e % p, c = e / p;
+    const double sc_ = nrm[c];
+    int rank = 0;
+    for (int c2 = 0; c2 < p; ++c2) rank += (nrm[c2] > sc_) || (nrm[c2] == sc_ && c2 < c);
+    const bool keep = !(d.thresh2 > 0.0) || sc_ * sc_ >= d.thresh2;
+    T v;
+    if (WITH_V) v = keep ? Vg[(size_t)r + (size_t)c * d.ldv] : sc<T>::zero();
+    else v = sc<T>::scale(Xg[(size_t)r + (size_t)c * d.ldx], (keep && sc_ > 0.0) ? 1.0 / sc_ : 0.0);
+    Ug[(size_t)r + (size_t)rank * d.ldu] = v;
+    if (r == 0) sg[rank] = sc_;
+  }
+  if (tid == 0 && d.count) {
+    int cnt = 0;
+    for (int c = 0; c < p; ++c) cnt += !(d.thresh2 > 0.0) || nrm[c] * nrm[c] >= d.thresh2;
+    *reinterpret_cast<int32_t*>(d.count) = cnt;
+  }
+}
+
+}  // namespace tmf
+
+extern "C" int tmf_jacobi_block_batched(int dtype, int with_v, const tmf_jacobi_desc* d_desc, int nprob, int max_p,
+                                        int32_t* d_sweeps, void* stream) {
+  using namespace tmf;
+  if (nprob <= 0) return TMF_OK;
+  const size_t elem = (dtype == TMF_C128) ? 16 : 8;
+  if (max_p <= 0 || max_p > 512) {
+    set_error("tmf_jacobi_block_batched: p = %d not in 1..512", max_p);
+    return TMF_E_LIMIT;
+  }
+  int bw = 32;  // widest block whose pair (x2 with the rotation accumulator) fits 150 KiB of LDS
+  while (bw > 1 && (size_t)(with_v ? 2 : 1) * 2 * bw * max_p * elem + 64 > 150 * 1024) bw >>= 1;
+  const size_t lds = (size_t)(with_v ? 2 : 1) * 2 * bw * max_p * elem + 64;
+  if (lds > 160 * 1024 || lds < (size_t)max_p * 8) {
+    set_error("tmf_jacobi_block_batched: p = %d does not fit the LDS staging", max_p);
+    return TMF_E_LIMIT;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)jacobi_block_kernel<cd, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)jacobi_block_kernel<cd, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)jacobi_block_kernel<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)jacobi_block_kernel<double, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const dim3 g(nprob), b(512);
+  if (dtype == TMF_C128) {
+    if (with_v) hipLaunchKernelGGL((jacobi_block_kernel<cd, true>), g, b, lds, s, d_desc, bw, d_sweeps);
+    else hipLaunchKernelGGL((jacobi_block_kernel<cd, false>), g, b, lds, s, d_desc, bw, d_sweeps);
+  } else if (dtype == TMF_F64) {
+    if (with_v) hipLaunchKernelGGL((jacobi_block_kernel<double, true>), g, b, lds, s, d_desc, bw, d_sweeps);
+    else hipLaunchKernelGGL((jacobi_block_kernel<double, false>), g, b, lds, s, d_desc, bw, d_sweeps);
+  } else {
+    set_error("tmf_jacobi_block_batched: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+  return check_hip(hipGetLastError(), "tmf_jacobi_block_batched");
+}

@@ -56,6 +56,7 @@ class Engine:
         self.device = torch.device(device)
         self.lib = nat.load()
         self.profile = bool(int(os.environ.get("TMF_PROFILE", "0"))) if profile is None else profile
+        self.range_iterations_used, self.range_width, self.range_floor = 0, P_RANGE, 0.0
         self.checks = True          # evaluate testing.check_schmidt_decomposition's deviations on the device
         self.check_results = {}
         self.timings = {}
@@ -182,18 +183,32 @@ class Engine:
 
     def jacobi(self, X, V, s, count, thresh2, p, ldx, ldv, left_only=False):
         """One-sided Jacobi per problem.  ``left_only``: ``V`` receives the normalised LEFT singular
-        vectors (tmf_svd_left_batched, no rotation accumulator) instead of the right ones."""
+        vectors (tmf_svd_left_batched, no rotation accumulator) instead of the right ones.
+        p > 64: block variant in global memory (tmf_jacobi_block_batched; destroys X)."""
         p = np.asarray(p, np.int64)
         sel = np.nonzero(p > 0)[0]
         if sel.size == 0:
             return
         d = np.zeros(sel.size, nat.jacobi_desc)
-        for f, v in (("X", X), ("U" if left_only else "V", V), ("s", s), ("count", count), ("p", p), ("ldx", ldx),
-                     ("ldu" if left_only else "ldv", ldv)):
+        big = int(p.max()) > 64
+        out_field = "U" if (left_only or big) else "V"
+        for f, v in (("X", X), (out_field, V), ("s", s), ("count", count), ("p", p), ("ldx", ldx),
+                     ("ldu" if out_field == "U" else "ldv", ldv)):
             d[f] = np.broadcast_to(np.asarray(v), p.shape)[sel]
         d["thresh2"] = thresh2
-        if not left_only:
+        if out_field == "V":
             d["ldu"] = 1
+        if big:
+            if not left_only:   # workspace for the accumulated rotations
+                pp = p[sel]
+                wo = np.concatenate(([0], np.cumsum(pp * pp)))
+                d_ws = self._alloc(int(wo[-1]))
+                self._keep.append(d_ws)
+                d["V"], d["ldv"] = d_ws.data_ptr() + wo[:-1] * self.elem, pp
+            dd = self._up(d)
+            nat.check(self.lib.tmf_jacobi_block_batched(self.dtype, 0 if left_only else 1, dd.data_ptr(), sel.size,
+                                                        int(p.max()), None, self.stream), "tmf_jacobi_block_batched")
+            return
         dd = self._up(d)
         fn = self.lib.tmf_svd_left_batched if left_only else self.lib.tmf_jacobi_batched
         d_sw = None
@@ -374,54 +389,61 @@ class Engine:
         return out
 
     def _finish(self, mps):
-        mps.info = {"range_finder_iterations": self.range_iterations_used,
+        mps.info = {"range_finder_iterations": self.range_iterations_used, "range_finder_columns": self.range_width,
                     "range_finder_smallest_sigma": self.range_floor,
                     "checks": dict(getattr(self, "check_results", {}))}
         return mps
 
-    def entangled_stage_adaptive(self, L, n, m, blk, off, omp, doE, p, thr2, P, cs_b, nest=None):
-        """Runs the entangled stage; if for some cut the smallest singular value s_P captured by the
-        P-column range finder exceeds ``self.range_floor_tol``, repeats it with one round of subspace
-        iteration and then applies the (cubed-ratio) adequacy check.
+    range_ladder = (P_RANGE, 128, 256)   # widths of the range finder tried in turn
 
-        Why an absolute tolerance: a direction with singular value s_i is found with angle error
-        ~ s_P / s_i, and enters the state with weight ~ s_i, so the state error is ~ s_P for every
-        direction.  1e-11 keeps it two orders below the 1e-9 parity tolerance on Schmidt values
-        (measured on the L=1024 headline case: s_P = 1.6e-13, |dS| vs oracle 1e-12).  The Nambu
-        engine overrides the tolerance with the rounding floor because its pairing construction
-        (filled = conj(empty)) needs the orbitals themselves, not only the state, to be accurate.
-        Returns the stage dict plus host copies."""
-        st = self.entangled_stage(L, n, m, blk, off, omp, doE, p, thr2, P, iterations=0, nest=nest)
-        h_sig, oS = st["d_sig"].cpu().numpy(), st["oS"]
-        full = doE & (p == P) & (P < np.minimum(n, m))
-        worst = max((h_sig[oS[i] + P - 1] for i in np.nonzero(full)[0]), default=0.0)
-        self.range_floor = float(worst)
-        st["range_iterations"] = 0
-        if worst > self.range_floor_tol:
-            st = self.entangled_stage(L, n, m, blk, off, omp, doE, p, thr2, P, iterations=1, nest=nest)
-            h_sig = st["d_sig"].cpu().numpy()
-            st["range_iterations"] = 1
-            self.check_range_finder(h_sig, st["oS"], p, P, n, m, doE, thr2, cs_b)
-        st["h_e"], st["h_cnt"] = st["d_e"].cpu().numpy(), st["d_cnt"].cpu().numpy()
-        self.range_iterations_used = st["range_iterations"]
-        return st
+    def entangled_stage_adaptive(self, L, n, m, blk, off, doE, thr2, cs_b, x, side, Cp):
+        """Runs the entangled stage with the narrowest adequate range finder.
 
-    @staticmethod
-    def check_range_finder(h_sig, oS, p, P, n, m, doE, thr2, cs_b):
-        """The randomised range finder has p <= P columns.  When p < min(n, m) its accuracy for a
-        direction with singular value s is ~ s_(p+1) / s, so the weakest captured singular value must
-        lie far below the threshold sqrt(thr2) (here: a factor 1e3); otherwise the entanglement rank of
-        the cut exceeds what the P-column range finder / LDS Jacobi kernel resolve and we refuse to
-        return degraded orbitals."""
-        for i in np.nonzero(doE & (p == P) & (P < np.minimum(n, m)))[0]:
-            s_last = h_sig[oS[i] + P - 1]
-            # with one subspace iteration the error of the weakest kept direction is
-            # ~ (s_last / sqrt(thr2))^3; demand <= 1e-10
-            if s_last > 4.6e-4 * thr2**0.5:
-                raise NotImplementedError(
-                    f"cut {cs_b[i]}: entanglement rank too large for the {P}-column range finder "
-                    f"(smallest captured singular value {s_last:.1e} vs threshold {thr2 ** 0.5:.1e}); "
-                    f"a wider range finder needs the global-memory Jacobi variant")
+        Adequacy is CHECKED, not assumed.  A direction with singular value s_i is found with angle error
+        ~ s_P / s_i (s_P: smallest singular value captured by the P columns) and enters the state with
+        weight ~ s_i, so the state error is ~ s_P for every direction.  If s_P exceeds
+        ``self.range_floor_tol`` (1e-11: two orders below the 1e-9 parity tolerance on Schmidt values;
+        measured on the L=1024 headline case: s_P = 1.6e-13, |dS| vs oracle 1e-12; the Nambu engine
+        uses the rounding floor because its pairing construction needs the orbitals themselves) the
+        stage is repeated with one round of subspace iteration, which cubes the ratio.  If that is
+        still not enough, or a cut has P or more directions above the threshold, the next width of
+        ``range_ladder`` is tried (p > 64 runs the block Jacobi kernels in global memory); beyond the
+        ladder the call raises instead of returning degraded orbitals.
+        x, side: cut positions in matrix indices and block side; Cp: the column-major matrix.
+        Returns the stage dict plus P, p and host copies of the Ritz values / counts."""
+        el = self.elem
+        reason = ""
+        for P in self.range_ladder:
+            d_Om = self._alloc(L * P)
+            nat.check(self.lib.tmf_fill_normal(self.dtype, d_Om.data_ptr(), L * P, 0x5EED1, self.stream), "fill")
+            omp = d_Om.data_ptr() + np.where(side == 0, x, 0) * el      # rows of Omega on the other side
+            p = np.where(doE, np.minimum(P, np.minimum(n, m)), 0)
+            nest = (x, side, Cp, d_Om.data_ptr())
+            full = doE & (p == P) & (P < np.minimum(n, m))              # cuts the range finder truncates
+            st = self.entangled_stage(L, n, m, blk, off, omp, doE, p, thr2, P, iterations=0, nest=nest)
+            h_sig, oS = st["d_sig"].cpu().numpy(), st["oS"]
+            worst = max((h_sig[oS[i] + P - 1] for i in np.nonzero(full)[0]), default=0.0)
+            self.range_floor = float(worst)
+            its = 0
+            if worst > self.range_floor_tol:
+                st = self.entangled_stage(L, n, m, blk, off, omp, doE, p, thr2, P, iterations=1, nest=nest)
+                its = 1
+                h_sig, oS = st["d_sig"].cpu().numpy(), st["oS"]
+                bad = [i for i in np.nonzero(full)[0] if h_sig[oS[i] + P - 1] > 4.6e-4 * thr2**0.5]
+                if bad:   # (s_P / sqrt(thr2))^3 > 1e-10 even after the iteration
+                    reason = (f"cut {cs_b[bad[0]]}: smallest captured singular value "
+                              f"{h_sig[oS[bad[0]] + P - 1]:.1e} vs threshold {thr2 ** 0.5:.1e} with {P} columns")
+                    continue
+            h_cnt = st["d_cnt"].cpu().numpy()
+            sat = np.nonzero(full & (h_cnt >= p))[0]
+            if sat.size:
+                reason = f"cut {cs_b[sat[0]]}: {P} or more orbitals above the range-finder threshold"
+                continue
+            st.update(P=P, p=p, d_Om=d_Om, range_iterations=its, h_e=st["d_e"].cpu().numpy(), h_cnt=h_cnt)
+            self.range_iterations_used, self.range_width = its, P
+            return st
+        raise NotImplementedError(f"entanglement rank beyond the widest range finder ({self.range_ladder[-1]} "
+                                  f"columns): {reason}")
 
     # ------------------------------------------------------------------ the sweep
     def run(self, C, trunc, ortho_center, unit_cell_width, threads=None, download=True, site_range=None):
@@ -465,9 +487,6 @@ class Engine:
         d_C = self._alloc(L * L)
         nat.check(self.lib.tmf_transpose(self.dtype, d_Crm.data_ptr(), d_C.data_ptr(), L, self.stream), "tmf_transpose")
         Cp = d_C.data_ptr()
-        P = P_RANGE
-        d_Om = self._alloc(L * P)
-        nat.check(self.lib.tmf_fill_normal(self.dtype, d_Om.data_ptr(), L * P, 0x5EED1, self.stream), "fill")
         self._tick("upload", t0)
 
         # ---- cut-side problems --------------------------------------------------------------
@@ -488,7 +507,6 @@ class Engine:
         m = L - n
         blk = Cp + np.where(cs_side == 0, 0, (cs_b + cs_b * L)) * el      # A = C_LL or C_RR
         off = Cp + np.where(cs_side == 0, cs_b * L, cs_b) * el            # F (n x m)
-        omp = d_Om.data_ptr() + np.where(cs_side == 0, cs_b, 0) * el      # rows of Omega on the other side
         has_centre = (oc, 0) in need
         centre_R = np.nonzero((cs_b == oc) & (cs_side == 1))[0][0] if has_centre else -1
         centre_L = np.nonzero((cs_b == oc) & (cs_side == 0))[0][0] if has_centre else -1
@@ -496,15 +514,14 @@ class Engine:
         doE = (n > 0) & (m > 0)
         if has_centre:
             doE[centre_R] = False
-        p = np.where(doE, np.minimum(P, np.minimum(n, m)), 0)
 
         def offsets(sizes):
             o = np.concatenate(([0], np.cumsum(sizes)))
             return o[:-1], int(o[-1])
 
         t0 = time.perf_counter()
-        st = self.entangled_stage_adaptive(L, n, m, blk, off, omp, doE, p, thr2, P, cs_b,
-                                           nest=(cs_b, cs_side, Cp, d_Om.data_ptr()))
+        st = self.entangled_stage_adaptive(L, n, m, blk, off, doE, thr2, cs_b, cs_b, cs_side, Cp)
+        P, p = st["P"], st["p"]
         UEp, oS, ld1 = st["UEp"], st["oS"], st["ld1"]
         self._tick("E_entangled", t0)
 
@@ -518,11 +535,6 @@ class Engine:
         colP = np.arange(P)
         valid = colP[None, :] < h_cnt[:, None]
         E2 = np.where(valid, h_e[np.minimum(oS[:, None] + colP[None, :], max(len(h_e) - 1, 0))], 0.0)
-        sat = doE & (h_cnt >= p) & (p == P) & (P < np.minimum(n, m))
-        if np.any(sat):
-            raise NotImplementedError(
-                f"cut {cs_b[np.nonzero(sat)[0][0]]}: more than {P - 1} orbitals above the range-finder threshold; "
-                f"entanglement rank beyond the compiled limit of the LDS Jacobi kernel")
         x_hi = np.sum(valid & (E2 >= 1 - cutoff), axis=1)   # kept but 'filled' by slater.py:350
         x_lo = np.sum(valid & (E2 < cutoff), axis=1)
         ent0 = np.where(doE, x_hi, 0)                        # first entangled column inside U_E

@@ -144,9 +144,6 @@ class PfEngine(Engine):
         d_C = self._alloc(D * D)
         nat.check(self.lib.tmf_transpose(self.dtype, d_Crm.data_ptr(), d_C.data_ptr(), D, self.stream), "transpose")
         Cp = d_C.data_ptr()
-        P = P_RANGE
-        d_Om = self._alloc(D * P)
-        nat.check(self.lib.tmf_fill_normal(self.dtype, d_Om.data_ptr(), D * P, 0x5EED2, self.stream), "fill")
         self._tick("upload", t0)
 
         # ---- cut sides ----------------------------------------------------------------------------
@@ -163,16 +160,14 @@ class PfEngine(Engine):
         m = D - n
         blk = Cp + np.where(cs_side == 0, 0, 2 * cs_b + 2 * cs_b * D) * el
         off = Cp + np.where(cs_side == 0, 2 * cs_b * D, 2 * cs_b) * el
-        omp = d_Om.data_ptr() + np.where(cs_side == 0, 2 * cs_b, 0) * el
         cidx = {(int(b), int(s_)): i for i, (b, s_) in enumerate(zip(cs_b, cs_side))}
         centre_L, centre_R = cidx[(oc, 0)], cidx[(oc, 1)]
         doE = (n > 0) & (m > 0)
         doE[centre_R] = False
-        p = np.where(doE, np.minimum(P, np.minimum(n, m)), 0)
 
         t0 = time.perf_counter()
-        st = self.entangled_stage_adaptive(D, n, m, blk, off, omp, doE, p, thr2, P, cs_b,
-                                           nest=(2 * cs_b, cs_side, Cp, d_Om.data_ptr()))
+        st = self.entangled_stage_adaptive(D, n, m, blk, off, doE, thr2, cs_b, 2 * cs_b, cs_side, Cp)
+        P, p = st["P"], st["p"]
         UEp, oS, ld1 = st["UEp"], st["oS"], st["ld1"]
         self._tick("E_entangled", t0)
 
@@ -187,8 +182,6 @@ class PfEngine(Engine):
             if not doE[i]:
                 continue
             cnt = int(h_cnt[i])
-            if cnt >= p[i] and p[i] == P and P < min(n[i], m[i]):
-                raise NotImplementedError(f"cut {cs_b[i]}: more than {P // 2 - 1} entangled pairs (LDS Jacobi limit)")
             lam = h_e[oS[i]: oS[i] + cnt]
             if cnt % 2 or np.abs(lam + lam[::-1] - 1.0).max(initial=0.0) > 1e-8:
                 raise ValueError("Eigenvalues break Nambu symmetry")  # pfaffian.py:799-800

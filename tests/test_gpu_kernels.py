@@ -544,3 +544,44 @@ def test_recon_error_kernel(eng, cplx):
     got = eng.recon_errors(items).cpu().numpy()
     np.testing.assert_allclose(got[:-1], refs, rtol=1e-12)
     assert np.isinf(got[-1])
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("left_only", [True, False])
+def test_jacobi_block_variant_beyond_64(eng, cplx, left_only):
+    """tmf_jacobi_block_batched (p > 64: X and V in global memory, column blocks staged in LDS) against
+    NumPy: singular values, orthonormal vectors, reconstruction; mixed sizes in one launch."""
+    setup(eng, cplx)
+    rng = np.random.default_rng(21)
+    ps = [65, 96, 7, 130]
+    Xs = []
+    for p in ps:
+        if left_only:   # graded lower-triangular factor, as in the sweep
+            sv = np.logspace(-0.3, -12, p)
+            B = (np.linalg.qr(rnd(rng, (2 * p, p), cplx))[0] * sv) @ np.linalg.qr(rnd(rng, (p, p), cplx))[0]
+            Xs.append(np.ascontiguousarray(np.linalg.qr(B)[1].conj().T))
+        else:           # Hermitian positive semi-definite, eigenvalues in [0, 1]
+            Q = np.linalg.qr(rnd(rng, (p, p), cplx))[0]
+            Xs.append((Q * rng.random(p)) @ Q.conj().T)
+    dX = [dev(eng, x) for x in Xs]
+    dO = [dev(eng, np.zeros_like(x)) for x in Xs]
+    ds = [torch.zeros(p, dtype=torch.float64, device="cuda:0") for p in ps]
+    dc = torch.zeros(len(ps), dtype=torch.int32, device="cuda:0")
+    thr2 = 1e-18 if left_only else 0.0
+    eng.jacobi([d[1] for d in dX], [d[1] for d in dO], [s.data_ptr() for s in ds],
+               dc.data_ptr() + 4 * np.arange(len(ps)), thr2, ps, ps, ps, left_only=left_only)
+    torch.cuda.synchronize()
+    for p, X, do, s_ in zip(ps, Xs, dO, ds):
+        Out, s = back(do[0], (p, p)), s_.cpu().numpy()
+        sref = np.linalg.svd(X, compute_uv=False)
+        if left_only:
+            c = int(np.sum(sref**2 >= thr2))
+            np.testing.assert_allclose(s[:c], sref[:c], rtol=1e-8)
+            U = Out[:, :c]
+            np.testing.assert_allclose(U.conj().T @ U, np.eye(c), atol=1e-11)
+            Ur = np.linalg.svd(X)[0][:, :c]
+            np.testing.assert_allclose(np.abs(np.einsum("ij,ij->j", Ur.conj(), U)), 1.0, atol=1e-8)
+        else:
+            np.testing.assert_allclose(s, sref, rtol=0, atol=1e-13)
+            np.testing.assert_allclose(Out.conj().T @ Out, np.eye(p), atol=1e-12)
+            np.testing.assert_allclose((Out * s) @ Out.conj().T, X, atol=1e-12)

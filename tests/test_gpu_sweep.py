@@ -348,3 +348,38 @@ def test_self_check_deviations_match_the_reference():
         warned = sorted({str(w.message).strip().split("\n")[0] for w in rec
                          if isinstance(w.message, testing.ComparisonWarning)})
         assert warned == case["warned"], (warned, case["warned"])
+
+
+def test_entanglement_rank_beyond_64_uses_the_wider_range_finder():
+    """A dense random Hamiltonian (volume-law ground state): every orbital of the centre blocks is
+    entangled (rank 80 > 64 columns), so the sweep falls back to the 128-column range finder and the
+    block Jacobi kernels; parity with the oracle as everywhere else.  With the ladder cut short the
+    call must refuse (NotImplementedError) instead of returning degraded orbitals."""
+    from temfpy_amd import slater
+    from temfpy_amd.slater import _engine
+
+    rng = np.random.default_rng(12)
+    L, chi = 160, 48
+    M = rng.standard_normal((L, L)) + 1j * rng.standard_normal((L, L))
+    C, N = slater.correlation_matrix(M + M.conj().T)
+    mps = run_hip(C, chi)
+    assert mps.info["range_finder_columns"] == 128
+    assert max(len(b.e) for b in mps.bonds) > 64
+    cuts, sites = orc.c_to_mps(C, {"chi_max": chi})
+    for b in range(L + 1):
+        np.testing.assert_allclose(mps.bonds[b].e, cuts[b].e, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(mps.lam[b], cuts[b].lam, rtol=0, atol=1e-9)
+    S = mps.entanglement_entropy(all_bonds=True)
+    Sref = np.array([-(c.lam**2 * np.log(c.lam**2)).sum() for c in cuts])
+    assert np.abs(S - Sref).max() < 1e-10
+    assert abs(1 - overlap(cuts, sites, mps, L // 2)) < 1e-9
+    assert max(mps.info["checks"].values()) < 1e-10
+
+    eng = _engine("cuda:0")
+    old = eng.range_ladder
+    try:
+        eng.range_ladder = (64,)
+        with pytest.raises(NotImplementedError, match="entanglement rank"):
+            run_hip(C, chi)
+    finally:
+        eng.range_ladder = old
