@@ -383,3 +383,56 @@ def test_entanglement_rank_beyond_64_uses_the_wider_range_finder():
             run_hip(C, chi)
     finally:
         eng.range_ladder = old
+
+
+def test_config3_full_size_against_oracle_samples():
+    """BASELINE config 3 at FULL size (L=1024, chi=512, the benchmark workload): the oracle is too slow
+    for all 1024 sites (~5 min), so six sites spread over the chain - including both neighbours of the
+    centre - are recomputed with it and compared like the small cases: occupation patterns exactly,
+    e <= 1e-13, lambda <= 1e-9, S <= 1e-10, |tensor blocks| <= 1e-5 max and 1e-6 in the Frobenius norm
+    (see the comment at the assertion).  Plus size-independent
+    properties on every bond: normalisation, charge bookkeeping, chi profile."""
+    from tests_inputs import random_hopping
+    from temfpy_amd import slater
+
+    L, chi = 1024, 512
+    C, N = slater.correlation_matrix(random_hopping(L, 0))
+    oc = L // 2
+    mps = run_hip(C, chi)
+    assert max(mps.chi) == chi and mps.chi[0] == 1 and mps.chi[-1] == 1
+    for b in range(L + 1):
+        bd = mps.bonds[b]
+        assert abs((bd.lam**2).sum() - 1) < 1e-12
+        assert np.all(bd.q_left == bd.n_filled_left + bd.sets.sum(axis=1))
+        assert bd.n_filled_left + bd.n_filled_right + len(bd.e) == N
+    trunc = orc.as_trunc({"chi_max": chi})
+    for i in (0, 200, oc - 1, oc, 700, L - 1):
+        if i >= oc:
+            bra = orc.cut_vectors(C, i + 1, trunc, "R")
+            ket = orc.cut_vectors(C, i, trunc, "R" if i > oc else "LR")
+            site = orc.site_tensor(bra, ket, "right")
+        else:
+            bra = orc.cut_vectors(C, i, trunc, "L")
+            ket = orc.cut_vectors(C, i + 1, trunc, "L" if i + 1 < oc else "LR")
+            site = orc.site_tensor(bra, ket, "left")
+        for c in (bra, ket):
+            bd = mps.bonds[c.x]
+            np.testing.assert_array_equal(bd.sets, c.sets)
+            np.testing.assert_allclose(bd.e, c.e, rtol=0, atol=1e-13)
+            np.testing.assert_allclose(bd.lam, c.lam, rtol=0, atol=1e-9)
+            p1, p2 = bd.lam**2, c.lam**2
+            assert abs((p1 * np.log(p1)).sum() - (p2 * np.log(p2)).sum()) < 1e-10
+        s = mps.sites[i]
+        assert sorted(b[0] for b in s.blocks) == sorted(site.blocks)
+        num = den = 0.0
+        for q, r0, r1, c0, c1, blk in s.blocks:
+            ref = site.blocks[q][4]
+            assert blk.shape == ref.shape and (r0, r1, c0, c1) == tuple(site.blocks[q][:4])
+            # At this size every bulk cut has eigenvalues within 0.03-0.3 decades of the 1e-12 cutoff whose
+            # eigenvectors LAPACK itself resolves only to eps / gap ~ 1e-3; entries change at second order
+            # in that mixing (measured with tools/diag_full_size.py: <= 3.2e-6 elementwise, 2.2e-7 in the
+            # Frobenius norm, on every bulk site alike).  The bounds below leave a factor ~3.
+            np.testing.assert_allclose(np.abs(blk), np.abs(ref), rtol=0, atol=1e-5 * max(1.0, np.abs(ref).max()))
+            num += ((np.abs(blk) - np.abs(ref)) ** 2).sum()
+            den += (np.abs(ref) ** 2).sum()
+        assert np.sqrt(num / den) < 1e-6
