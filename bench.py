@@ -80,6 +80,10 @@ def main():
     ap.add_argument("--chi", type=int, default=512)
     ap.add_argument("--cpu-sample", type=int, default=40, help="sites timed with the CPU oracle (0 = skip)")
     ap.add_argument("--streams", type=int, default=1, help="shards converted concurrently on one GPU (HIP streams)")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="site ranges of one conversion interleaved by cooperative scheduling (engine.run_pipelined); "
+                         "measured slower than 1 (81 ms vs 69 ms for 2 ranges: the batched kernels lose efficiency on half "
+                         "batches), kept as an experiment switch")
     a = ap.parse_args()
 
     import torch
@@ -102,7 +106,7 @@ def main():
 
     from tests_inputs import random_hopping
     from temfpy_amd import slater
-    from temfpy_amd.engine import Engine
+    from temfpy_amd.engine import Engine, run_pipelined
     from temfpy_amd.schmidt_utils import to_stopping_condition
 
     L, chi = a.L, a.chi
@@ -121,7 +125,17 @@ def main():
     engines = [eng] + [Engine(dev, profile=False) for _ in range(a.streams - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(a.streams)]
 
+    pipe_engines = [eng] + [Engine(dev, profile=False) for _ in range(a.pipeline - 1)]
+
     def convert(d_mat, rng_sites):
+        if a.streams == 1 and a.pipeline > 1:
+            lo, hi = rng_sites if rng_sites is not None else (0, L)
+            sub = [(lo + a_, lo + b_) for a_, b_ in shard_sites(hi - lo, max(min(oc - lo, hi - lo), 0), a.pipeline)]
+            sub = [r for r in sub if r[1] > r[0]]
+            res = run_pipelined(pipe_engines[: len(sub)], d_mat, trunc, oc, L, sub, download=False)
+            eng.det_events = [e for en in pipe_engines[: len(sub)] for e in en.det_events]
+            eng.gemm_events = [e for en in pipe_engines[: len(sub)] for e in en.gemm_events]
+            return res[0]
         if a.streams == 1:
             return eng.run(d_mat, trunc, oc, L, download=False, site_range=rng_sites)
         # several shards of this rank's range in flight on separate HIP streams: the host phases of
@@ -150,7 +164,7 @@ def main():
         for _ in range(a.warmup):
             step()
         barrier()
-        for e_ in engines:
+        for e_ in engines + pipe_engines:
             e_.time_gemm = collect
         t0 = time.perf_counter()
         last = None

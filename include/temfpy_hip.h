@@ -74,6 +74,21 @@ typedef struct {
 int tmf_orth_panel_batched(int dtype, const tmf_panel_desc* d_desc, int nprob, int max_n, int max_w,
                            void* stream);
 
+/* Blocked Gram-Schmidt QR of many slabs in one call (the loop over panels runs in C++; the GEMM and
+ * panel descriptors of every step are built on the device from these records): orthonormalises the
+ * columns [c_begin, c_end) of each slab against all columns before them, `passes` projections per
+ * panel (2: well-conditioned slabs, 3: numerically rank-deficient range-finder slabs).
+ * scratch: c_end x 16 elements per slab; norms: 0 or the raw column norms of [c_begin, c_end)
+ * (tmf_column_norms_batched), see tmf_orth_panel_batched.  h_desc is a host copy of d_desc.
+ * d_work: device scratch of at least tmf_bcgs_work_bytes(h_desc, nprob) bytes. */
+typedef struct {
+  uint64_t base, scratch, norms;
+  int32_t rows, ld, c_begin, c_end;
+} tmf_bcgs_desc;             /* 40 bytes */
+int64_t tmf_bcgs_work_bytes(const tmf_bcgs_desc* h_desc, int nprob);
+int tmf_bcgs_batched(int dtype, const tmf_bcgs_desc* d_desc, const tmf_bcgs_desc* h_desc, int nprob, int passes,
+                     void* d_work, int64_t work_bytes, void* stream);
+
 /* One-sided (Hestenes) Jacobi on a p x p matrix X held in LDS: X V = U diag(s).
  * Outputs s (descending) and V (columns permuted accordingly); optionally U.
  * p <= 64.  Used for the small SVD / Hermitian eigenproblems that replace

@@ -27,6 +27,9 @@ recon_desc = np.dtype([("T", "<u8"), ("X", "<u8"), ("Y", "<u8"), ("w", "<u8"), (
                        ("cols", "<i4"), ("q", "<i4"), ("inner", "<i4"), ("ldt", "<i4"), ("ldx", "<i4"), ("ldy", "<i4"),
                        ("mode", "<i4"), ("y_reverse", "<i4"), ("pad", "<i4")])
 assert recon_desc.itemsize == 80
+bcgs_desc = np.dtype([("base", "<u8"), ("scratch", "<u8"), ("norms", "<u8"), ("rows", "<i4"), ("ld", "<i4"),
+                      ("c_begin", "<i4"), ("c_end", "<i4")])
+assert bcgs_desc.itemsize == 40
 norms_desc = np.dtype([("src", "<u8"), ("out", "<u8"), ("n", "<i4"), ("c", "<i4"), ("lds_", "<i4"), ("pad", "<i4")])
 jacobi_desc = np.dtype([("X", "<u8"), ("V", "<u8"), ("U", "<u8"), ("s", "<u8"), ("count", "<u8"),
                         ("thresh2", "<f8"), ("p", "<i4"), ("ldx", "<i4"), ("ldv", "<i4"), ("ldu", "<i4")])
@@ -67,10 +70,12 @@ assert colnorm_desc.itemsize == 40 and sector.itemsize == 48 and site_out.itemsi
 
 SYMBOLS = [
     "tmf_last_error", "tmf_version", "tmf_device_count", "tmf_gemm_batched", "tmf_orth_panel_batched",
-    "tmf_jacobi_batched", "tmf_svd_left_batched", "tmf_nested_products_batched", "tmf_recon_error_batched", "tmf_jacobi_block_batched", "tmf_lu_schur_batched", "tmf_det_gather_batched", "tmf_transpose", "tmf_fill_normal",
-    "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_cut_vectors", "tmf_site_prepare",
-    "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_column_norms_batched", "tmf_det_reduced_batched", "tmf_pf_gather_batched", "tmf_nambu_assemble_batched",
-    "tmf_nambu_w_batched", "tmf_pf_matrix_batched",
+    "tmf_bcgs_work_bytes", "tmf_bcgs_batched", "tmf_jacobi_batched", "tmf_svd_left_batched",
+    "tmf_jacobi_block_batched", "tmf_nested_products_batched", "tmf_recon_error_batched", "tmf_lu_schur_batched",
+    "tmf_det_gather_batched", "tmf_det_reduced_batched", "tmf_transpose", "tmf_fill_normal",
+    "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_column_norms_batched", "tmf_cut_vectors",
+    "tmf_site_prepare", "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_pf_gather_batched",
+    "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched",
 ]
 
 
@@ -100,6 +105,9 @@ def load():
     lib.tmf_nested_products_batched.argtypes = [i32, vp, i32, i32, i32, vp]
     lib.tmf_recon_error_batched.argtypes = [i32, vp, vp, i32, vp]
     lib.tmf_jacobi_block_batched.argtypes = [i32, i32, vp, i32, i32, vp, vp]
+    lib.tmf_bcgs_work_bytes.argtypes = [vp, i32]
+    lib.tmf_bcgs_work_bytes.restype = i64
+    lib.tmf_bcgs_batched.argtypes = [i32, vp, vp, i32, i32, vp, i64, vp]
     lib.tmf_lu_schur_batched.argtypes = [i32, vp, i32, i32, vp]
     lib.tmf_det_gather_batched.argtypes = [i32, i32, vp, i32, i32, vp]
     lib.tmf_det_reduced_batched.argtypes = [i32, i32, vp, i32, i32, vp]

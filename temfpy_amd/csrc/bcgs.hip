@@ -1,0 +1,135 @@
+// Blocked classical Gram-Schmidt (BCGS with re-orthogonalisation) of many slabs, driven from C++.
+//
+// Orthonormalises the columns [c_begin, c_end) of every slab against all columns before them, panel
+// by panel: per panel and pass two MFMA GEMMs (coefficients Q^H P, update P -= Q c) and then the LDS
+// panel kernel (orth_panel.hip).  It is the QR of the range-finder slabs and of the filled-orbital
+// bases that replace numpy.linalg.eigh (slater.py:347).
+//
+// The descriptors and tile tables of every step are BUILT ON THE DEVICE from one small per-slab
+// record (a 256-thread kernel: pointer arithmetic + a block scan for the tile offsets), so a whole QR
+// needs a single descriptor upload and ~8 launches per panel from this loop - the Python driver
+// spent 0.15 ms per GEMM on building and uploading them (154 GEMMs per conversion, measured).
+#include "common.hpp"
+
+namespace tmf {
+
+__global__ __launch_bounds__(256) void bcgs_prepare_kernel(const tmf_bcgs_desc* __restrict__ desc, int nprob, int t,
+                                                           int w, size_t elem, tmf_gemm_desc* __restrict__ g_coef,
+                                                           tmf_gemm_desc* __restrict__ g_upd,
+                                                           tmf_panel_desc* __restrict__ pd, int32_t* __restrict__ tiles_coef,
+                                                           int32_t* __restrict__ tiles_upd) {
+  __shared__ int scan_c[257], scan_u[257];
+  const int tid = threadIdx.x;
+  const int per = (nprob + 255) / 256;
+  const int i0 = tid * per, i1 = min(nprob, i0 + per);
+  int nc = 0, nu = 0;
+  for (int i = i0; i < i1; ++i) {
+    const tmf_bcgs_desc d = desc[i];
+    const int span = d.c_end - d.c_begin;
+    const bool act = span > t && d.rows > 0;
+    const int j = d.c_begin + t;                       // columns already orthonormal
+    const int wj = act ? min(w, d.c_end - j) : 0;
+    const uint64_t colp = d.base + (uint64_t)j * d.ld * elem;
+    tmf_gemm_desc c, u;
+    c.A = d.base, c.B = colp, c.C = d.scratch;          // coefficients (j x wj) = Q^H P
+    c.M = act ? j : 0, c.N = wj, c.K = d.rows, c.lda = d.ld, c.ldb = d.ld, c.ldc = j > 1 ? j : 1;
+    u.A = d.base, u.B = d.scratch, u.C = colp;          // P -= Q c
+    u.M = act ? d.rows : 0, u.N = (act && j > 0) ? wj : 0, u.K = j, u.lda = d.ld, u.ldb = j > 1 ? j : 1, u.ldc = d.ld;
+    if (j == 0) c.N = 0;                                // first panel: nothing to project against
+    g_coef[i] = c, g_upd[i] = u;
+    tmf_panel_desc p;
+    p.A = colp, p.norms = d.norms ? d.norms + 8ull * t : 0ull, p.n = act ? d.rows : 0, p.w = wj, p.lda = d.ld, p.pad = 0;
+    pd[i] = p;
+    nc += (c.M > 0 && c.N > 0) ? (c.M + 63) / 64 : 0;   // 16-wide tiles: one tile column
+    nu += (u.M > 0 && u.N > 0) ? (u.M + 63) / 64 : 0;
+  }
+  scan_c[tid + 1] = nc, scan_u[tid + 1] = nu;
+  if (tid == 0) scan_c[0] = scan_u[0] = 0;
+  __syncthreads();
+  if (tid == 0)
+    for (int k = 1; k <= 256; ++k) scan_c[k] += scan_c[k - 1], scan_u[k] += scan_u[k - 1];
+  __syncthreads();
+  int oc = scan_c[tid], ou = scan_u[tid];
+  for (int i = i0; i < i1; ++i) {
+    const tmf_gemm_desc c = g_coef[i], u = g_upd[i];
+    if (c.M > 0 && c.N > 0)
+      for (int m = 0; m < (c.M + 63) / 64; ++m, ++oc) {
+        tiles_coef[4 * oc] = i, tiles_coef[4 * oc + 1] = m, tiles_coef[4 * oc + 2] = 0, tiles_coef[4 * oc + 3] = 0;
+      }
+    if (u.M > 0 && u.N > 0)
+      for (int m = 0; m < (u.M + 63) / 64; ++m, ++ou) {
+        tiles_upd[4 * ou] = i, tiles_upd[4 * ou + 1] = m, tiles_upd[4 * ou + 2] = 0, tiles_upd[4 * ou + 3] = 0;
+      }
+  }
+}
+
+}  // namespace tmf
+
+extern "C" int64_t tmf_bcgs_work_bytes(const tmf_bcgs_desc* h_desc, int nprob) {
+  int64_t tc = 0, tu = 0;
+  for (int i = 0; i < nprob; ++i) {
+    tc += (h_desc[i].c_end + 63) / 64;
+    tu += (h_desc[i].rows + 63) / 64;
+  }
+  return (int64_t)nprob * (2 * sizeof(tmf_gemm_desc) + sizeof(tmf_panel_desc)) + 16 * (tc + tu) + 1024;
+}
+
+extern "C" int tmf_bcgs_batched(int dtype, const tmf_bcgs_desc* d_desc, const tmf_bcgs_desc* h_desc, int nprob,
+                                int passes, void* d_work, int64_t work_bytes, void* stream) {
+  using namespace tmf;
+  if (nprob <= 0) return TMF_OK;
+  if (dtype != TMF_C128 && dtype != TMF_F64) {
+    set_error("tmf_bcgs_batched: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+  if (work_bytes < tmf_bcgs_work_bytes(h_desc, nprob)) {
+    set_error("tmf_bcgs_batched: workspace of %lld bytes is too small (tmf_bcgs_work_bytes)", (long long)work_bytes);
+    return TMF_E_ARG;
+  }
+  const size_t elem = (dtype == TMF_C128) ? 16 : 8;
+  int max_rows = 0, max_span = 0;
+  int64_t cap_c = 0;
+  for (int i = 0; i < nprob; ++i) {
+    max_rows = h_desc[i].rows > max_rows ? h_desc[i].rows : max_rows;
+    const int span = h_desc[i].c_end - h_desc[i].c_begin;
+    max_span = span > max_span ? span : max_span;
+    cap_c += (h_desc[i].c_end + 63) / 64;
+  }
+  int w = 16;  // widest panel that fits the LDS of orth_panel_kernel
+  while ((size_t)max_rows * w * elem + 1024 > 150 * 1024 && w > 1) w >>= 1;
+  char* wk = static_cast<char*>(d_work);
+  tmf_gemm_desc* g_coef = reinterpret_cast<tmf_gemm_desc*>(wk);
+  tmf_gemm_desc* g_upd = g_coef + nprob;
+  tmf_panel_desc* pd = reinterpret_cast<tmf_panel_desc*>(g_upd + nprob);
+  int32_t* tiles_coef = reinterpret_cast<int32_t*>(pd + nprob);
+  int32_t* tiles_upd = tiles_coef + 4 * cap_c;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  for (int t = 0; t < max_span; t += w) {
+    int64_t nc = 0, nu = 0;
+    int nact = 0;
+    for (int i = 0; i < nprob; ++i) {
+      const tmf_bcgs_desc& d = h_desc[i];
+      if (d.c_end - d.c_begin <= t || d.rows <= 0) continue;
+      ++nact;
+      const int j = d.c_begin + t;
+      if (j > 0) {
+        nc += (j + 63) / 64;
+        nu += (d.rows + 63) / 64;
+      }
+    }
+    if (nact == 0) break;
+    hipLaunchKernelGGL(bcgs_prepare_kernel, dim3(1), dim3(256), 0, s, d_desc, nprob, t, w, elem, g_coef, g_upd, pd,
+                       tiles_coef, tiles_upd);
+    int st = check_hip(hipGetLastError(), "tmf_bcgs_batched prepare");
+    if (st) return st;
+    for (int p = 0; p < passes && nc > 0; ++p) {
+      st = tmf_gemm_batched(dtype, 1, 1.0, 0.0, g_coef, tiles_coef, (int)nc, 16, stream);
+      if (st) return st;
+      st = tmf_gemm_batched(dtype, 0, -1.0, 1.0, g_upd, tiles_upd, (int)nu, 16, stream);
+      if (st) return st;
+    }
+    st = tmf_orth_panel_batched(dtype, pd, nprob, max_rows, w, stream);
+    if (st) return st;
+  }
+  return TMF_OK;
+}

@@ -45,6 +45,75 @@ def _cdiv(a, b):
     return (a + b - 1) // b
 
 
+class _GpuWait:
+    """Wait handle for everything enqueued so far on the current stream."""
+
+    def __init__(self, torch, device):
+        self.ev = torch.cuda.Event()
+        self.ev.record(torch.cuda.current_stream(device))
+
+    def ready(self):
+        return self.ev.query()
+
+    def block(self):
+        self.ev.synchronize()
+
+
+class _ThreadWait:
+    def __init__(self, th):
+        self.th = th
+
+    def ready(self):
+        return not self.th.is_alive()
+
+    def block(self):
+        self.th.join()
+
+
+def _drive(gen):
+    """Runs a sweep generator to completion, blocking at every wait point (the ordinary, unpipelined call)."""
+    try:
+        while True:
+            next(gen).block()
+    except StopIteration as stop:
+        return stop.value
+
+
+def run_pipelined(engines, C, trunc, ortho_center, unit_cell_width, ranges, download=True, threads=None):
+    """One conversion split into site ranges that are swept concurrently by cooperative scheduling:
+    every range is a generator (``Engine.run_gen``) that yields where it would otherwise block (GPU
+    results coming down, the host enumeration thread), and the scheduler resumes whichever range can
+    continue.  The launches of all ranges go to the same HIP stream, so the GPU executes the entangled
+    stage of range B while the host classifies and enumerates range A, and so on: the host round
+    trips of one range hide behind the kernels of the other (single Python thread, no GIL contest;
+    the native host phases run in their own threads).  Returns the per-range MPSData objects."""
+    torch = engines[0].torch
+    dev = engines[0].device
+    torch.cuda.current_stream(dev).synchronize()
+    if isinstance(C, torch.Tensor):
+        Ld = int(round(C.numel() ** 0.5))
+        diag = torch.real(C.reshape(-1)[:: Ld + 1]).cpu().numpy().astype(np.float64)
+    else:
+        diag = np.real(np.diagonal(np.asarray(C))).astype(np.float64)
+    gens = [e.run_gen(C, trunc, ortho_center, unit_cell_width, threads=threads, download=download, site_range=r,
+                      diag=diag, presynced=True) for e, r in zip(engines, ranges)]
+    waits, out = [None] * len(gens), [None] * len(gens)
+    live = list(range(len(gens)))
+    while live:
+        progressed = False
+        for j in list(live):
+            if waits[j] is None or waits[j].ready():
+                try:
+                    waits[j] = next(gens[j])
+                except StopIteration as stop:
+                    out[j] = stop.value
+                    live.remove(j)
+                progressed = True
+        if not progressed:
+            waits[live[0]].block()
+    return out
+
+
 class Engine:
     def __init__(self, device="cuda:0", profile=None):
         import torch
@@ -141,16 +210,17 @@ class Engine:
 
     def bcgs2(self, base, rows, ld, c_begin, c_end, scratch_ptr, passes=2):
         """Orthonormalise columns [c_begin, c_end) of every matrix against all columns before
-        them (blocked classical Gram-Schmidt with re-orthogonalisation), panels of width w.
+        them (blocked classical Gram-Schmidt with re-orthogonalisation, tmf_bcgs_batched: the panel
+        loop and its descriptors live in C++ / on the device).
         passes=2 for well-conditioned slabs; passes=3 for numerically rank-deficient ones
         (range finder), where a second pass still acts on rounding noise."""
-        base, rows, ld, c_begin, c_end = (np.asarray(x, np.int64) for x in (base, rows, ld, c_begin, c_end))
-        if base.size == 0:
+        base, rows, ld, c_begin, c_end, scratch_ptr = (np.asarray(x, np.int64) for x in
+                                                       (base, rows, ld, c_begin, c_end, scratch_ptr))
+        keep = np.nonzero((rows > 0) & (c_end > c_begin))[0]
+        if keep.size == 0:
             return
-        max_rows = int(rows.max())
-        w = PANEL_W
-        while max_rows * w * self.elem + 1024 > 150 * 1024 and w > 1:
-            w //= 2
+        keep = keep[np.argsort(-rows[keep], kind="stable")]      # long slabs first: their tiles run longest
+        base, rows, ld, c_begin, c_end, scratch_ptr = (x[keep] for x in (base, rows, ld, c_begin, c_end, scratch_ptr))
         span = c_end - c_begin
         # norms of the raw columns: the panel kernel zeroes columns whose residual is rounding noise
         noff = np.concatenate(([0], np.cumsum(span)))[:-1]
@@ -162,24 +232,15 @@ class Engine:
         nd["n"], nd["c"], nd["lds_"] = rows, span, ld
         t_nd = self._up(nd)
         nat.check(self.lib.tmf_column_norms_batched(self.dtype, t_nd.data_ptr(), base.size, self.stream), "norms")
-        for t in range(0, int(span.max()), w):
-            act = np.nonzero((span > t) & (rows > 0))[0]
-            if act.size == 0:
-                break
-            j = c_begin[act] + t
-            wj = np.minimum(w, c_end[act] - j)
-            colp = base[act] + j * ld[act] * self.elem
-            for _ in range(passes):
-                self.gemm(1, 1.0, 0.0, base[act], colp, scratch_ptr[act], j, wj, rows[act], ld[act], ld[act],
-                          np.maximum(j, 1))
-                self.gemm(0, -1.0, 1.0, base[act], scratch_ptr[act], colp, rows[act], wj, j, ld[act],
-                          np.maximum(j, 1), ld[act])
-            d = np.zeros(act.size, nat.panel_desc)
-            d["A"], d["n"], d["w"], d["lda"] = colp, rows[act], wj, ld[act]
-            d["norms"] = nrmp[act] + 8 * t
-            dd = self._up(d)
-            nat.check(self.lib.tmf_orth_panel_batched(self.dtype, dd.data_ptr(), act.size, max_rows, w, self.stream),
-                      "tmf_orth_panel_batched")
+        bd = np.zeros(base.size, nat.bcgs_desc)
+        bd["base"], bd["scratch"], bd["norms"] = base, scratch_ptr, nrmp
+        bd["rows"], bd["ld"], bd["c_begin"], bd["c_end"] = rows, ld, c_begin, c_end
+        t_bd = self._up(bd)
+        wb = int(self.lib.tmf_bcgs_work_bytes(nat._p(bd), base.size))
+        d_work = self.torch.empty(wb, dtype=self.torch.uint8, device=self.device)
+        self._keep.append(d_work)
+        nat.check(self.lib.tmf_bcgs_batched(self.dtype, t_bd.data_ptr(), nat._p(bd), base.size, passes,
+                                            d_work.data_ptr(), wb, self.stream), "tmf_bcgs_batched")
 
     def jacobi(self, X, V, s, count, thresh2, p, ldx, ldv, left_only=False):
         """One-sided Jacobi per problem.  ``left_only``: ``V`` receives the normalised LEFT singular
@@ -367,6 +428,22 @@ class Engine:
 
     range_floor_tol = 1e-11
 
+    def _fetch_async(self, tensors):
+        """Asynchronous device -> pinned host copies of small result tensors; returns (wait handle, NumPy
+        views).  The views are valid once the handle is ready and until the next call with the same slots."""
+        cache = getattr(self, "_fetch_cache", None)
+        if cache is None:
+            cache = self._fetch_cache = {}
+        views = []
+        for slot, t in enumerate(tensors):
+            key = (slot, t.dtype)
+            h = cache.get(key)
+            if h is None or h.numel() < t.numel():
+                h = cache[key] = self.torch.empty(max(int(t.numel() * 1.5), 1024), dtype=t.dtype, pin_memory=True)
+            h[: t.numel()].copy_(t.reshape(-1), non_blocking=True)
+            views.append(h[: t.numel()].numpy())
+        return _GpuWait(self.torch, self.device), views
+
     def _hbuf(self, name, shape, dtype, zero=False):
         """Persistent host scratch (grow-only, pre-faulted).  Fresh ``np.zeros`` arrays of this size
         are lazily mapped, and their first-touch page faults inside the 16 enumeration threads
@@ -396,8 +473,13 @@ class Engine:
 
     range_ladder = (P_RANGE, 128, 256)   # widths of the range finder tried in turn
 
-    def entangled_stage_adaptive(self, L, n, m, blk, off, doE, thr2, cs_b, x, side, Cp):
-        """Runs the entangled stage with the narrowest adequate range finder.
+    def entangled_stage_adaptive(self, *args):
+        """Blocking form of :meth:`entangled_stage_adaptive_gen`."""
+        return _drive(self.entangled_stage_adaptive_gen(*args))
+
+    def entangled_stage_adaptive_gen(self, L, n, m, blk, off, doE, thr2, cs_b, x, side, Cp):
+        """Runs the entangled stage with the narrowest adequate range finder (generator: yields a wait
+        handle wherever results have to come down from the GPU).
 
         Adequacy is CHECKED, not assumed.  A direction with singular value s_i is found with angle error
         ~ s_P / s_i (s_P: smallest singular value captured by the P columns) and enters the state with
@@ -421,25 +503,28 @@ class Engine:
             nest = (x, side, Cp, d_Om.data_ptr())
             full = doE & (p == P) & (P < np.minimum(n, m))              # cuts the range finder truncates
             st = self.entangled_stage(L, n, m, blk, off, omp, doE, p, thr2, P, iterations=0, nest=nest)
-            h_sig, oS = st["d_sig"].cpu().numpy(), st["oS"]
+            w_, (h_sig, h_cnt, h_e) = self._fetch_async([st["d_sig"], st["d_cnt"], st["d_e"]])
+            yield w_
+            h_sig, h_cnt, h_e, oS = h_sig.copy(), h_cnt.copy(), h_e.copy(), st["oS"]
             worst = max((h_sig[oS[i] + P - 1] for i in np.nonzero(full)[0]), default=0.0)
             self.range_floor = float(worst)
             its = 0
             if worst > self.range_floor_tol:
                 st = self.entangled_stage(L, n, m, blk, off, omp, doE, p, thr2, P, iterations=1, nest=nest)
                 its = 1
-                h_sig, oS = st["d_sig"].cpu().numpy(), st["oS"]
+                w_, (h_sig, h_cnt, h_e) = self._fetch_async([st["d_sig"], st["d_cnt"], st["d_e"]])
+                yield w_
+                h_sig, h_cnt, h_e, oS = h_sig.copy(), h_cnt.copy(), h_e.copy(), st["oS"]
                 bad = [i for i in np.nonzero(full)[0] if h_sig[oS[i] + P - 1] > 4.6e-4 * thr2**0.5]
                 if bad:   # (s_P / sqrt(thr2))^3 > 1e-10 even after the iteration
                     reason = (f"cut {cs_b[bad[0]]}: smallest captured singular value "
                               f"{h_sig[oS[bad[0]] + P - 1]:.1e} vs threshold {thr2 ** 0.5:.1e} with {P} columns")
                     continue
-            h_cnt = st["d_cnt"].cpu().numpy()
             sat = np.nonzero(full & (h_cnt >= p))[0]
             if sat.size:
                 reason = f"cut {cs_b[sat[0]]}: {P} or more orbitals above the range-finder threshold"
                 continue
-            st.update(P=P, p=p, d_Om=d_Om, range_iterations=its, h_e=st["d_e"].cpu().numpy(), h_cnt=h_cnt)
+            st.update(P=P, p=p, d_Om=d_Om, range_iterations=its, h_e=h_e, h_cnt=h_cnt)
             self.range_iterations_used, self.range_width = its, P
             return st
         raise NotImplementedError(f"entanglement rank beyond the widest range finder ({self.range_ladder[-1]} "
@@ -447,7 +532,14 @@ class Engine:
 
     # ------------------------------------------------------------------ the sweep
     def run(self, C, trunc, ortho_center, unit_cell_width, threads=None, download=True, site_range=None):
-        """One C -> MPS conversion.
+        """One C -> MPS conversion (blocking form of :meth:`run_gen`)."""
+        return _drive(self.run_gen(C, trunc, ortho_center, unit_cell_width, threads, download, site_range))
+
+    def run_gen(self, C, trunc, ortho_center, unit_cell_width, threads=None, download=True, site_range=None,
+                diag=None, presynced=False):
+        """One C -> MPS conversion as a generator: yields a wait handle (``ready()`` / ``block()``) at the
+        three places where the host has to wait - eigenvalues coming down, the enumeration thread, the
+        final results - so that several site ranges can be interleaved (:func:`run_pipelined`).
 
         C            (L, L) NumPy array, or a row-major torch tensor already resident in HBM
         download     False keeps the tensors in HBM (``self.d_out``) and returns no site blocks
@@ -458,19 +550,22 @@ class Engine:
         self.timings = {}
         self.det_events = []
         self.gemm_events = []
-        torch.cuda.current_stream(self.device).synchronize()  # staging arena of the previous call is free
+        if not presynced:
+            torch.cuda.current_stream(self.device).synchronize()  # staging arena of the previous call is free
         self._pin_off = 0
         if isinstance(C, torch.Tensor):
             d_Crm = C.reshape(-1)
             cplx = d_Crm.is_complex()
             L = int(round(d_Crm.numel() ** 0.5))
-            diag = torch.real(d_Crm[:: L + 1]).cpu().numpy().astype(np.float64)
+            if diag is None:
+                diag = torch.real(d_Crm[:: L + 1]).cpu().numpy().astype(np.float64)
         else:
             C = np.asarray(C)
             cplx = np.iscomplexobj(C)
             C = np.ascontiguousarray(C, np.complex128 if cplx else np.float64)
             L = len(C)
-            diag = np.real(np.diagonal(C)).astype(np.float64)
+            if diag is None:
+                diag = np.real(np.diagonal(C)).astype(np.float64)
             d_Crm = None
         self.dtype = nat.TMF_C128 if cplx else nat.TMF_F64
         self.elem = 16 if cplx else 8
@@ -520,7 +615,7 @@ class Engine:
             return o[:-1], int(o[-1])
 
         t0 = time.perf_counter()
-        st = self.entangled_stage_adaptive(L, n, m, blk, off, doE, thr2, cs_b, cs_b, cs_side, Cp)
+        st = yield from self.entangled_stage_adaptive_gen(L, n, m, blk, off, doE, thr2, cs_b, cs_b, cs_side, Cp)
         P, p = st["P"], st["p"]
         UEp, oS, ld1 = st["UEp"], st["oS"], st["ld1"]
         self._tick("E_entangled", t0)
@@ -750,6 +845,7 @@ class Engine:
             d_chk = self.recon_errors(items)
         self._tick("F_filled", t0)
 
+        yield _ThreadWait(th)
         th.join()
         if "exc" in hp:
             raise hp["exc"]
@@ -871,13 +967,13 @@ class Engine:
         t0 = time.perf_counter()
         bonds = ho["make_bonds"]()
         self._tick("host_bonds", t0)
+        yield _GpuWait(torch, self.device)
         self.check_results = {}
         if d_chk is not None:
             self.check_results = dict(zip(chk_names, (float(v) for v in d_chk.cpu().numpy())))
 
         # ---- host round trip 2: tensors back -----------------------------------------------------
         if not download:
-            torch.cuda.current_stream(self.device).synchronize()
             self.timings["total"] = time.perf_counter() - t_all
             self._keep.clear()
             return self._finish(MPSData(bonds, [], oc, unit_cell_width, dict(self.timings)))
