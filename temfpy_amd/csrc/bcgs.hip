@@ -13,8 +13,11 @@
 
 namespace tmf {
 
+// Block = columns [c_begin + t, c_begin + t + w); it is projected against the columns
+// [from, c_begin + t) with from = 0 (t0 < 0: everything before the block) or from = c_begin + t0
+// (the earlier panels of the same 16-column block).
 __global__ __launch_bounds__(256) void bcgs_prepare_kernel(const tmf_bcgs_desc* __restrict__ desc, int nprob, int t,
-                                                           int w, size_t elem, tmf_gemm_desc* __restrict__ g_coef,
+                                                           int w, int t0, size_t elem, tmf_gemm_desc* __restrict__ g_coef,
                                                            tmf_gemm_desc* __restrict__ g_upd,
                                                            tmf_panel_desc* __restrict__ pd, int32_t* __restrict__ tiles_coef,
                                                            int32_t* __restrict__ tiles_upd) {
@@ -27,15 +30,18 @@ __global__ __launch_bounds__(256) void bcgs_prepare_kernel(const tmf_bcgs_desc* 
     const tmf_bcgs_desc d = desc[i];
     const int span = d.c_end - d.c_begin;
     const bool act = span > t && d.rows > 0;
-    const int j = d.c_begin + t;                       // columns already orthonormal
-    const int wj = act ? min(w, d.c_end - j) : 0;
-    const uint64_t colp = d.base + (uint64_t)j * d.ld * elem;
+    const int jb = d.c_begin + t;                      // first column of the block
+    const int from = t0 < 0 ? 0 : d.c_begin + t0;
+    const int j = jb - from;                           // columns to project against
+    const int wj = act ? min(w, d.c_end - jb) : 0;
+    const uint64_t colp = d.base + (uint64_t)jb * d.ld * elem;
+    const uint64_t qp = d.base + (uint64_t)from * d.ld * elem;
     tmf_gemm_desc c, u;
-    c.A = d.base, c.B = colp, c.C = d.scratch;          // coefficients (j x wj) = Q^H P
+    c.A = qp, c.B = colp, c.C = d.scratch;              // coefficients (j x wj) = Q^H P
     c.M = act ? j : 0, c.N = wj, c.K = d.rows, c.lda = d.ld, c.ldb = d.ld, c.ldc = j > 1 ? j : 1;
-    u.A = d.base, u.B = d.scratch, u.C = colp;          // P -= Q c
+    u.A = qp, u.B = d.scratch, u.C = colp;              // P -= Q c
     u.M = act ? d.rows : 0, u.N = (act && j > 0) ? wj : 0, u.K = j, u.lda = d.ld, u.ldb = j > 1 ? j : 1, u.ldc = d.ld;
-    if (j == 0) c.N = 0;                                // first panel: nothing to project against
+    if (j == 0) c.N = 0;                                // nothing to project against
     g_coef[i] = c, g_upd[i] = u;
     tmf_panel_desc p;
     p.A = colp, p.norms = d.norms ? d.norms + 8ull * t : 0ull, p.n = act ? d.rows : 0, p.w = wj, p.lda = d.ld, p.pad = 0;
@@ -104,32 +110,45 @@ extern "C" int tmf_bcgs_batched(int dtype, const tmf_bcgs_desc* d_desc, const tm
   int32_t* tiles_coef = reinterpret_cast<int32_t*>(pd + nprob);
   int32_t* tiles_upd = tiles_coef + 4 * cap_c;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  for (int t = 0; t < max_span; t += w) {
+  // Outer blocks of 16 columns are projected against everything before them in one go (the GEMMs are
+  // bound by streaming those columns, so fewer, wider projections = less traffic); tall slabs whose
+  // LDS panel is narrower (w < 16) then orthonormalise the block panel by panel, projecting each
+  // later panel only against the earlier panels of its own block.
+  const int wo = 16;
+  auto project = [&](int t, int wb, int t0) -> int {
     int64_t nc = 0, nu = 0;
-    int nact = 0;
     for (int i = 0; i < nprob; ++i) {
       const tmf_bcgs_desc& d = h_desc[i];
       if (d.c_end - d.c_begin <= t || d.rows <= 0) continue;
-      ++nact;
-      const int j = d.c_begin + t;
+      const int j = d.c_begin + t - (t0 < 0 ? 0 : d.c_begin + t0);
       if (j > 0) {
         nc += (j + 63) / 64;
         nu += (d.rows + 63) / 64;
       }
     }
-    if (nact == 0) break;
-    hipLaunchKernelGGL(bcgs_prepare_kernel, dim3(1), dim3(256), 0, s, d_desc, nprob, t, w, elem, g_coef, g_upd, pd,
+    hipLaunchKernelGGL(bcgs_prepare_kernel, dim3(1), dim3(256), 0, s, d_desc, nprob, t, wb, t0, elem, g_coef, g_upd, pd,
                        tiles_coef, tiles_upd);
     int st = check_hip(hipGetLastError(), "tmf_bcgs_batched prepare");
-    if (st) return st;
-    for (int p = 0; p < passes && nc > 0; ++p) {
+    for (int p = 0; p < passes && nc > 0 && !st; ++p) {
       st = tmf_gemm_batched(dtype, 1, 1.0, 0.0, g_coef, tiles_coef, (int)nc, 16, stream);
+      if (!st) st = tmf_gemm_batched(dtype, 0, -1.0, 1.0, g_upd, tiles_upd, (int)nu, 16, stream);
+    }
+    return st;
+  };
+  for (int t = 0; t < max_span; t += wo) {
+    int st = project(t, wo, -1);
+    if (st) return st;
+    if (w == wo) {  // the block is one LDS panel: the descriptors of `project` are the panel's
+      st = tmf_orth_panel_batched(dtype, pd, nprob, max_rows, w, stream);
       if (st) return st;
-      st = tmf_gemm_batched(dtype, 0, -1.0, 1.0, g_upd, tiles_upd, (int)nu, 16, stream);
+      continue;
+    }
+    for (int ti = 0; ti < wo && t + ti < max_span; ti += w) {
+      st = project(t + ti, w, t);
+      if (st) return st;
+      st = tmf_orth_panel_batched(dtype, pd, nprob, max_rows, w, stream);
       if (st) return st;
     }
-    st = tmf_orth_panel_batched(dtype, pd, nprob, max_rows, w, stream);
-    if (st) return st;
   }
   return TMF_OK;
 }
