@@ -14,7 +14,6 @@
 #include <string.h>
 
 #include <algorithm>
-#include <queue>
 #include <vector>
 
 #include "../../include/temfpy_hip.h"
@@ -56,19 +55,6 @@ double np_pairwise_sum(const double* a, int n) {
   n2 -= n2 % 8;
   return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
 }
-
-struct Node {
-  double sum;
-  int64_t seq;
-  int i;
-  Mask set;
-};
-struct NodeGreater {  // min-heap on (sum, seq): the tuple order of schmidt_utils.py:290-314
-  bool operator()(const Node& a, const Node& b) const {
-    if (a.sum != b.sum) return a.sum > b.sum;
-    return a.seq > b.seq;
-  }
-};
 
 }  // namespace
 
@@ -122,12 +108,31 @@ extern "C" int tmf_cut_vectors(const double* e, int k, int filled_left, int64_t 
     for (int i = 0; i < k; ++i) idx[i] = i;
     std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return av[x] < av[y]; });
 
-    std::priority_queue<Node, std::vector<Node>, NodeGreater> heap;
-    int64_t seq = 0;
+    // binary heap of 16-byte items (sum, seq, payload index); the occupation masks live in a side array,
+    // so sifting moves 16 bytes instead of 40 (the heap operations are ~all of this function's time)
+    struct Item {
+      double sum;
+      uint32_t seq, id;
+    };
+    auto greater = [](const Item& a, const Item& b) { return a.sum != b.sum ? a.sum > b.sum : a.seq > b.seq; };
+    struct Payload {
+      Mask set;
+      int i;
+    };
+    std::vector<Item> heap;
+    std::vector<Payload> pay;
+    const size_t guess = chi_max > 0 ? (size_t)(2 * chi_max + 8) : 4096;
+    heap.reserve(guess), pay.reserve(guess), sums.reserve(guess / 2 + 2), sets.reserve(guess / 2 + 2);
+    uint32_t seq = 0;
+    auto push = [&](double sum, int i, const Mask& set) {
+      heap.push_back(Item{sum, seq++, (uint32_t)pay.size()});
+      pay.push_back(Payload{set, i});
+      std::push_heap(heap.begin(), heap.end(), greater);
+    };
     {
       Mask s = min_set;
       s.flip(idx[0]);
-      heap.push(Node{min_sum + av[idx[0]], seq, 0, s});
+      push(min_sum + av[idx[0]], 0, s);
     }
     auto keep_generating = [&]() {  // schmidt_utils.py:99-138
       if (chi_max > 0 && (int64_t)sums.size() > chi_max) return false;
@@ -136,21 +141,23 @@ extern "C" int tmf_cut_vectors(const double* e, int k, int filled_left, int64_t 
     };
     while (!heap.empty() && keep_generating()) {
       ++n_checked;
-      Node nd = heap.top();
-      heap.pop();
+      std::pop_heap(heap.begin(), heap.end(), greater);
+      const Item it = heap.back();
+      heap.pop_back();
+      const Payload nd = pay[it.id];
       if (in_sector(filled_left + nd.set.count())) {
-        sums.push_back(nd.sum);
+        sums.push_back(it.sum);
         sets.push_back(nd.set);
       }
       if (nd.i < k - 1) {
         Mask c1 = nd.set;
         c1.flip(idx[nd.i + 1]);
-        double s = nd.sum + av[idx[nd.i + 1]];
-        heap.push(Node{s, ++seq, nd.i + 1, c1});
+        double s = it.sum + av[idx[nd.i + 1]];
+        push(s, nd.i + 1, c1);
         Mask c2 = c1;
         c2.flip(idx[nd.i]);
         s = s - av[idx[nd.i]];
-        heap.push(Node{s, ++seq, nd.i + 1, c2});
+        push(s, nd.i + 1, c2);
       }
     }
   }
@@ -182,15 +189,21 @@ extern "C" int tmf_cut_vectors(const double* e, int k, int filled_left, int64_t 
   }
   // stable sort by left charge (slater.py:672-678), Schmidt values (slater.py:489)
   std::vector<int64_t> ord(cut);
-  for (int64_t i = 0; i < cut; ++i) ord[i] = i;
-  std::stable_sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) { return sets[x].count() < sets[y].count(); });
+  {
+    int start[130] = {0};
+    for (int64_t i = 0; i < cut; ++i) ++start[sets[i].count() + 1];
+    for (int b = 1; b < 130; ++b) start[b] += start[b - 1];
+    for (int64_t i = 0; i < cut; ++i) ord[start[sets[i].count()]++] = i;
+  }
+  double tab[2][128];
+  for (int i = 0; i < k; ++i) tab[0][i] = 1.0 - e[i], tab[1][i] = e[i];
   for (int64_t r = 0; r < cut; ++r) {
     const Mask& s = sets[ord[r]];
     sets_out[2 * r] = s.lo;
     sets_out[2 * r + 1] = s.hi;
     q_left[r] = filled_left + s.count();
     double prod = 1.0;
-    for (int i = 0; i < k; ++i) prod *= s.get(i) ? e[i] : 1.0 - e[i];
+    for (int i = 0; i < k; ++i) prod *= tab[s.get(i)][i];
     lam_raw[r] = sqrt(prod);
   }
   return TMF_OK;
@@ -232,11 +245,20 @@ extern "C" int tmf_site_prepare(const tmf_site_in* in, const uint64_t* sets_b, c
 
   // ---- classify entangled orbitals: 0 never, 1 sometimes, 2 always --------------------------
   auto classify = [](const Side& s, std::vector<int>& cls) {
+    // AND / OR of all occupation masks: an orbital is always (never) occupied iff its bit is set in
+    // every (no) mask - mirrored for the right side, where occupation is the complement
+    uint64_t and_lo = ~0ull, and_hi = ~0ull, or_lo = 0, or_hi = 0;
+    for (int a = 0; a < s.chi; ++a) {
+      and_lo &= s.sets[2 * a], and_hi &= s.sets[2 * a + 1];
+      or_lo |= s.sets[2 * a], or_hi |= s.sets[2 * a + 1];
+    }
+    const Mask all{and_lo, and_hi}, any{or_lo, or_hi};
     cls.assign(s.k, 0);
     for (int j = 0; j < s.k; ++j) {
-      int cnt = 0;
-      for (int a = 0; a < s.chi; ++a) cnt += s.occ(a, j);
-      cls[j] = cnt == 0 ? 0 : (cnt == s.chi ? 2 : 1);
+      const int bit = s.right ? s.k - 1 - j : j;
+      const bool always = s.right ? !any.get(bit) : all.get(bit);
+      const bool never = s.right ? all.get(bit) : !any.get(bit);
+      cls[j] = never ? 0 : (always ? 2 : 1);
     }
   };
   std::vector<int> cb, ck;
@@ -321,8 +343,14 @@ extern "C" int tmf_site_prepare(const tmf_site_in* in, const uint64_t* sets_b, c
     cnt[r] = B.nf + B.ent_count(a) + p;  // particles in the bra orbitals incl. the physical one
     perm[r] = r;
   }
-  if (!right) std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return cnt[x] < cnt[y]; });
-  else std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return cnt[x] > cnt[y]; });
+  {  // stable counting sort by particle number (ascending on the left, descending on the right)
+    int cmin = cnt[0], cmax = cnt[0];
+    for (int r = 1; r < nb2; ++r) cmin = std::min(cmin, cnt[r]), cmax = std::max(cmax, cnt[r]);
+    std::vector<int> start(cmax - cmin + 2, 0);
+    for (int r = 0; r < nb2; ++r) ++start[(right ? cmax - cnt[r] : cnt[r] - cmin) + 1];
+    for (size_t b = 1; b < start.size(); ++b) start[b] += start[b - 1];
+    for (int r = 0; r < nb2; ++r) perm[start[right ? cmax - cnt[r] : cnt[r] - cmin]++] = r;
+  }
   for (int r = 0; r < nb2; ++r) {
     bra_p[r] = perm[r] >= B.chi;
     bra_alpha[r] = perm[r] % B.chi;
@@ -334,6 +362,42 @@ extern "C" int tmf_site_prepare(const tmf_site_in* in, const uint64_t* sets_b, c
     if (o.ent < 0) return true;  // filled
     return s.occ(alpha, o.ent);
   };
+  // Occupancy of the S-rows / S-columns of one Schmidt vector as a 64-bit word (bit i = S position i):
+  // constant bits for filled orbitals, the physical bit, and one shift per entangled position.
+  struct SMap {
+    uint64_t fixed = 0;      // filled orbitals: always occupied
+    int phys = -1;           // S position of the physical orbital
+    int n = 0;
+    uint8_t pos[64], bit[64], inv[64];
+  };
+  auto make_map = [&](const Side& s, const std::vector<Orb>& part, SMap& mp) -> bool {
+    if (part.size() > 64) return false;
+    for (size_t i = 0; i < part.size(); ++i) {
+      const Orb& o = part[i];
+      if (o.src < 0) mp.phys = (int)i;
+      else if (o.ent < 0) mp.fixed |= 1ull << i;
+      else {
+        mp.pos[mp.n] = (uint8_t)i;
+        mp.bit[mp.n] = (uint8_t)(s.right ? s.k - 1 - o.ent : o.ent);
+        mp.inv[mp.n] = s.right ? 1 : 0;
+        ++mp.n;
+      }
+    }
+    return true;
+  };
+  auto occ_word = [](const SMap& mp, const uint64_t* set2, int p) -> uint64_t {
+    uint64_t wd = mp.fixed;
+    if (mp.phys >= 0 && p) wd |= 1ull << mp.phys;
+    const uint64_t lo = set2[0], hi = set2[1];
+    for (int t = 0; t < mp.n; ++t) {
+      const int b = mp.bit[t];
+      const uint64_t v = ((b < 64 ? lo >> b : hi >> (b - 64)) & 1ull) ^ mp.inv[t];
+      wd |= v << mp.pos[t];
+    }
+    return wd;
+  };
+  SMap map_b, map_k;
+  const bool fast = make_map(B, srows, map_b) && make_map(K, scols, map_k);
   int nsec = 0;
   int64_t idx_used = 0, out_elems = 0;
   int c0 = 0;
@@ -355,7 +419,9 @@ extern "C" int tmf_site_prepare(const tmf_site_in* in, const uint64_t* sets_b, c
       }
       // order of the minors: occupied S-columns of the first ket row
       int n = 0;
-      for (int i = 0; i < sk; ++i) n += occupied(K, scols[i], c0, 0);
+      if (fast) n = __builtin_popcountll(occ_word(map_k, K.sets + 2 * (size_t)c0, 0));
+      else
+        for (int i = 0; i < sk; ++i) n += occupied(K, scols[i], c0, 0);
       const int64_t need = (int64_t)(r1 - r0 + c1 - c0) * n;
       if (idx_used + need > idx_cap) {
         tmf::set_error("tmf_site_prepare: index pool too small (%lld > %lld)", (long long)(idx_used + need),
@@ -368,11 +434,18 @@ extern "C" int tmf_site_prepare(const tmf_site_in* in, const uint64_t* sets_b, c
       S.bra_off = idx_used;
       for (int r = r0; r < r1; ++r) {
         int m = 0;
-        for (int i = 0; i < sb; ++i)
-          if (occupied(B, srows[i], bra_alpha[r], bra_p[r])) {
-            if (m < n) idx_pool[idx_used + m] = (uint8_t)i;
-            ++m;
-          }
+        if (fast) {
+          uint64_t wd = occ_word(map_b, B.sets + 2 * (size_t)bra_alpha[r], bra_p[r]);
+          m = __builtin_popcountll(wd);
+          if (m == n)
+            for (int q = 0; q < n; ++q, wd &= wd - 1) idx_pool[idx_used + q] = (uint8_t)__builtin_ctzll(wd);
+        } else {
+          for (int i = 0; i < sb; ++i)
+            if (occupied(B, srows[i], bra_alpha[r], bra_p[r])) {
+              if (m < n) idx_pool[idx_used + m] = (uint8_t)i;
+              ++m;
+            }
+        }
         if (m != n) {  // slater.py:847-855
           tmf::set_error("tmf_site_prepare: bra row %d has %d particles in the minor, ket sector has %d", r, m, n);
           return TMF_E_ARG;
@@ -382,11 +455,18 @@ extern "C" int tmf_site_prepare(const tmf_site_in* in, const uint64_t* sets_b, c
       S.ket_off = idx_used;
       for (int c = c0; c < c1; ++c) {
         int m = 0;
-        for (int i = 0; i < sk; ++i)
-          if (occupied(K, scols[i], c, 0)) {
-            if (m < n) idx_pool[idx_used + m] = (uint8_t)i;
-            ++m;
-          }
+        if (fast) {
+          uint64_t wd = occ_word(map_k, K.sets + 2 * (size_t)c, 0);
+          m = __builtin_popcountll(wd);
+          if (m == n)
+            for (int q = 0; q < n; ++q, wd &= wd - 1) idx_pool[idx_used + q] = (uint8_t)__builtin_ctzll(wd);
+        } else {
+          for (int i = 0; i < sk; ++i)
+            if (occupied(K, scols[i], c, 0)) {
+              if (m < n) idx_pool[idx_used + m] = (uint8_t)i;
+              ++m;
+            }
+        }
         if (m != n) {
           tmf::set_error("tmf_site_prepare: ket row %d has %d particles in the minor, sector has %d", c, m, n);
           return TMF_E_ARG;
