@@ -634,13 +634,14 @@ class Engine:
         x_lo = np.sum(valid & (E2 < cutoff), axis=1)
         ent0 = np.where(doE, x_hi, 0)                        # first entangled column inside U_E
         k = np.where(doE, h_cnt - x_hi - x_lo, 0).astype(np.int64)
-        e_side = [E2[i, ent0[i]: ent0[i] + k[i]].copy() for i in range(ncs)]
+        e_side = [E2[i, a_: b_] for i, (a_, b_) in enumerate(zip(ent0.tolist(), (ent0 + k).tolist()))]  # views
+        esum = np.where((colP[None, :] >= ent0[:, None]) & (colP[None, :] < (ent0 + k)[:, None]), E2, 0.0).sum(axis=1)
         # centre: right-side eigenvalues are 1 - e_L reversed (slater.py:386 convention)
         if has_centre:
             k[centre_R] = k[centre_L]
             e_side[centre_R] = (1.0 - e_side[centre_L])[::-1].copy()
-        nf = np.array([int(np.round(tr[i] - e_side[i].sum())) for i in range(ncs)])
-        nf = np.clip(nf, 0, n - k).astype(np.int64)
+            esum[centre_R] = e_side[centre_R].sum()
+        nf = np.clip(np.round(tr - esum).astype(np.int64), 0, n - k)
         self._tick("host_classify", t0)
 
         def host_phase():
