@@ -57,6 +57,12 @@ int tmf_gemm_batched(int dtype, int opA, double alpha, double beta, const tmf_ge
                      const int32_t* d_tiles /* [ntiles][4]: problem, tile_m, tile_n, 0 */, int ntiles,
                      int tile_n /* 64 or 16 */, void* stream);
 
+/* Tall-skinny form of the above for op(A) = A^H, N <= 16 and a long contraction (the coefficient
+ * products Q^H P of the blocked Gram-Schmidt): 16 x 16 output tiles, 64 rows of A and B per step.
+ * d_tiles: [ntiles][4] = problem, tile_m (units of 16 rows of C), 0, 0. */
+int tmf_gemm_tall_batched(int dtype, double alpha, double beta, const tmf_gemm_desc* d_desc, const int32_t* d_tiles,
+                          int ntiles, void* stream);
+
 /* Orthonormalise the columns [c0, c0+w) of A (n x *) in place against themselves
  * (classical Gram-Schmidt, twice), one workgroup per problem, panel staged in LDS.
  * With `norms` given, a column whose residual is below 1e-14 of its original norm (pure

@@ -69,7 +69,7 @@ assert schur_desc.itemsize == 48 and det_desc.itemsize == 72 and gather_desc.ite
 assert colnorm_desc.itemsize == 40 and sector.itemsize == 48 and site_out.itemsize == 40
 
 SYMBOLS = [
-    "tmf_last_error", "tmf_version", "tmf_device_count", "tmf_gemm_batched", "tmf_orth_panel_batched",
+    "tmf_last_error", "tmf_version", "tmf_device_count", "tmf_gemm_batched", "tmf_gemm_tall_batched", "tmf_orth_panel_batched",
     "tmf_bcgs_work_bytes", "tmf_bcgs_batched", "tmf_jacobi_batched", "tmf_svd_left_batched",
     "tmf_jacobi_block_batched", "tmf_nested_products_batched", "tmf_recon_error_batched", "tmf_lu_schur_batched",
     "tmf_det_gather_batched", "tmf_det_reduced_batched", "tmf_transpose", "tmf_fill_normal",
@@ -99,6 +99,7 @@ def load():
     lib.tmf_last_error.restype = C.c_char_p
     vp, i32, i64, f64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_uint64
     lib.tmf_gemm_batched.argtypes = [i32, i32, f64, f64, vp, vp, i32, i32, vp]
+    lib.tmf_gemm_tall_batched.argtypes = [i32, f64, f64, vp, vp, i32, vp]
     lib.tmf_orth_panel_batched.argtypes = [i32, vp, i32, i32, i32, vp]
     lib.tmf_jacobi_batched.argtypes = [i32, vp, i32, i32, vp, vp]
     lib.tmf_svd_left_batched.argtypes = [i32, vp, i32, i32, vp, vp]

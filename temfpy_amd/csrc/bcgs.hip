@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void bcgs_prepare_kernel(const tmf_bcgs_desc* 
     tmf_panel_desc p;
     p.A = colp, p.norms = d.norms ? d.norms + 8ull * t : 0ull, p.n = act ? d.rows : 0, p.w = wj, p.lda = d.ld, p.pad = 0;
     pd[i] = p;
-    nc += (c.M > 0 && c.N > 0) ? (c.M + 63) / 64 : 0;   // 16-wide tiles: one tile column
+    nc += (c.M > 0 && c.N > 0) ? (c.M + 15) / 16 : 0;   // tall kernel: 16 x 16 output tiles
     nu += (u.M > 0 && u.N > 0) ? (u.M + 63) / 64 : 0;
   }
   scan_c[tid + 1] = nc, scan_u[tid + 1] = nu;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void bcgs_prepare_kernel(const tmf_bcgs_desc* 
   for (int i = i0; i < i1; ++i) {
     const tmf_gemm_desc c = g_coef[i], u = g_upd[i];
     if (c.M > 0 && c.N > 0)
-      for (int m = 0; m < (c.M + 63) / 64; ++m, ++oc) {
+      for (int m = 0; m < (c.M + 15) / 16; ++m, ++oc) {
         tiles_coef[4 * oc] = i, tiles_coef[4 * oc + 1] = m, tiles_coef[4 * oc + 2] = 0, tiles_coef[4 * oc + 3] = 0;
       }
     if (u.M > 0 && u.N > 0)
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void bcgs_prepare_kernel(const tmf_bcgs_desc* 
 extern "C" int64_t tmf_bcgs_work_bytes(const tmf_bcgs_desc* h_desc, int nprob) {
   int64_t tc = 0, tu = 0;
   for (int i = 0; i < nprob; ++i) {
-    tc += (h_desc[i].c_end + 63) / 64;
+    tc += (h_desc[i].c_end + 15) / 16;
     tu += (h_desc[i].rows + 63) / 64;
   }
   return (int64_t)nprob * (2 * sizeof(tmf_gemm_desc) + sizeof(tmf_panel_desc)) + 16 * (tc + tu) + 1024;
@@ -99,7 +99,7 @@ extern "C" int tmf_bcgs_batched(int dtype, const tmf_bcgs_desc* d_desc, const tm
     max_rows = h_desc[i].rows > max_rows ? h_desc[i].rows : max_rows;
     const int span = h_desc[i].c_end - h_desc[i].c_begin;
     max_span = span > max_span ? span : max_span;
-    cap_c += (h_desc[i].c_end + 63) / 64;
+    cap_c += (h_desc[i].c_end + 15) / 16;
   }
   int w = 16;  // widest panel that fits the LDS of orth_panel_kernel
   while ((size_t)max_rows * w * elem + 1024 > 150 * 1024 && w > 1) w >>= 1;
@@ -122,7 +122,7 @@ extern "C" int tmf_bcgs_batched(int dtype, const tmf_bcgs_desc* d_desc, const tm
       if (d.c_end - d.c_begin <= t || d.rows <= 0) continue;
       const int j = d.c_begin + t - (t0 < 0 ? 0 : d.c_begin + t0);
       if (j > 0) {
-        nc += (j + 63) / 64;
+        nc += (j + 15) / 16;
         nu += (d.rows + 63) / 64;
       }
     }
@@ -130,7 +130,7 @@ extern "C" int tmf_bcgs_batched(int dtype, const tmf_bcgs_desc* d_desc, const tm
                        tiles_coef, tiles_upd);
     int st = check_hip(hipGetLastError(), "tmf_bcgs_batched prepare");
     for (int p = 0; p < passes && nc > 0 && !st; ++p) {
-      st = tmf_gemm_batched(dtype, 1, 1.0, 0.0, g_coef, tiles_coef, (int)nc, 16, stream);
+      st = tmf_gemm_tall_batched(dtype, 1.0, 0.0, g_coef, tiles_coef, (int)nc, stream);
       if (!st) st = tmf_gemm_batched(dtype, 0, -1.0, 1.0, g_upd, tiles_upd, (int)nu, 16, stream);
     }
     return st;

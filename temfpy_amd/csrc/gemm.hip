@@ -158,6 +158,103 @@ __global__ __launch_bounds__(256) void gemm_kernel(const tmf_gemm_desc* __restri
       }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tall-skinny variant:  C (M x N, N <= 16) = alpha * A^H B + beta * C  with a long contraction
+// (K = rows of an orbital slab) and few output columns - the coefficient products Q^H P of the blocked
+// Gram-Schmidt.  The general kernel above advances 16 rows per iteration and exposes one memory
+// latency per iteration (measured 2.9 us x K/16, and its 64-column A tile is mostly padding when
+// M < 64); here a workgroup owns a 16 x 16 output tile and stages 64 rows per iteration (1 KiB
+// contiguous per column), the four waves split the 64 rows between them and their partial tiles are
+// summed in a fixed order at the end (deterministic).
+// ---------------------------------------------------------------------------------------------
+constexpr int TK = 64;
+constexpr int LDK = TK + 1;
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tall_kernel(const tmf_gemm_desc* __restrict__ desc,
+                                                        const int32_t* __restrict__ tiles, double alpha, double beta) {
+  constexpr int CP = sc<T>::cplx;
+  constexpr int NP = CP ? 2 : 1;
+  __shared__ double As[NP][16][LDK];
+  __shared__ double Bs[NP][16][LDK];
+  __shared__ double red[4][NP][4][64];
+
+  const int4 tl = reinterpret_cast<const int4*>(tiles)[blockIdx.x];
+  const tmf_gemm_desc d = desc[tl.x];
+  const int m0 = tl.y * 16;
+  const T* __restrict__ A = reinterpret_cast<const T*>(d.A);
+  const T* __restrict__ B = reinterpret_cast<const T*>(d.B);
+  T* __restrict__ C = reinterpret_cast<T*>(d.C);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  d4 acc[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) acc[p] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  for (int k0 = 0; k0 < d.K; k0 += TK) {
+    const int kk = lane;  // row inside the chunk; wave = column group
+#pragma unroll
+    for (int c = wave; c < 16; c += 4) {
+      T va = sc<T>::zero(), vb = sc<T>::zero();
+      if (k0 + kk < d.K) {
+        if (m0 + c < d.M) va = A[(size_t)(k0 + kk) + (size_t)(m0 + c) * d.lda];
+        if (c < d.N) vb = B[(size_t)(k0 + kk) + (size_t)c * d.ldb];
+      }
+      if constexpr (CP) {
+        As[0][c][kk] = va.x, As[1][c][kk] = -va.y;  // conjugate
+        Bs[0][c][kk] = vb.x, Bs[1][c][kk] = vb.y;
+      } else {
+        As[0][c][kk] = va;
+        Bs[0][c][kk] = vb;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kc = wave * 16; kc < wave * 16 + 16; kc += 4) {
+      const double ar = As[0][l15][kc + l4], br = Bs[0][l15][kc + l4];
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(br, ar, acc[0], 0, 0, 0);
+      if constexpr (CP) {
+        const double ai = As[1][l15][kc + l4], bi = Bs[1][l15][kc + l4];
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bi, ai, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi, ar, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(br, ai, acc[1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][p][r][lane] = acc[p][r];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + l15, n = l4 + 4 * r;   // lane holds C[m = l15][n = l4 + 4 r]
+      double vr = ((red[0][0][r][lane] + red[1][0][r][lane]) + red[2][0][r][lane]) + red[3][0][r][lane];
+      double vi = 0.0;
+      if constexpr (CP) vi = ((red[0][1][r][lane] + red[1][1][r][lane]) + red[2][1][r][lane]) + red[3][1][r][lane];
+      if (m < d.M && n < d.N) {
+        T* c = C + (size_t)m + (size_t)n * d.ldc;
+        if constexpr (CP) {
+          cd v = make_cd(alpha * vr, alpha * vi);
+          if (beta != 0.0) {
+            const cd o = *c;
+            v.x = fma(beta, o.x, v.x);
+            v.y = fma(beta, o.y, v.y);
+          }
+          *c = v;
+        } else {
+          double v = alpha * vr;
+          if (beta != 0.0) v = fma(beta, *c, v);
+          *c = v;
+        }
+      }
+    }
+  }
+}
+
 template <typename T>
 static int launch(int opA, double alpha, double beta, const tmf_gemm_desc* d, const int32_t* t, int nt, int tile_n,
                   hipStream_t s) {
@@ -186,4 +283,18 @@ extern "C" int tmf_gemm_batched(int dtype, int opA, double alpha, double beta, c
   if (dtype == TMF_F64) return tmf::launch<double>(opA, alpha, beta, d_desc, d_tiles, ntiles, tile_n, s);
   tmf::set_error("tmf_gemm_batched: bad dtype %d", dtype);
   return TMF_E_ARG;
+}
+
+extern "C" int tmf_gemm_tall_batched(int dtype, double alpha, double beta, const tmf_gemm_desc* d_desc,
+                                     const int32_t* d_tiles, int ntiles, void* stream) {
+  if (ntiles <= 0) return TMF_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 g(ntiles), b(256);
+  if (dtype == TMF_C128) hipLaunchKernelGGL((tmf::gemm_tall_kernel<tmf::cd>), g, b, 0, s, d_desc, d_tiles, alpha, beta);
+  else if (dtype == TMF_F64) hipLaunchKernelGGL((tmf::gemm_tall_kernel<double>), g, b, 0, s, d_desc, d_tiles, alpha, beta);
+  else {
+    tmf::set_error("tmf_gemm_tall_batched: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+  return tmf::check_hip(hipGetLastError(), "tmf_gemm_tall_batched launch");
 }

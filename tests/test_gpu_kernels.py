@@ -585,3 +585,30 @@ def test_jacobi_block_variant_beyond_64(eng, cplx, left_only):
             np.testing.assert_allclose(s, sref, rtol=0, atol=1e-13)
             np.testing.assert_allclose(Out.conj().T @ Out, np.eye(p), atol=1e-12)
             np.testing.assert_allclose((Out * s) @ Out.conj().T, X, atol=1e-12)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_gemm_tall_batched(eng, cplx):
+    """tmf_gemm_tall_batched (C = alpha A^H B + beta C, N <= 16, long K; 16 x 16 tiles, 64 rows per step)
+    against NumPy, ragged shapes incl. K not a multiple of 64 and M not a multiple of 16."""
+    setup(eng, cplx)
+    nat = eng.nat
+    rng = np.random.default_rng(31)
+    shapes = [(56, 8, 768), (1, 1, 1), (17, 16, 65), (290, 16, 300), (33, 5, 64), (16, 16, 1023)]
+    for alpha, beta in ((1.0, 0.0), (-0.5, 1.0)):
+        As = [rnd(rng, (K, M), cplx) for M, N, K in shapes]
+        Bs = [rnd(rng, (K, N), cplx) for M, N, K in shapes]
+        Cs = [rnd(rng, (M, N), cplx) for M, N, K in shapes]
+        dA, dB, dC = [dev(eng, a) for a in As], [dev(eng, b) for b in Bs], [dev(eng, c) for c in Cs]
+        d = np.zeros(len(shapes), nat.gemm_desc)
+        tiles = []
+        for i, (M, N, K) in enumerate(shapes):
+            d[i] = (dA[i][1], dB[i][1], dC[i][1], M, N, K, K, K, M)
+            tiles += [(i, t, 0, 0) for t in range(_cdiv(M, 16))]
+        t_d, t_t = eng._up(d), eng._up(np.array(tiles, np.int32))
+        nat.check(eng.lib.tmf_gemm_tall_batched(eng.dtype, alpha, beta, t_d.data_ptr(), t_t.data_ptr(), len(tiles),
+                                                eng.stream), "tall")
+        torch.cuda.synchronize()
+        for (M, N, K), A, B, C0, dc in zip(shapes, As, Bs, Cs, dC):
+            ref = alpha * (A.conj().T @ B) + beta * C0
+            np.testing.assert_allclose(back(dc[0], (M, N)), ref, rtol=0, atol=1e-12 * max(1.0, np.abs(ref).max()) * K**0.5)
