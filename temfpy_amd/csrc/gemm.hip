@@ -57,51 +57,83 @@ __global__ __launch_bounds__(256) void gemm_kernel(const tmf_gemm_desc* __restri
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[p][i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
-  for (int k0 = 0; k0 < d.K; k0 += KT) {
-    // ---- stage A tile (64 x 16) ---------------------------------------------------
+  // Software pipeline: the global loads of tile k+1 are issued into registers before the MFMAs of
+  // tile k, so that one memory latency is hidden behind the other's arithmetic (and behind the other
+  // workgroups of the CU) instead of being exposed once per 16 rows of K.
+  constexpr int NA = TM * KT / 256, NB = (TN * KT + 255) / 256;
+  T ra[NA], rb[NB];
+  auto load_regs = [&](const int k0) {
     if (OPA == 0) {
       const int i = tid & 63;
 #pragma unroll
-      for (int kk = tid >> 6; kk < KT; kk += 4) {
-        T v = sc<T>::zero();
-        if (m0 + i < d.M && k0 + kk < d.K) v = A[(size_t)(m0 + i) + (size_t)(k0 + kk) * d.lda];
+      for (int q = 0; q < NA; ++q) {
+        const int kk = (tid >> 6) + 4 * q;
+        ra[q] = (m0 + i < d.M && k0 + kk < d.K) ? A[(size_t)(m0 + i) + (size_t)(k0 + kk) * d.lda] : sc<T>::zero();
+      }
+    } else {
+      const int kk = tid & 15;
+#pragma unroll
+      for (int q = 0; q < NA; ++q) {
+        const int i = (tid >> 4) + 16 * q;
+        ra[q] = (m0 + i < d.M && k0 + kk < d.K) ? A[(size_t)(k0 + kk) + (size_t)(m0 + i) * d.lda] : sc<T>::zero();
+      }
+    }
+    const int kk = tid & 15;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int j = (tid >> 4) + 16 * q;
+      rb[q] = (j < TN && n0 + j < d.N && k0 + kk < d.K) ? B[(size_t)(k0 + kk) + (size_t)(n0 + j) * d.ldb] : sc<T>::zero();
+    }
+  };
+  auto store_regs = [&]() {
+    if (OPA == 0) {
+      const int i = tid & 63;
+#pragma unroll
+      for (int q = 0; q < NA; ++q) {
+        const int kk = (tid >> 6) + 4 * q;
         if constexpr (CP) {
-          As[0][i][kk] = v.x;
-          As[1][i][kk] = v.y;
+          As[0][i][kk] = ra[q].x;
+          As[1][i][kk] = ra[q].y;
         } else {
-          As[0][i][kk] = v;
+          As[0][i][kk] = ra[q];
         }
       }
     } else {
       const int kk = tid & 15;
 #pragma unroll
-      for (int i = tid >> 4; i < TM; i += 16) {
-        T v = sc<T>::zero();
-        if (m0 + i < d.M && k0 + kk < d.K) v = A[(size_t)(k0 + kk) + (size_t)(m0 + i) * d.lda];
+      for (int q = 0; q < NA; ++q) {
+        const int i = (tid >> 4) + 16 * q;
         if constexpr (CP) {
-          As[0][i][kk] = v.x;
-          As[1][i][kk] = -v.y;  // conjugate
+          As[0][i][kk] = ra[q].x;
+          As[1][i][kk] = -ra[q].y;  // conjugate
         } else {
-          As[0][i][kk] = v;
+          As[0][i][kk] = ra[q];
         }
       }
     }
-    // ---- stage B tile (16 x TN) ---------------------------------------------------
-    {
-      const int kk = tid & 15;
+    const int kk = tid & 15;
 #pragma unroll
-      for (int j = tid >> 4; j < TN; j += 16) {
-        T v = sc<T>::zero();
-        if (n0 + j < d.N && k0 + kk < d.K) v = B[(size_t)(k0 + kk) + (size_t)(n0 + j) * d.ldb];
+    for (int q = 0; q < NB; ++q) {
+      const int j = (tid >> 4) + 16 * q;
+      if (j < TN) {
         if constexpr (CP) {
-          Bs[0][j][kk] = v.x;
-          Bs[1][j][kk] = v.y;
+          Bs[0][j][kk] = rb[q].x;
+          Bs[1][j][kk] = rb[q].y;
         } else {
-          Bs[0][j][kk] = v;
+          Bs[0][j][kk] = rb[q];
         }
       }
     }
-    __syncthreads();
+  };
+
+  if (d.K > 0) {
+    load_regs(0);
+    store_regs();
+  }
+  __syncthreads();
+  for (int k0 = 0; k0 < d.K; k0 += KT) {
+    const bool more = k0 + KT < d.K;
+    if (more) load_regs(k0 + KT);
 #pragma unroll
     for (int kc = 0; kc < KT; kc += 4) {
       double ar[MI], ai[MI], br[NI], bi[NI];
@@ -128,6 +160,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const tmf_gemm_desc* __restri
         }
     }
     __syncthreads();
+    if (more) {
+      store_regs();
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: lane holds C[m = l15][n = l4 + 4 r] of each 16 x 16 sub-tile -----------
