@@ -93,6 +93,8 @@ typedef struct {
 } tmf_bcgs_desc;             /* 40 bytes */
 int64_t tmf_bcgs_work_bytes(const tmf_bcgs_desc* h_desc, int nprob);
 int tmf_bcgs_batched(int dtype, const tmf_bcgs_desc* d_desc, const tmf_bcgs_desc* h_desc, int nprob, int passes,
+                     int flags /* bit 0: Cholesky-QR (twice) inside the panels instead of the LDS Gram-Schmidt panel
+                                  kernel - for well-conditioned slabs (filled-orbital bases) only */,
                      void* d_work, int64_t work_bytes, void* stream);
 
 /* One-sided (Hestenes) Jacobi on a p x p matrix X held in LDS: X V = U diag(s).

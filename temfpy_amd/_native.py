@@ -108,7 +108,7 @@ def load():
     lib.tmf_jacobi_block_batched.argtypes = [i32, i32, vp, i32, i32, vp, vp]
     lib.tmf_bcgs_work_bytes.argtypes = [vp, i32]
     lib.tmf_bcgs_work_bytes.restype = i64
-    lib.tmf_bcgs_batched.argtypes = [i32, vp, vp, i32, i32, vp, i64, vp]
+    lib.tmf_bcgs_batched.argtypes = [i32, vp, vp, i32, i32, i32, vp, i64, vp]
     lib.tmf_lu_schur_batched.argtypes = [i32, vp, i32, i32, vp]
     lib.tmf_det_gather_batched.argtypes = [i32, i32, vp, i32, i32, vp]
     lib.tmf_det_reduced_batched.argtypes = [i32, i32, vp, i32, i32, vp]

@@ -20,7 +20,8 @@ __global__ __launch_bounds__(256) void bcgs_prepare_kernel(const tmf_bcgs_desc* 
                                                            int w, int t0, size_t elem, tmf_gemm_desc* __restrict__ g_coef,
                                                            tmf_gemm_desc* __restrict__ g_upd,
                                                            tmf_panel_desc* __restrict__ pd, int32_t* __restrict__ tiles_coef,
-                                                           int32_t* __restrict__ tiles_upd) {
+                                                           int32_t* __restrict__ tiles_upd, tmf_gemm_desc* __restrict__ g_gram,
+                                                           int32_t* __restrict__ tiles_gram) {
   __shared__ int scan_c[257], scan_u[257];
   const int tid = threadIdx.x;
   const int per = (nprob + 255) / 256;
@@ -46,6 +47,13 @@ __global__ __launch_bounds__(256) void bcgs_prepare_kernel(const tmf_bcgs_desc* 
     tmf_panel_desc p;
     p.A = colp, p.norms = d.norms ? d.norms + 8ull * t : 0ull, p.n = act ? d.rows : 0, p.w = wj, p.lda = d.ld, p.pad = 0;
     pd[i] = p;
+    if (g_gram) {  // Gram matrix of the panel (Cholesky-QR mode): wj x wj into the slab's scratch, one tile each
+      tmf_gemm_desc g;
+      g.A = colp, g.B = colp, g.C = d.scratch, g.M = wj, g.N = wj, g.K = act ? d.rows : 0, g.lda = d.ld, g.ldb = d.ld;
+      g.ldc = wj > 1 ? wj : 1;
+      g_gram[i] = g;
+      tiles_gram[4 * i] = i, tiles_gram[4 * i + 1] = 0, tiles_gram[4 * i + 2] = 0, tiles_gram[4 * i + 3] = 0;
+    }
     nc += (c.M > 0 && c.N > 0) ? (c.M + 15) / 16 : 0;   // tall kernel: 16 x 16 output tiles
     nu += (u.M > 0 && u.N > 0) ? (u.M + 63) / 64 : 0;
   }
@@ -69,6 +77,83 @@ __global__ __launch_bounds__(256) void bcgs_prepare_kernel(const tmf_bcgs_desc* 
   }
 }
 
+// Cholesky-QR step of one panel per workgroup: G = P^H P (w x w, in the slab's scratch) -> upper R with
+// G = R^H R -> X = R^{-1} -> P <- P X.  A pivot below 1e-13 of its diagonal entry (column dependent on the
+// earlier ones to rounding) gives a ZERO column, like the LDS panel kernel.  Run twice per panel
+// ("CholQR2"): the first pass leaves an orthogonality error ~ eps * cond(P)^2, the second removes it.
+// Only for well-conditioned panels (the filled-orbital bases); the range-finder slabs, whose columns
+// can be pure rounding noise, keep the Gram-Schmidt panel kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void cholqr_apply_kernel(const tmf_panel_desc* __restrict__ pd,
+                                                           const tmf_gemm_desc* __restrict__ gram) {
+  const tmf_panel_desc d = pd[blockIdx.x];
+  const int n = d.n, w = d.w;
+  if (n <= 0 || w <= 0) return;
+  __shared__ T R[16][17], X[16][17];
+  __shared__ int dropped[16];
+  const T* __restrict__ G = reinterpret_cast<const T*>(gram[blockIdx.x].C);
+  const int ldg = gram[blockIdx.x].ldc;
+  const int tid = threadIdx.x;
+  if (tid < 256) {
+    const int r = tid & 15, c = tid >> 4;
+    R[r][c] = (r < w && c < w) ? G[(size_t)r + (size_t)c * ldg] : sc<T>::zero();
+    X[r][c] = sc<T>::zero();
+  }
+  __syncthreads();
+  // Cholesky (row by row of the upper factor), thread i owns column i
+  for (int j = 0; j < w; ++j) {
+    if (tid < 16) {
+      const int i = tid;
+      if (i >= j && i < w) {
+        T v = R[j][i];   // G_ji
+        for (int k = 0; k < j; ++k) v = sc<T>::fms(v, sc<T>::conj(R[k][j]), R[k][i]);
+        R[j][i] = v;     // unscaled: divided by the pivot below
+      }
+    }
+    __syncthreads();
+    if (tid < 16) {
+      const int i = tid;
+      const double piv = sc<T>::real(R[j][j]);
+      const double g0 = sc<T>::real(reinterpret_cast<const T*>(G)[(size_t)j + (size_t)j * ldg]);
+      const bool drop = !(piv > 1e-13 * g0) || !(g0 > 0.0);
+      if (i == 0) dropped[j] = drop;
+      if (i >= j && i < w) {
+        if (drop) R[j][i] = (i == j) ? sc<T>::one() : sc<T>::zero();
+        else R[j][i] = sc<T>::scale(R[j][i], 1.0 / sqrt(piv));
+      }
+    }
+    __syncthreads();
+  }
+  // X = R^{-1} (upper triangular), thread c owns column c
+  if (tid < 16 && tid < w) {
+    const int c = tid;
+    if (!dropped[c]) {
+      X[c][c] = sc<T>::scale(sc<T>::one(), 1.0 / sc<T>::real(R[c][c]));
+      for (int i = c - 1; i >= 0; --i) {
+        T acc = sc<T>::zero();
+        for (int k = i + 1; k <= c; ++k) acc = sc<T>::fmac(acc, R[i][k], X[k][c]);
+        X[i][c] = sc<T>::scale(acc, -1.0 / sc<T>::real(R[i][i]));
+      }
+    }
+  }
+  __syncthreads();
+  T* __restrict__ P = reinterpret_cast<T*>(d.A);
+  for (int r = tid; r < n; r += 256) {
+    T x[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) x[c] = c < w ? P[(size_t)r + (size_t)c * d.lda] : sc<T>::zero();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c < w) {
+        T y = sc<T>::zero();
+#pragma unroll
+        for (int k = 0; k <= c; ++k) y = sc<T>::fmac(y, x[k], X[k][c]);
+        P[(size_t)r + (size_t)c * d.lda] = y;
+      }
+    }
+  }
+}
+
 }  // namespace tmf
 
 extern "C" int64_t tmf_bcgs_work_bytes(const tmf_bcgs_desc* h_desc, int nprob) {
@@ -77,11 +162,11 @@ extern "C" int64_t tmf_bcgs_work_bytes(const tmf_bcgs_desc* h_desc, int nprob) {
     tc += (h_desc[i].c_end + 15) / 16;
     tu += (h_desc[i].rows + 63) / 64;
   }
-  return (int64_t)nprob * (2 * sizeof(tmf_gemm_desc) + sizeof(tmf_panel_desc)) + 16 * (tc + tu) + 1024;
+  return (int64_t)nprob * (3 * sizeof(tmf_gemm_desc) + sizeof(tmf_panel_desc) + 16) + 16 * (tc + tu) + 1024;
 }
 
 extern "C" int tmf_bcgs_batched(int dtype, const tmf_bcgs_desc* d_desc, const tmf_bcgs_desc* h_desc, int nprob,
-                                int passes, void* d_work, int64_t work_bytes, void* stream) {
+                                int passes, int flags, void* d_work, int64_t work_bytes, void* stream) {
   using namespace tmf;
   if (nprob <= 0) return TMF_OK;
   if (dtype != TMF_C128 && dtype != TMF_F64) {
@@ -101,15 +186,32 @@ extern "C" int tmf_bcgs_batched(int dtype, const tmf_bcgs_desc* d_desc, const tm
     max_span = span > max_span ? span : max_span;
     cap_c += (h_desc[i].c_end + 15) / 16;
   }
+  const bool cholqr = (flags & 1) != 0;   // Cholesky-QR panels (no LDS panel: always 16 wide)
   int w = 16;  // widest panel that fits the LDS of orth_panel_kernel
-  while ((size_t)max_rows * w * elem + 1024 > 150 * 1024 && w > 1) w >>= 1;
+  while (!cholqr && (size_t)max_rows * w * elem + 1024 > 150 * 1024 && w > 1) w >>= 1;
   char* wk = static_cast<char*>(d_work);
   tmf_gemm_desc* g_coef = reinterpret_cast<tmf_gemm_desc*>(wk);
   tmf_gemm_desc* g_upd = g_coef + nprob;
   tmf_panel_desc* pd = reinterpret_cast<tmf_panel_desc*>(g_upd + nprob);
   int32_t* tiles_coef = reinterpret_cast<int32_t*>(pd + nprob);
   int32_t* tiles_upd = tiles_coef + 4 * cap_c;
+  int64_t cap_u = 0;
+  for (int i = 0; i < nprob; ++i) cap_u += (h_desc[i].rows + 63) / 64;
+  tmf_gemm_desc* g_gram = reinterpret_cast<tmf_gemm_desc*>(tiles_upd + 4 * cap_u);
+  int32_t* tiles_gram = reinterpret_cast<int32_t*>(g_gram + nprob);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  auto orth_panel = [&]() -> int {
+    if (!cholqr) return tmf_orth_panel_batched(dtype, pd, nprob, max_rows, w, stream);
+    for (int rep = 0; rep < 2; ++rep) {
+      int st = tmf_gemm_tall_batched(dtype, 1.0, 0.0, g_gram, tiles_gram, nprob, stream);
+      if (st) return st;
+      if (dtype == TMF_C128) hipLaunchKernelGGL(cholqr_apply_kernel<cd>, dim3(nprob), dim3(256), 0, s, pd, g_gram);
+      else hipLaunchKernelGGL(cholqr_apply_kernel<double>, dim3(nprob), dim3(256), 0, s, pd, g_gram);
+      st = check_hip(hipGetLastError(), "tmf_bcgs_batched cholqr");
+      if (st) return st;
+    }
+    return TMF_OK;
+  };
   // Outer blocks of 16 columns are projected against everything before them in one go (the GEMMs are
   // bound by streaming those columns, so fewer, wider projections = less traffic); tall slabs whose
   // LDS panel is narrower (w < 16) then orthonormalise the block panel by panel, projecting each
@@ -127,7 +229,7 @@ extern "C" int tmf_bcgs_batched(int dtype, const tmf_bcgs_desc* d_desc, const tm
       }
     }
     hipLaunchKernelGGL(bcgs_prepare_kernel, dim3(1), dim3(256), 0, s, d_desc, nprob, t, wb, t0, elem, g_coef, g_upd, pd,
-                       tiles_coef, tiles_upd);
+                       tiles_coef, tiles_upd, cholqr ? g_gram : (tmf_gemm_desc*)nullptr, tiles_gram);
     int st = check_hip(hipGetLastError(), "tmf_bcgs_batched prepare");
     for (int p = 0; p < passes && nc > 0 && !st; ++p) {
       st = tmf_gemm_tall_batched(dtype, 1.0, 0.0, g_coef, tiles_coef, (int)nc, stream);
@@ -139,14 +241,14 @@ extern "C" int tmf_bcgs_batched(int dtype, const tmf_bcgs_desc* d_desc, const tm
     int st = project(t, wo, -1);
     if (st) return st;
     if (w == wo) {  // the block is one LDS panel: the descriptors of `project` are the panel's
-      st = tmf_orth_panel_batched(dtype, pd, nprob, max_rows, w, stream);
+      st = orth_panel();
       if (st) return st;
       continue;
     }
     for (int ti = 0; ti < wo && t + ti < max_span; ti += w) {
       st = project(t + ti, w, t);
       if (st) return st;
-      st = tmf_orth_panel_batched(dtype, pd, nprob, max_rows, w, stream);
+      st = orth_panel();
       if (st) return st;
     }
   }

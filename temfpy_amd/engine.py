@@ -208,12 +208,13 @@ class Engine:
             fl = float((d["M"].astype(np.float64) * d["N"] * d["K"]).sum()) * (8.0 if self.dtype == nat.TMF_C128 else 2.0)
             self.gemm_events.append((ev0, ev1, fl))
 
-    def bcgs2(self, base, rows, ld, c_begin, c_end, scratch_ptr, passes=2):
+    def bcgs2(self, base, rows, ld, c_begin, c_end, scratch_ptr, passes=2, cholqr=False):
         """Orthonormalise columns [c_begin, c_end) of every matrix against all columns before
         them (blocked classical Gram-Schmidt with re-orthogonalisation, tmf_bcgs_batched: the panel
         loop and its descriptors live in C++ / on the device).
         passes=2 for well-conditioned slabs; passes=3 for numerically rank-deficient ones
-        (range finder), where a second pass still acts on rounding noise."""
+        (range finder), where a second pass still acts on rounding noise.  cholqr: Cholesky-QR inside the
+        panels (well-conditioned slabs only: the filled-orbital bases)."""
         base, rows, ld, c_begin, c_end, scratch_ptr = (np.asarray(x, np.int64) for x in
                                                        (base, rows, ld, c_begin, c_end, scratch_ptr))
         keep = np.nonzero((rows > 0) & (c_end > c_begin))[0]
@@ -240,7 +241,7 @@ class Engine:
         d_work = self.torch.empty(wb, dtype=self.torch.uint8, device=self.device)
         self._keep.append(d_work)
         nat.check(self.lib.tmf_bcgs_batched(self.dtype, t_bd.data_ptr(), nat._p(bd), base.size, passes,
-                                            d_work.data_ptr(), wb, self.stream), "tmf_bcgs_batched")
+                                            1 if cholqr else 0, d_work.data_ptr(), wb, self.stream), "tmf_bcgs_batched")
 
     def jacobi(self, X, V, s, count, thresh2, p, ldx, ldv, left_only=False):
         """One-sided Jacobi per problem.  ``left_only``: ``V`` receives the normalised LEFT singular
@@ -427,6 +428,7 @@ class Engine:
                     keep=(d_Y, d_U0, d_W1, d_Bt, d_Q2, d_R, d_Z, d_T, d_X, d_sig, d_scr))
 
     range_floor_tol = 1e-11
+    filled_cholqr = os.environ.get("TMF_FILLED_CHOLQR", "1") == "1"   # panel method of the filled-basis QR
 
     def _fetch_async(self, tensors):
         """Asynchronous device -> pinned host copies of small result tensors; returns (wait handle, NumPy
@@ -818,7 +820,7 @@ class Engine:
             d_scr2 = self._alloc(int((ncolV.max() + 1) * PANEL_W) * ncs)
             scr2 = d_scr2.data_ptr() + np.arange(ncs) * int((ncolV.max() + 1) * PANEL_W) * el
             has = nf > 0
-            self.bcgs2(Vp[has], n[has], ld1[has], k[has], ncolV[has], scr2[has])
+            self.bcgs2(Vp[has], n[has], ld1[has], k[has], ncolV[has], scr2[has], cholqr=self.filled_cholqr)
         # self-check of the centre cut (testing.py:131-177; slater.py:419-420 runs it only there)
         chk_names, d_chk = [], None
         if self.checks and has_centre and doE[centre_L]:

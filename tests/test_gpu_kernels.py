@@ -68,7 +68,9 @@ def test_gemm_batched(eng, cplx, opA):
 
 
 @pytest.mark.parametrize("cplx", [True, False])
-def test_bcgs2_orthonormalises_and_keeps_span(eng, cplx):
+@pytest.mark.parametrize("cholqr", [False, True])
+def test_bcgs2_orthonormalises_and_keeps_span(eng, cplx, cholqr):
+    """tmf_bcgs_batched with both panel methods (LDS Gram-Schmidt panel kernel / Cholesky-QR twice)."""
     setup(eng, cplx)
     rng = np.random.default_rng(2)
     cases = [(40, 0, 40), (300, 0, 64), (513, 5, 70), (100, 10, 11), (1000, 0, 33), (17, 0, 1)]
@@ -81,7 +83,7 @@ def test_bcgs2_orthonormalises_and_keeps_span(eng, cplx):
         dm.append(dev(eng, A))
     scr = eng._alloc(len(cases) * 80 * 16)
     eng.bcgs2([d[1] for d in dm], [c[0] for c in cases], [c[0] for c in cases], [c[1] for c in cases],
-              [c[2] for c in cases], scr.data_ptr() + np.arange(len(cases)) * 80 * 16 * eng.elem)
+              [c[2] for c in cases], scr.data_ptr() + np.arange(len(cases)) * 80 * 16 * eng.elem, cholqr=cholqr)
     torch.cuda.synchronize()
     for (n, c0, c1), A, d in zip(cases, mats, dm):
         Q = back(d[0], (n, c1))
@@ -94,14 +96,15 @@ def test_bcgs2_orthonormalises_and_keeps_span(eng, cplx):
 
 
 @pytest.mark.parametrize("cplx", [True, False])
-def test_bcgs2_exactly_rank_deficient_gives_zero_columns(eng, cplx):
+@pytest.mark.parametrize("cholqr", [False, True])
+def test_bcgs2_exactly_rank_deficient_gives_zero_columns(eng, cplx, cholqr):
     setup(eng, cplx)
     rng = np.random.default_rng(3)
     A = np.zeros((50, 8), complex if cplx else float)
     A[:, :3] = rnd(rng, (50, 3), cplx)
     d = dev(eng, A)
     scr = eng._alloc(8 * 16)
-    eng.bcgs2([d[1]], [50], [50], [0], [8], np.array([scr.data_ptr()]))
+    eng.bcgs2([d[1]], [50], [50], [0], [8], np.array([scr.data_ptr()]), cholqr=cholqr)
     torch.cuda.synchronize()
     Q = back(d[0], (50, 8))
     G = Q.conj().T @ Q
