@@ -115,7 +115,11 @@ __global__ __launch_bounds__(256) void cholqr_apply_kernel(const tmf_panel_desc*
       const int i = tid;
       const double piv = sc<T>::real(R[j][j]);
       const double g0 = sc<T>::real(reinterpret_cast<const T*>(G)[(size_t)j + (size_t)j * ldg]);
-      const bool drop = !(piv > 1e-13 * g0) || !(g0 > 0.0);
+      bool drop = !(piv > 1e-13 * g0) || !(g0 > 0.0);
+      if (d.norms) {  // residual below 1e-14 of the column's norm BEFORE any projection: rounding noise
+        const double raw = reinterpret_cast<const double*>(d.norms)[j];
+        drop = drop || !(piv > 1e-28 * raw * raw);
+      }
       if (i == 0) dropped[j] = drop;
       if (i >= j && i < w) {
         if (drop) R[j][i] = (i == j) ? sc<T>::one() : sc<T>::zero();
