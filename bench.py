@@ -210,7 +210,8 @@ def main():
         if dom is not None:
             avg_ms = float(np.mean(det_ms[dom]))
             ach = det_flops[dom] / (avg_ms * 1e-3) / 1e12
-            kname = (f"tmf::reduced_det_kernel<tmf::cd, {str(dom)[:-1]}>" if str(dom).endswith("r")
+            kname = ("tmf::ppt_det_kernel<tmf::cd>" if dom == "ppt"
+                     else f"tmf::reduced_det_kernel<tmf::cd, {str(dom)[:-1]}>" if str(dom).endswith("r")
                      else f"tmf::det_kernel<tmf::cd, {dom}, G>")
             traffic = None  # HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)
             pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")  # made by tools/pmc_traffic.py

@@ -72,7 +72,7 @@ SYMBOLS = [
     "tmf_last_error", "tmf_version", "tmf_device_count", "tmf_gemm_batched", "tmf_gemm_tall_batched", "tmf_orth_panel_batched",
     "tmf_bcgs_work_bytes", "tmf_bcgs_batched", "tmf_jacobi_batched", "tmf_svd_left_batched",
     "tmf_jacobi_block_batched", "tmf_nested_products_batched", "tmf_recon_error_batched", "tmf_lu_schur_batched",
-    "tmf_det_gather_batched", "tmf_det_reduced_batched", "tmf_transpose", "tmf_fill_normal",
+    "tmf_det_gather_batched", "tmf_det_reduced_batched", "tmf_det_ppt_batched", "tmf_transpose", "tmf_fill_normal",
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_column_norms_batched", "tmf_cut_vectors",
     "tmf_site_prepare", "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_pf_gather_batched",
     "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched",
@@ -111,6 +111,7 @@ def load():
     lib.tmf_bcgs_batched.argtypes = [i32, vp, vp, i32, i32, i32, vp, i64, vp]
     lib.tmf_lu_schur_batched.argtypes = [i32, vp, i32, i32, vp]
     lib.tmf_det_gather_batched.argtypes = [i32, i32, vp, i32, i32, vp]
+    lib.tmf_det_ppt_batched.argtypes = [i32, vp, i32, i32, vp]
     lib.tmf_det_reduced_batched.argtypes = [i32, i32, vp, i32, i32, vp]
     lib.tmf_pf_gather_batched.argtypes = [i32, i32, vp, i32, i32, vp]
     for fn in (lib.tmf_nambu_assemble_batched, lib.tmf_nambu_w_batched, lib.tmf_pf_matrix_batched):
@@ -206,3 +207,9 @@ def reduced_det_lds(el, n, sb, sk, nsk, na):
     a16 = lambda x: (x + 15) & ~15  # noqa: E731
     return (a16(sb * sk * el) + a16(nsk * n) + a16(nsk * 8) + a16(na * n)
             + 4 * (((n | 1) * sk + 264) * el + 576) + 16)
+
+
+def ppt_det_lds(el, sb, sk, nsk, na):
+    """Dynamic LDS bytes of one tmf_det_ppt_batched tile (layout: csrc/det_ppt.hip)."""
+    a16 = lambda x: (x + 15) & ~15  # noqa: E731
+    return a16(a16(sb * sk * el) + (nsk + na) * 8) + 4 * (264 * el + 288)

@@ -47,6 +47,8 @@ struct sc<double> {
   }
   __device__ static inline double real(double a) { return a; }
   __device__ static inline double from_real(double a) { return a; }
+  __device__ static inline double from2(double re, double) { return re; }
+  __device__ static inline double imag(double) { return 0.0; }
   __device__ static inline double neg(double a) { return -a; }
 };
 
@@ -86,6 +88,8 @@ struct sc<cd> {
   }
   __device__ static inline double real(cd a) { return a.x; }
   __device__ static inline cd from_real(double a) { return make_cd(a, 0.0); }
+  __device__ static inline cd from2(double re, double im) { return make_cd(re, im); }
+  __device__ static inline double imag(cd a) { return a.y; }
   __device__ static inline cd neg(cd a) { return make_cd(-a.x, -a.y); }
 };
 

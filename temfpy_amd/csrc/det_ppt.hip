@@ -1,0 +1,404 @@
+// Gathered determinants of a whole charge sector from ONE pivoted exchange of its matrix.
+//
+// Reference: slater.py:828-869 computes every minor det(M[rows(a)][:, cols(b)]) of a sector from
+// scratch; det_reduced.hip shares one Gauss-Jordan elimination per bra row-set a.  Here the sharing is
+// two-sided.  Pivoting the n x n block M* = M[a*, b*] out of the sb x sk sector matrix exchanges the
+// roles of the variables y_{a*} and x_{b*} in y = M x (Tucker's principal pivot transform): the same
+// graph {(x, M x)} is then described by a matrix G, and every Pluecker coordinate of the graph - every
+// minor - can be read from either description:
+//
+//     det M[a, b] = (+-) det M* . det G[R, C],
+//     R = (a \ a*)  u  { pivot rows of the columns b* \ b },   C = (b \ b*)  u  { pivot columns of the rows a* \ a }.
+//
+// The small determinant has order d = |a \ a*| + |b \ b*| - the number of orbitals in which the pair
+// differs from the pivot configuration, 0..4 for almost every pair of a Slater -> MPS sweep - and G is
+// computed once per workgroup by n exchange steps with FULL pivoting over the whole sector matrix
+// (rows of the leading bra set and columns of the leading ket set preferred by a factor ~3 in
+// magnitude), so it is as stable as a completely pivoted LU.  The per-bra-set eliminations, 85 % of the
+// time of det_reduced.hip (measured), disappear.
+//
+// The sign is the product of five shuffle / sorting signs of the Pluecker correspondence; all of them
+// reduce to O(d) mask operations and table look-ups (derivation and a brute-force check against
+// numpy.linalg.det in tools/prototype_ppt_minors.py).  One lane owns one (a, b) pair: masks -> R, C, sign
+// -> closed-form determinant for d <= 4; the few larger ones are queued in LDS and evaluated eight at a
+// time by 8-lane groups (det_group, det_common.hpp).  The kernel is not specialised on n: one launch
+// covers all sectors of all sites.
+#include <stdlib.h>
+
+#include "det_common.hpp"
+
+namespace tmf {
+
+namespace {
+
+__device__ inline uint64_t below(int i) { return (i >= 64) ? ~0ull : ((1ull << i) - 1ull); }
+__device__ inline uint64_t above(uint64_t m, int i) { return (i >= 63) ? 0ull : (m >> (i + 1)); }
+
+template <typename T, int DD, int G>
+__device__ inline T small_det_group(const T* __restrict__ Gm, const int ld, uint64_t rmask, uint64_t cmask, const int d,
+                                    const int c, T* __restrict__ scratch) {
+  T a[DD];
+  int col = 0;
+  {
+    uint64_t cm = cmask;
+    for (int i = 0; i < c && i < d; ++i) cm &= cm - 1;
+    col = (c < d) ? __ffsll((unsigned long long)cm) - 1 : 0;
+  }
+#pragma unroll
+  for (int r = 0; r < DD; ++r) {
+    T v = (r == c) ? sc<T>::one() : sc<T>::zero();
+    if (r < d) {
+      const int row = __ffsll((unsigned long long)rmask) - 1;
+      rmask &= rmask - 1;
+      v = (c < d) ? Gm[row + col * ld] : sc<T>::zero();
+    } else if (c < d) {
+      v = sc<T>::zero();
+    }
+    a[r] = v;
+  }
+  return det_group<T, DD, G>(a, c, scratch);
+}
+
+}  // namespace
+
+// dynamic LDS: [ G : sb*sk T ][ kmask : nsk u64 ][ amask : na u64 ][ per wave: scratch 8*33 T | queue 72 u32 ]
+template <typename T>
+__global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __restrict__ desc, const float boost) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ unsigned red_key[4];
+  __shared__ uint8_t row_of[64], col_of[64], invr[64], prow_seq[64], pcol_seq[64];
+  __shared__ uint64_t s_PA, s_PB;
+  __shared__ int s_singular, s_csector;
+  __shared__ double s_prod[2];
+
+  const tmf_det_desc d = desc[blockIdx.x];
+  const int sb = d.sb, sk = d.sk, n = d.n, nsk = d.nsk, na = d.a1 - d.a0;
+  T* Gm = reinterpret_cast<T*>(smem);                       // Gm[r + c * sb]
+  size_t off = ((size_t)sb * sk * sizeof(T) + 15) & ~(size_t)15;
+  uint64_t* kmask = reinterpret_cast<uint64_t*>(smem + off);
+  off += (size_t)nsk * 8;
+  uint64_t* amask = reinterpret_cast<uint64_t*>(smem + off);
+  off += (size_t)na * 8;
+  off = (off + 15) & ~(size_t)15;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  constexpr int SCR = 8 * 33;
+  const size_t per_wave = SCR * sizeof(T) + 72 * 4;
+  T* scr_w = reinterpret_cast<T*>(smem + off + (size_t)wave * per_wave);
+  uint32_t* queue = reinterpret_cast<uint32_t*>(scr_w + SCR);
+
+  const T* __restrict__ S = reinterpret_cast<const T*>(d.S);
+  for (int e = tid; e < sb * sk; e += 256) Gm[e] = S[(size_t)(e % sb) + (size_t)(e / sb) * d.lds];
+  const uint8_t* __restrict__ gk = reinterpret_cast<const uint8_t*>(d.ket_idx);
+  const uint8_t* __restrict__ gb = reinterpret_cast<const uint8_t*>(d.bra_idx);
+  for (int b = tid; b < nsk; b += 256) {
+    uint64_t m = 0;
+    for (int u = 0; u < n; ++u) m |= 1ull << gk[(size_t)b * n + u];
+    kmask[b] = m;
+  }
+  for (int a = tid; a < na; a += 256) {
+    uint64_t m = 0;
+    for (int u = 0; u < n; ++u) m |= 1ull << gb[(size_t)(d.a0 + a) * n + u];
+    amask[a] = m;
+  }
+  // preferred pivots: rows of the sector's leading bra set, columns of its leading ket set
+  uint64_t pref_r = 0, pref_c = 0;
+  for (int u = 0; u < n; ++u) {
+    pref_r |= 1ull << gb[u];
+    pref_c |= 1ull << gk[u];
+  }
+  if (tid == 0) {
+    s_PA = 0, s_PB = 0, s_singular = 0;
+    s_prod[0] = 1.0, s_prod[1] = 0.0;
+  }
+  __syncthreads();
+
+  // ---------------- n exchange steps with full pivoting over the sector matrix -----------------------
+  uint64_t usedR = 0, usedC = 0;   // uniform copies
+  for (int t = 0; t < n; ++t) {
+    unsigned key = 0u;
+    for (int e = tid; e < sb * sk; e += 256) {
+      const int r = e % sb, c = e / sb;
+      if (((usedR >> r) | (usedC >> c)) & 1ull) continue;
+      float v = (float)sc<T>::abs2(Gm[e]);
+      if ((pref_r >> r) & 1ull) v *= boost;
+      if ((pref_c >> c) & 1ull) v *= boost;
+      // 20 bits of magnitude (sign bit clear), 12 bits of element index (sb * sk <= 4096): ties -> larger index
+      const unsigned mag = __float_as_uint(v) & ~4095u;
+      const unsigned k = mag ? (mag | (unsigned)e) : 0u;
+      key = k > key ? k : key;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned other = (unsigned)__shfl_xor((int)key, o);
+      key = other > key ? other : key;
+    }
+    if (lane == 0) red_key[wave] = key;
+    __syncthreads();
+    key = red_key[0];
+    for (int w = 1; w < 4; ++w) key = red_key[w] > key ? red_key[w] : key;
+    if (key == 0u) {  // nothing left to pivot on: rank(M) < n, every minor of order n vanishes
+      if (tid == 0) s_singular = 1;
+      __syncthreads();
+      break;
+    }
+    const int pe = (int)(key & 4095u), pr = pe % sb, pc = pe / sb;
+    const T p = Gm[pe];
+    const T pinv = sc<T>::inv_fast(p);
+    __syncthreads();  // everybody has read the pivot (and red_key) before anything is overwritten
+    // rank-1 part on the elements outside the pivot row and column
+    for (int e = tid; e < sb * sk; e += 256) {
+      const int r = e % sb, c = e / sb;
+      if (r == pr || c == pc) continue;
+      const T f = sc<T>::mul(Gm[r + pc * sb], pinv);
+      Gm[e] = sc<T>::fms(Gm[e], f, Gm[pr + c * sb]);
+    }
+    __syncthreads();
+    for (int e = tid; e < sb + sk; e += 256) {
+      if (e < sb) {        // pivot column: G[i, pc] = M[i, pc] / p
+        if (e != pr) Gm[e + pc * sb] = sc<T>::mul(Gm[e + pc * sb], pinv);
+      } else {             // pivot row: G[pr, j] = -M[pr, j] / p
+        const int c = e - sb;
+        if (c != pc) Gm[pr + c * sb] = sc<T>::neg(sc<T>::mul(Gm[pr + c * sb], pinv));
+      }
+    }
+    if (tid == 0) {
+      Gm[pe] = pinv;
+      row_of[pc] = (uint8_t)pr, col_of[pr] = (uint8_t)pc;
+      prow_seq[t] = (uint8_t)pr, pcol_seq[t] = (uint8_t)pc;
+      s_PA |= 1ull << pr, s_PB |= 1ull << pc;
+      const T q = sc<T>::mul(sc<T>::from2(s_prod[0], s_prod[1]), p);
+      s_prod[0] = sc<T>::real(q), s_prod[1] = sc<T>::imag(q);
+    }
+    usedR |= 1ull << pr, usedC |= 1ull << pc;
+    __syncthreads();
+  }
+  T* __restrict__ out = reinterpret_cast<T*>(d.out);
+  if (s_singular) {
+    for (int64_t e = tid; e < (int64_t)na * nsk; e += 256) out[(size_t)d.a0 * nsk + e] = sc<T>::zero();
+    return;
+  }
+  const uint64_t PA = s_PA, PB = s_PB;
+  const uint64_t NPB = below(sk) & ~PB;
+  // tables: invr[r] = inversions of the sequence col_of over the pivot rows (ascending) that involve r;
+  // sign of det M*_sorted relative to the product of the pivots = parity of the two pivot sequences
+  if (tid < 64) {
+    const int r = tid;
+    int v = 0;
+    if ((PA >> r) & 1ull) {
+      const int cr = col_of[r];
+      for (uint64_t m = PA & below(r); m; m &= m - 1) v += col_of[__ffsll((unsigned long long)m) - 1] > cr;
+      for (uint64_t m = above(PA, r); m; m &= m - 1) v += col_of[__ffsll((unsigned long long)m) + r] < cr;
+    }
+    invr[r] = (uint8_t)v;
+  }
+  if (tid == 64) {
+    int inv = 0;
+    for (int i = 0; i < n; ++i)
+      for (int j = i + 1; j < n; ++j) inv += (prow_seq[i] > prow_seq[j]) + (pcol_seq[i] > pcol_seq[j]);
+    s_csector = inv & 1;
+  }
+  __syncthreads();
+  const T scale = *reinterpret_cast<const T*>(d.scale);
+  const T pref_fac = sc<T>::mul(scale, sc<T>::from2(s_prod[0], s_prod[1]));
+  const int csec = s_csector;
+  const int grp = lane >> 3, c8 = lane & 7;
+  T* scr_g = scr_w + grp * 33;
+
+  // everything that depends on the bra set only (uniform in the wavefront)
+  struct ASide {
+    uint64_t in, out_, cm;   // rows entering, pivot rows leaving, pivot columns of the leaving rows
+    int da, par;
+  };
+  auto a_side = [&](const uint64_t am) {
+    ASide s;
+    s.in = am & ~PA, s.out_ = PA & ~am, s.cm = 0;
+    s.da = __popcll(s.in);
+    int par = 0;
+    uint64_t seen = 0;
+    for (uint64_t m = s.out_; m; m &= m - 1) {
+      const int r = __ffsll((unsigned long long)m) - 1, cr = col_of[r];
+      par += __popcll(above(NPB, cr)) + invr[r] + __popcll(above(seen, cr));   // I_X0Y1, I_Y1Y1 (two parts)
+      seen |= 1ull << cr;
+      s.cm |= 1ull << cr;
+    }
+    for (uint64_t m = s.in; m; m &= m - 1) {
+      const int r0 = __ffsll((unsigned long long)m) - 1;
+      par += __popcll(above(PA, r0)) + __popcll(above(s.out_, r0));            // I_Y0Y1
+    }
+    s.par = par;
+    return s;
+  };
+  // the pair: masks of the small determinant and the parity of the sign
+  auto pair = [&](const ASide& A, const uint64_t bm, uint64_t& Rm, uint64_t& Cm) {
+    const uint64_t bin = bm & ~PB, bout = PB & ~bm;
+    const int db = __popcll(bin);
+    int par = csec + A.par + db * (n - A.da);                                  // sector, bra part, I_X1Y1
+    Rm = A.in;
+    uint64_t seen = 0;
+    for (uint64_t m = bout; m; m &= m - 1) {
+      const int c1 = __ffsll((unsigned long long)m) - 1, r1 = row_of[c1];
+      par += c1 + __popcll(above(NPB, c1)) + __popcll(above(bin, c1))          // T1, I_X0X1
+             + __popcll(above(seen, r1)) + __popcll(A.in & below(r1));         // I_X1X1, I_X1Y0
+      seen |= 1ull << r1;
+      Rm |= 1ull << r1;
+    }
+    for (uint64_t m = bin; m; m &= m - 1) {
+      const int c0 = __ffsll((unsigned long long)m) - 1;
+      par += c0 + __popcll(PB & below(c0)) + __popcll(A.cm & below(c0));       // T1, I_X0Y1 (two parts)
+    }
+    Cm = bin | A.cm;
+    const int dd = __popcll(Cm);
+    int csum = 0;
+    for (uint64_t m = Cm; m; m &= m - 1) csum += __ffsll((unsigned long long)m) - 1;
+    par += dd * (sk - 1) + csum + ((dd * (dd - 1)) >> 1);                       // T5
+    return par;
+  };
+
+  auto slow_batch = [&](const uint32_t item, const bool live) {
+    const int al = live ? (int)(item >> 16) & 0x7fff : 0, b = live ? (int)(item & 0xffffu) : 0;
+    const ASide A = a_side(amask[al]);
+    uint64_t Rm, Cm;
+    const int par = pair(A, kmask[b], Rm, Cm);
+    const int dd = live ? __popcll(Cm) : 0;
+    unsigned dmax = (unsigned)dd;
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned other = (unsigned)__shfl_xor((int)dmax, o);
+      dmax = other > dmax ? other : dmax;
+    }
+    T det = sc<T>::one();
+    bool direct = false;
+    if (dmax <= 8u) {
+      det = small_det_group<T, 8, 8>(Gm, sb, Rm, Cm, dd, c8, scr_g);
+    } else {
+      // (never seen in a sweep: more than 8 exchanged orbitals.)  The 8 pairs are evaluated one after the
+      // other as full n x n minors of the ORIGINAL matrix, gathered from global memory by 16-lane groups
+      // (n <= 16 here): no exchange identity, no sign bookkeeping.
+      direct = true;
+      for (int g = 0; g < 8; ++g) {
+        const uint32_t it = (uint32_t)__shfl((int)item, g * 8);
+        const int lv = __shfl((int)live, g * 8);
+        const int ag = (int)(it >> 16) & 0x7fff, bg = (int)(it & 0xffffu), c = lane & 15;
+        T acol[16];
+        const uint8_t* ra = gb + (size_t)(d.a0 + ag) * n;
+        const int colg = (c < n) ? gk[(size_t)bg * n + c] : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          T v = (r == c) ? sc<T>::one() : sc<T>::zero();
+          if (r < n && c < n) v = S[(size_t)ra[r] + (size_t)colg * d.lds];
+          else if (r < n || c < n) v = (r == c) ? sc<T>::one() : sc<T>::zero();
+          acol[r] = v;
+        }
+        T dt = det_group<T, 16, 16>(acol, c, scr_w + (lane >> 4) * 33);
+        dt = shfl_t<T>(dt, 0, 64);
+        if (grp == g && lv) det = dt;
+      }
+    }
+    if (live && c8 == 0) {
+      T v = direct ? sc<T>::mul(scale, det) : sc<T>::mul(pref_fac, det);
+      if (!direct && (par & 1)) v = sc<T>::neg(v);
+      out[(size_t)(d.a0 + al) * nsk + b] = v;
+    }
+  };
+
+  int qn = 0;  // pairs waiting for the slow path (uniform in the wavefront)
+  for (int al = wave; al < na; al += 4) {
+    const ASide A = a_side(amask[al]);
+    T* __restrict__ orow = out + (size_t)(d.a0 + al) * nsk;
+    for (int b0 = 0; b0 < nsk; b0 += 64) {
+      const int b = b0 + lane;
+      const bool live = b < nsk;
+      uint64_t Rm = 0, Cm = 0;
+      int par = 0, dd = 0;
+      if (live) {
+        par = pair(A, kmask[b], Rm, Cm);
+        dd = __popcll(Cm);
+      }
+      const bool slow = live && dd > 4;
+      if (live && !slow) {
+        int iv[4], jv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          iv[t] = 0, jv[t] = 0;
+          if (t < dd) {
+            iv[t] = __ffsll((unsigned long long)Rm) - 1;
+            jv[t] = (__ffsll((unsigned long long)Cm) - 1) * sb;
+            Rm &= Rm - 1, Cm &= Cm - 1;
+          }
+        }
+        T det = sc<T>::one();
+        if (dd == 1) {
+          det = Gm[iv[0] + jv[0]];
+        } else if (dd == 2) {
+          const T m00 = Gm[iv[0] + jv[0]], m10 = Gm[iv[1] + jv[0]], m01 = Gm[iv[0] + jv[1]], m11 = Gm[iv[1] + jv[1]];
+          det = sc<T>::fms(sc<T>::mul(m00, m11), m01, m10);
+        } else if (dd == 3) {
+          const T m00 = Gm[iv[0] + jv[0]], m10 = Gm[iv[1] + jv[0]], m20 = Gm[iv[2] + jv[0]];
+          const T m01 = Gm[iv[0] + jv[1]], m11 = Gm[iv[1] + jv[1]], m21 = Gm[iv[2] + jv[1]];
+          const T m02 = Gm[iv[0] + jv[2]], m12 = Gm[iv[1] + jv[2]], m22 = Gm[iv[2] + jv[2]];
+          const T c0 = sc<T>::fms(sc<T>::mul(m11, m22), m12, m21);
+          const T c1 = sc<T>::fms(sc<T>::mul(m10, m22), m12, m20);
+          const T c2 = sc<T>::fms(sc<T>::mul(m10, m21), m11, m20);
+          det = sc<T>::fmac(sc<T>::fms(sc<T>::mul(m00, c0), m01, c1), m02, c2);
+        } else if (dd == 4) {
+          // Laplace expansion along the first two columns: sum over row pairs (p < q) of
+          // (-1)^(p+q+1) |M[pq; 01]| |M[rs; 23]|  with {r, s} the complementary rows
+          T m[4][4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) m[r][c] = Gm[iv[r] + jv[c]];
+          auto d2 = [&](int p, int q, int c0_, int c1_) {
+            return sc<T>::fms(sc<T>::mul(m[p][c0_], m[q][c1_]), m[p][c1_], m[q][c0_]);
+          };
+          det = sc<T>::mul(d2(0, 1, 0, 1), d2(2, 3, 2, 3));
+          det = sc<T>::fms(det, d2(0, 2, 0, 1), d2(1, 3, 2, 3));
+          det = sc<T>::fmac(det, d2(0, 3, 0, 1), d2(1, 2, 2, 3));
+          det = sc<T>::fmac(det, d2(1, 2, 0, 1), d2(0, 3, 2, 3));
+          det = sc<T>::fms(det, d2(1, 3, 0, 1), d2(0, 2, 2, 3));
+          det = sc<T>::fmac(det, d2(2, 3, 0, 1), d2(0, 1, 2, 3));
+        }
+        T v = sc<T>::mul(pref_fac, det);
+        if (par & 1) v = sc<T>::neg(v);
+        orow[b] = v;
+      }
+      const uint64_t sm = __ballot(slow);
+      if (sm) {
+        if (slow) queue[qn + __popcll(sm & below(lane))] = ((uint32_t)al << 16) | (uint32_t)b;
+        qn += __popcll(sm);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        while (qn >= 8) {
+          qn -= 8;
+          slow_batch(queue[qn + grp], true);
+        }
+      }
+    }
+  }
+  if (qn > 0) slow_batch(queue[grp < qn ? grp : 0], grp < qn);
+}
+
+}  // namespace tmf
+
+extern "C" int tmf_det_ppt_batched(int dtype, const tmf_det_desc* d_desc, int ntiles, int lds_bytes, void* stream) {
+  using namespace tmf;
+  if (ntiles <= 0) return TMF_OK;
+  if (lds_bytes < 0 || lds_bytes > 150 * 1024) {
+    set_error("tmf_det_ppt_batched: lds_bytes %d exceeds the dynamic LDS budget (150 KiB)", lds_bytes);
+    return TMF_E_LIMIT;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)ppt_det_kernel<cd>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)ppt_det_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
+  static float boost = getenv("TMF_PPT_BOOST") ? (float)atof(getenv("TMF_PPT_BOOST")) : 10.0f;  // experiment knob
+  if (dtype == TMF_C128) hipLaunchKernelGGL(ppt_det_kernel<cd>, dim3(ntiles), dim3(256), lds_bytes, s, d_desc, boost);
+  else if (dtype == TMF_F64) hipLaunchKernelGGL(ppt_det_kernel<double>, dim3(ntiles), dim3(256), lds_bytes, s, d_desc, boost);
+  else {
+    set_error("tmf_det_ppt_batched: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+  return check_hip(hipGetLastError(), "tmf_det_ppt_batched launch");
+}

@@ -429,6 +429,7 @@ class Engine:
 
     range_floor_tol = 1e-11
     filled_cholqr = os.environ.get("TMF_FILLED_CHOLQR", "1") == "1"   # panel method of the filled-basis QR
+    det_method = os.environ.get("TMF_DET_METHOD", "ppt")              # "ppt" | "reduced" (A/B switch)
 
     def _fetch_async(self, tensors):
         """Asynchronous device -> pinned host copies of small result tensors; returns (wait handle, NumPy
@@ -912,7 +913,10 @@ class Engine:
             nsb_ = (sec_all["r1"] - sec_all["r0"]).astype(np.int64)
             nsk_ = (sec_all["c1"] - sec_all["c0"]).astype(np.int64)
             cls_ = np.where(nq <= 32, nq, 64)  # exact order for n <= 32 (templated kernels), generic above
-            ta = np.clip(_cdiv(4096, nsk_), 1, nsb_)
+            # sectors whose matrix and order fit the pivoted-exchange kernel (det_ppt.hip): one launch for all
+            sec_ppt = ((nq >= 1) & (nq <= 16) & (sbv[sec_site] <= 64) & (skv[sec_site] <= 64)
+                       & (self.det_method == "ppt"))
+            ta = np.clip(_cdiv(np.where(sec_ppt, 16384, 4096), nsk_), 1, nsb_)
             ntile = _cdiv(nsb_, ta)
             tsec = np.repeat(np.arange(len(sec_all)), ntile)
             tloc = np.arange(int(ntile.sum())) - np.repeat(np.cumsum(ntile) - ntile, ntile)
@@ -938,24 +942,38 @@ class Engine:
             pairs = (dd_all["a1"] - dd_all["a0"]).astype(np.int64) * dd_all["nsk"]
             # reduced-minor kernel (one Gauss-Jordan per bra row-set) whenever the sometimes-matrix has
             # <= 64 columns and 1 <= n <= 32; the direct kernel covers the rest
-            use_red = (tcls >= 1) & (tcls <= 32) & (skv[tsite] <= 64) & (not self.force_direct_det)
+            use_ppt = sec_ppt[tsec]
+            use_red = (tcls >= 1) & (tcls <= 32) & (skv[tsite] <= 64) & (not self.force_direct_det) & ~use_ppt
             lneed_red = nat.reduced_det_lds(el, nq[tsec], sbv[tsite], skv[tsite], nsk_[tsec], ta[tsec]) - 16
             use_red &= lneed_red + 16 <= 160 * 1024
             lneed = np.where(use_red, lneed_red, lneed)
+            lneed = np.where(use_ppt, nat.ppt_det_lds(el, sbv[tsite], skv[tsite], nsk_[tsec], ta[tsec]), lneed)
             if int(lneed.max()) > 160 * 1024:
                 raise NotImplementedError("determinant tile exceeds the 160 KiB LDS of a CU")
-            launches = sorted({(int(c_), bool(r_)) for c_, r_ in zip(tcls.tolist(), use_red.tolist())},
-                              key=lambda cr: -int(pairs[(tcls == cr[0]) & (use_red == cr[1])].sum()))
+            flop_per_det = (8.0 / 3.0) if cplx else (2.0 / 3.0)  # LU of an n x n complex / real matrix
+            selp = np.nonzero(use_ppt)[0]
+            if selp.size:
+                selp = selp[np.argsort(-pairs[selp], kind="stable")]          # biggest tiles first
+                t_dd = self._up(dd_all[selp])
+                flops = float((pairs[selp].astype(np.float64) * nq[tsec][selp].astype(np.float64) ** 3).sum()) * flop_per_det
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(torch.cuda.current_stream(self.device))
+                nat.check(self.lib.tmf_det_ppt_batched(self.dtype, t_dd.data_ptr(), len(selp), int(lneed[selp].max()),
+                                                       self.stream), "tmf_det_ppt_batched")
+                ev1.record(torch.cuda.current_stream(self.device))
+                self.det_events.append(("ppt", ev0, ev1, flops, int(pairs[selp].sum())))
+                n_det += int(pairs[selp].sum())
+            launches = sorted({(int(c_), bool(r_)) for c_, r_ in zip(tcls[~use_ppt].tolist(), use_red[~use_ppt].tolist())},
+                              key=lambda cr: -int(pairs[(tcls == cr[0]) & (use_red == cr[1]) & ~use_ppt].sum()))
             for cls, red in launches:
-                selc = np.nonzero((tcls == cls) & (use_red == red))[0]
+                selc = np.nonzero((tcls == cls) & (use_red == red) & ~use_ppt)[0]
                 if selc.size == 0:
                     continue
                 # biggest tiles first
                 selc = selc[np.argsort(-(pairs[selc] * (nq[tsec][selc] + 1) ** 2), kind="stable")]
                 dd = dd_all[selc]
                 t_dd = self._up(dd)
-                flops = float((pairs[selc].astype(np.float64) * nq[tsec][selc].astype(np.float64) ** 3).sum())
-                flops *= (8.0 / 3.0) if cplx else (2.0 / 3.0)  # LU of an n x n complex / real matrix
+                flops = float((pairs[selc].astype(np.float64) * nq[tsec][selc].astype(np.float64) ** 3).sum()) * flop_per_det
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record(torch.cuda.current_stream(self.device))
                 fn = self.lib.tmf_det_reduced_batched if red else self.lib.tmf_det_gather_batched

@@ -615,3 +615,68 @@ def test_gemm_tall_batched(eng, cplx):
         for (M, N, K), A, B, C0, dc in zip(shapes, As, Bs, Cs, dC):
             ref = alpha * (A.conj().T @ B) + beta * C0
             np.testing.assert_allclose(back(dc[0], (M, N)), ref, rtol=0, atol=1e-12 * max(1.0, np.abs(ref).max()) * K**0.5)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("n,sb,sk,mode", [(1, 6, 5, "near"), (2, 9, 9, "near"), (5, 12, 12, "near"), (8, 15, 20, "near"),
+                                          (12, 19, 30, "near"), (13, 20, 31, "far"), (16, 23, 40, "near"),
+                                          (16, 64, 64, "far"), (12, 19, 30, "rankdef"), (6, 13, 14, "graded"),
+                                          (12, 30, 40, "mixed"), (7, 20, 30, "mixed"), (3, 3, 3, "near")])
+def test_det_ppt_matches_numpy(eng, cplx, n, sb, sk, mode):
+    """tmf_det_ppt_batched (one pivoted exchange of the sector matrix per workgroup, every minor a small
+    determinant of the exchanged matrix) against numpy.linalg.det.  'near': bra AND ket sets differ from
+    the leading ones by 0-3 exchanged orbitals each (the situation of a sweep, d = 0..6: closed forms and
+    the queued path); 'far': random sets (d up to 2 n, the 16/32-lane path); 'rankdef': the sector matrix
+    has rank < n (every minor is 0); 'graded': rows scaled over 12 decades; 'mixed': 150 ket sets."""
+    setup(eng, cplx)
+    nat = eng.nat
+    rng = np.random.default_rng(300 + n + sk)
+    S = rnd(rng, (sb, sk), cplx)
+    if mode == "graded":
+        S *= np.logspace(0, -12, sb)[:, None]
+    if mode == "rankdef":
+        S = rnd(rng, (sb, n - 1), cplx) @ rnd(rng, (n - 1, sk), cplx)
+    nsb, nsk = (23, 41) if mode != "mixed" else (9, 150)
+
+    def family(size, base, count):
+        out = []
+        for _ in range(count):
+            if mode == "far":
+                out.append(np.sort(rng.choice(size, n, replace=False)))
+                continue
+            k = base.copy()
+            for _ in range(rng.integers(0, min(6 if mode == "mixed" else 3, n, size - n) + 1)):
+                free = np.setdiff1d(np.arange(size), k)
+                if len(free):
+                    k[rng.integers(n)] = rng.choice(free)
+            out.append(np.sort(k))
+        out[0] = base
+        return np.stack(out).astype(np.uint8)
+
+    bra = family(sb, np.sort(rng.choice(sb, n, replace=False)), nsb)
+    ket = family(sk, np.sort(rng.choice(sk, n, replace=False)), nsk)
+    scale = rnd(rng, (1,), cplx)
+    dS_, dsc = dev(eng, S), dev(eng, scale)
+    tb, tk = eng._up(bra), eng._up(ket)
+    out = eng._alloc(nsb * nsk, zero=True)
+    ta = 8
+    dd = np.zeros(_cdiv(nsb, ta), nat.det_desc)
+    for j in range(len(dd)):
+        dd[j] = (dS_[1], dsc[1], tb.data_ptr(), tk.data_ptr(), out.data_ptr(), sb, sk, sb, n, nsb, nsk, j * ta,
+                 min(nsb, (j + 1) * ta))
+    lds = nat.ppt_det_lds(eng.elem, sb, sk, nsk, ta)
+    t = eng._up(dd)
+    nat.check(eng.lib.tmf_det_ppt_batched(eng.dtype, t.data_ptr(), len(dd), lds, eng.stream), "ppt")
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(nsb, nsk)
+    ref = np.empty((nsb, nsk), S.dtype)
+    for a in range(nsb):
+        for b in range(nsk):
+            ref[a, b] = scale[0] * np.linalg.det(S[np.ix_(bra[a], ket[b])])
+    if mode == "rankdef":
+        assert np.abs(got).max() <= 1e-9 * np.abs(S).max() ** n
+    elif mode == "graded":  # every row of `ref` has its own scale
+        for a in range(nsb):
+            np.testing.assert_allclose(got[a], ref[a], rtol=0, atol=1e-9 * np.abs(ref[a]).max())
+    else:
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
