@@ -180,8 +180,8 @@ int tmf_det_reduced_batched(int dtype, int order, const tmf_det_desc* d_desc, in
  * workgroup: every minor is +- det(M*) times a determinant of order d = number of orbitals in which
  * the pair (a, b) differs from the pivot configuration (0..4 for almost all pairs), one lane per pair.
  * Not specialised on the order: tiles of all orders go into one launch.  Requires sb, sk <= 64 and
- * n <= 16.  lds_bytes per workgroup: align16(sb*sk*elem) + (nsk + (a1-a0)) * 8 (+ pad to 16)
- *   + 4 * (264 * elem + 288). */
+ * n <= 32.  lds_bytes per workgroup: align16(sb*sk*elem) + (nsk + (a1-a0)) * 8 (+ pad to 16)
+ *   + 4 * (max(264, n*n) * elem + 288). */
 int tmf_det_ppt_batched(int dtype, const tmf_det_desc* d_desc, int ntiles, int lds_bytes, void* stream);
 
 /* Batched gathered Pfaffians (pfaffian.py:1429-1479 `_tensor_block` + :1413-1426 `_many_pfaffian`,

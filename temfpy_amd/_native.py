@@ -209,7 +209,7 @@ def reduced_det_lds(el, n, sb, sk, nsk, na):
             + 4 * (((n | 1) * sk + 264) * el + 576) + 16)
 
 
-def ppt_det_lds(el, sb, sk, nsk, na):
+def ppt_det_lds(el, sb, sk, nsk, na, n):
     """Dynamic LDS bytes of one tmf_det_ppt_batched tile (layout: csrc/det_ppt.hip)."""
     a16 = lambda x: (x + 15) & ~15  # noqa: E731
-    return a16(a16(sb * sk * el) + (nsk + na) * 8) + 4 * (264 * el + 288)
+    return a16(a16(sb * sk * el) + (nsk + na) * 8) + 4 * (np.maximum(264, n * n) * el + 288)

@@ -35,7 +35,7 @@ __device__ inline uint64_t below(int i) { return (i >= 64) ? ~0ull : ((1ull << i
 __device__ inline uint64_t above(uint64_t m, int i) { return (i >= 63) ? 0ull : (m >> (i + 1)); }
 
 template <typename T, int DD, int G>
-__device__ inline T small_det_group(const T* __restrict__ Gm, const int ld, uint64_t rmask, uint64_t cmask, const int d,
+__device__ __attribute__((noinline)) T small_det_group(const T* __restrict__ Gm, const int ld, uint64_t rmask, uint64_t cmask, const int d,
                                     const int c, T* __restrict__ scratch) {
   T a[DD];
   int col = 0;
@@ -59,9 +59,56 @@ __device__ inline T small_det_group(const T* __restrict__ Gm, const int ld, uint
   return det_group<T, DD, G>(a, c, scratch);
 }
 
+// Determinant of the n x n matrix A (LDS, column-major, leading dimension n, n <= 16) by Gaussian
+// elimination with partial pivoting, the whole wavefront cooperating.  Only for the (never observed)
+// pairs that differ from the pivot configuration in more than 8 orbitals: small code, few registers.
+template <typename T>
+__device__ inline T wave_lds_det(T* __restrict__ A, const int n, const int lane) {
+  T det = sc<T>::one();
+  for (int k = 0; k < n; ++k) {
+    // pivot row of column k
+    float best = -1.0f;
+    int brow = k;
+    for (int r = k + lane; r < n; r += 64) {
+      const float v = (float)sc<T>::abs2(A[r + k * n]);
+      if (v > best) best = v, brow = r;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o);
+      const int orow = __shfl_xor(brow, o);
+      if (ob > best || (ob == best && orow < brow)) best = ob, brow = orow;
+    }
+    if (!(best > 0.0f)) return sc<T>::zero();
+    __builtin_amdgcn_wave_barrier();
+    if (brow != k) {
+      for (int c = lane; c < n; c += 64) {
+        const T t = A[k + c * n];
+        A[k + c * n] = A[brow + c * n];
+        A[brow + c * n] = t;
+      }
+      det = sc<T>::neg(det);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const T p = A[k + k * n];
+    det = sc<T>::mul(det, p);
+    const T pinv = sc<T>::inv_fast(p);
+    const int m = n - 1 - k;
+    for (int e = lane; e < m * m; e += 64) {
+      const int r = k + 1 + e % m, c = k + 1 + e / m;
+      A[r + c * n] = sc<T>::fms(A[r + c * n], sc<T>::mul(A[r + k * n], pinv), A[k + c * n]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  return det;
+}
+
 }  // namespace
 
-// dynamic LDS: [ G : sb*sk T ][ kmask : nsk u64 ][ amask : na u64 ][ per wave: scratch 8*33 T | queue 72 u32 ]
+// dynamic LDS: [ G : sb*sk T ][ kmask : nsk u64 ][ amask : na u64 ][ per wave: scratch max(264, n*n) T | queue 72 u32 ]
 template <typename T>
 __global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __restrict__ desc, const float boost) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -81,8 +128,8 @@ __global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __rest
   off += (size_t)na * 8;
   off = (off + 15) & ~(size_t)15;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  constexpr int SCR = 8 * 33;
-  const size_t per_wave = SCR * sizeof(T) + 72 * 4;
+  const int SCR = (n * n > 8 * 33) ? n * n : 8 * 33;   // 8 groups x 33, or one n x n minor (fallback path)
+  const size_t per_wave = (size_t)SCR * sizeof(T) + 72 * 4;
   T* scr_w = reinterpret_cast<T*>(smem + off + (size_t)wave * per_wave);
   uint32_t* queue = reinterpret_cast<uint32_t*>(scr_w + SCR);
 
@@ -270,26 +317,22 @@ __global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __rest
       det = small_det_group<T, 8, 8>(Gm, sb, Rm, Cm, dd, c8, scr_g);
     } else {
       // (never seen in a sweep: more than 8 exchanged orbitals.)  The 8 pairs are evaluated one after the
-      // other as full n x n minors of the ORIGINAL matrix, gathered from global memory by 16-lane groups
-      // (n <= 16 here): no exchange identity, no sign bookkeeping.
+      // other as full n x n minors of the ORIGINAL matrix, gathered from global memory into the
+      // wavefront's LDS scratch (n <= 32): no exchange identity, no sign bookkeeping.
       direct = true;
       for (int g = 0; g < 8; ++g) {
         const uint32_t it = (uint32_t)__shfl((int)item, g * 8);
         const int lv = __shfl((int)live, g * 8);
-        const int ag = (int)(it >> 16) & 0x7fff, bg = (int)(it & 0xffffu), c = lane & 15;
-        T acol[16];
+        const int ag = (int)(it >> 16) & 0x7fff, bg = (int)(it & 0xffffu);
         const uint8_t* ra = gb + (size_t)(d.a0 + ag) * n;
-        const int colg = (c < n) ? gk[(size_t)bg * n + c] : 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          T v = (r == c) ? sc<T>::one() : sc<T>::zero();
-          if (r < n && c < n) v = S[(size_t)ra[r] + (size_t)colg * d.lds];
-          else if (r < n || c < n) v = (r == c) ? sc<T>::one() : sc<T>::zero();
-          acol[r] = v;
-        }
-        T dt = det_group<T, 16, 16>(acol, c, scr_w + (lane >> 4) * 33);
-        dt = shfl_t<T>(dt, 0, 64);
+        const uint8_t* cb = gk + (size_t)bg * n;
+        for (int e = lane; e < n * n; e += 64) scr_w[e] = S[(size_t)ra[e % n] + (size_t)cb[e / n] * d.lds];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const T dt = wave_lds_det<T>(scr_w, n, lane);
         if (grp == g && lv) det = dt;
+        __builtin_amdgcn_wave_barrier();
       }
     }
     if (live && c8 == 0) {
@@ -341,20 +384,27 @@ __global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __rest
         } else if (dd == 4) {
           // Laplace expansion along the first two columns: sum over row pairs (p < q) of
           // (-1)^(p+q+1) |M[pq; 01]| |M[rs; 23]|  with {r, s} the complementary rows
-          T m[4][4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) m[r][c] = Gm[iv[r] + jv[c]];
-          auto d2 = [&](int p, int q, int c0_, int c1_) {
-            return sc<T>::fms(sc<T>::mul(m[p][c0_], m[q][c1_]), m[p][c1_], m[q][c0_]);
-          };
-          det = sc<T>::mul(d2(0, 1, 0, 1), d2(2, 3, 2, 3));
-          det = sc<T>::fms(det, d2(0, 2, 0, 1), d2(1, 3, 2, 3));
-          det = sc<T>::fmac(det, d2(0, 3, 0, 1), d2(1, 2, 2, 3));
-          det = sc<T>::fmac(det, d2(1, 2, 0, 1), d2(0, 3, 2, 3));
-          det = sc<T>::fms(det, d2(1, 3, 0, 1), d2(0, 2, 2, 3));
-          det = sc<T>::fmac(det, d2(2, 3, 0, 1), d2(0, 1, 2, 3));
+          // (the six 2 x 2 minors of the first two columns are formed before the last two columns are
+          // loaded: half the live registers of loading all 16 entries first)
+          T p01, p02, p03, p12, p13, p23;
+          {
+            const T a0 = Gm[iv[0] + jv[0]], a1 = Gm[iv[1] + jv[0]], a2 = Gm[iv[2] + jv[0]], a3 = Gm[iv[3] + jv[0]];
+            const T b0_ = Gm[iv[0] + jv[1]], b1 = Gm[iv[1] + jv[1]], b2 = Gm[iv[2] + jv[1]], b3 = Gm[iv[3] + jv[1]];
+            p01 = sc<T>::fms(sc<T>::mul(a0, b1), b0_, a1);
+            p02 = sc<T>::fms(sc<T>::mul(a0, b2), b0_, a2);
+            p03 = sc<T>::fms(sc<T>::mul(a0, b3), b0_, a3);
+            p12 = sc<T>::fms(sc<T>::mul(a1, b2), b1, a2);
+            p13 = sc<T>::fms(sc<T>::mul(a1, b3), b1, a3);
+            p23 = sc<T>::fms(sc<T>::mul(a2, b3), b2, a3);
+          }
+          const T c0 = Gm[iv[0] + jv[2]], c1 = Gm[iv[1] + jv[2]], c2 = Gm[iv[2] + jv[2]], c3 = Gm[iv[3] + jv[2]];
+          const T e0 = Gm[iv[0] + jv[3]], e1 = Gm[iv[1] + jv[3]], e2 = Gm[iv[2] + jv[3]], e3 = Gm[iv[3] + jv[3]];
+          det = sc<T>::mul(p01, sc<T>::fms(sc<T>::mul(c2, e3), e2, c3));
+          det = sc<T>::fms(det, p02, sc<T>::fms(sc<T>::mul(c1, e3), e1, c3));
+          det = sc<T>::fmac(det, p03, sc<T>::fms(sc<T>::mul(c1, e2), e1, c2));
+          det = sc<T>::fmac(det, p12, sc<T>::fms(sc<T>::mul(c0, e3), e0, c3));
+          det = sc<T>::fms(det, p13, sc<T>::fms(sc<T>::mul(c0, e2), e0, c2));
+          det = sc<T>::fmac(det, p23, sc<T>::fms(sc<T>::mul(c0, e1), e0, c1));
         }
         T v = sc<T>::mul(pref_fac, det);
         if (par & 1) v = sc<T>::neg(v);

@@ -914,7 +914,7 @@ class Engine:
             nsk_ = (sec_all["c1"] - sec_all["c0"]).astype(np.int64)
             cls_ = np.where(nq <= 32, nq, 64)  # exact order for n <= 32 (templated kernels), generic above
             # sectors whose matrix and order fit the pivoted-exchange kernel (det_ppt.hip): one launch for all
-            sec_ppt = ((nq >= 1) & (nq <= 16) & (sbv[sec_site] <= 64) & (skv[sec_site] <= 64)
+            sec_ppt = ((nq >= 1) & (nq <= 32) & (sbv[sec_site] <= 64) & (skv[sec_site] <= 64)
                        & (self.det_method == "ppt"))
             ta = np.clip(_cdiv(np.where(sec_ppt, 16384, 4096), nsk_), 1, nsb_)
             ntile = _cdiv(nsb_, ta)
@@ -947,7 +947,7 @@ class Engine:
             lneed_red = nat.reduced_det_lds(el, nq[tsec], sbv[tsite], skv[tsite], nsk_[tsec], ta[tsec]) - 16
             use_red &= lneed_red + 16 <= 160 * 1024
             lneed = np.where(use_red, lneed_red, lneed)
-            lneed = np.where(use_ppt, nat.ppt_det_lds(el, sbv[tsite], skv[tsite], nsk_[tsec], ta[tsec]), lneed)
+            lneed = np.where(use_ppt, nat.ppt_det_lds(el, sbv[tsite], skv[tsite], nsk_[tsec], ta[tsec], nq[tsec]), lneed)
             if int(lneed.max()) > 160 * 1024:
                 raise NotImplementedError("determinant tile exceeds the 160 KiB LDS of a CU")
             flop_per_det = (8.0 / 3.0) if cplx else (2.0 / 3.0)  # LU of an n x n complex / real matrix

@@ -621,7 +621,8 @@ def test_gemm_tall_batched(eng, cplx):
 @pytest.mark.parametrize("n,sb,sk,mode", [(1, 6, 5, "near"), (2, 9, 9, "near"), (5, 12, 12, "near"), (8, 15, 20, "near"),
                                           (12, 19, 30, "near"), (13, 20, 31, "far"), (16, 23, 40, "near"),
                                           (16, 64, 64, "far"), (12, 19, 30, "rankdef"), (6, 13, 14, "graded"),
-                                          (12, 30, 40, "mixed"), (7, 20, 30, "mixed"), (3, 3, 3, "near")])
+                                          (12, 30, 40, "mixed"), (7, 20, 30, "mixed"), (3, 3, 3, "near"),
+                                          (19, 30, 45, "near"), (24, 40, 60, "far"), (32, 64, 64, "near")])
 def test_det_ppt_matches_numpy(eng, cplx, n, sb, sk, mode):
     """tmf_det_ppt_batched (one pivoted exchange of the sector matrix per workgroup, every minor a small
     determinant of the exchanged matrix) against numpy.linalg.det.  'near': bra AND ket sets differ from
@@ -664,7 +665,7 @@ def test_det_ppt_matches_numpy(eng, cplx, n, sb, sk, mode):
     for j in range(len(dd)):
         dd[j] = (dS_[1], dsc[1], tb.data_ptr(), tk.data_ptr(), out.data_ptr(), sb, sk, sb, n, nsb, nsk, j * ta,
                  min(nsb, (j + 1) * ta))
-    lds = nat.ppt_det_lds(eng.elem, sb, sk, nsk, ta)
+    lds = int(nat.ppt_det_lds(eng.elem, sb, sk, nsk, ta, n))
     t = eng._up(dd)
     nat.check(eng.lib.tmf_det_ppt_batched(eng.dtype, t.data_ptr(), len(dd), lds, eng.stream), "ppt")
     torch.cuda.synchronize()
