@@ -69,6 +69,32 @@ class SiteData:
         return float(np.sqrt(sum((np.abs(b[5]) ** 2).sum() for b in self.blocks)))
 
 
+class LazyBonds:
+    """List-like view of the bonds of a conversion: the per-bond objects are built on first access from
+    the flat arrays the sweep produced (building all 1025 objects eagerly cost 4 ms of Python per
+    conversion, on the critical path once the determinant stage had shrunk to 3 ms)."""
+
+    def __init__(self, n, factory):
+        self._n, self._factory, self._cache = n, factory, {}
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        if i not in self._cache:
+            self._cache[i] = self._factory(i)
+        return self._cache[i]
+
+    def __iter__(self):
+        return (self[i] for i in range(self._n))
+
+
 class MPSData:
     """Finite MPS in mixed canonical form A..A [lam] B..B with U(1) charge blocks."""
 
