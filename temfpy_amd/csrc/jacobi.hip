@@ -35,7 +35,27 @@ __global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __re
   if (tid == 0) *flag = 0;
   __syncthreads();
 
-  const int pe = (p + 1) & ~1;      // players (even)
+  // Only columns that are not identically zero take part in the tournament (the Rayleigh-Ritz matrix
+  // has a zero row and column for every direction below the range-finder threshold: ~half of p).
+  __shared__ int act[128];
+  __shared__ int s_nact;
+  if (tid < 128) act[tid] = 0;
+  __syncthreads();
+  for (int c = tid; c < p; c += 512) {
+    bool nz = false;
+    for (int r = 0; r < p && !nz; ++r) nz = sc<T>::abs2(X[(size_t)c * p + r]) > 0.0;
+    act[c] = nz;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int k = 0;
+    for (int c = 0; c < p; ++c)
+      if (act[c]) act[k++] = c;   // in place: k <= c
+    s_nact = k;
+  }
+  __syncthreads();
+  const int nact = s_nact;
+  const int pe = (nact + 1) & ~1;   // players (even)
   const int m = pe - 1;             // players on the circle; player m sits still
   const int npairs = pe / 2;
   int tpp = 64;                     // lanes per pair: largest power of two with npairs*tpp <= 512
@@ -62,7 +82,8 @@ __global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __re
           i = j;
           j = t;
         }
-        if (j < p) {
+        if (j < nact) {
+          i = act[i], j = act[j];
           T* xi = X + (size_t)i * p;
           T* xj = X + (size_t)j * p;
           double al = 0.0, be = 0.0;
@@ -151,17 +172,18 @@ static int launch_jacobi(int dtype, const tmf_jacobi_desc* d_desc, int nprob, in
   if (nprob <= 0) return TMF_OK;
   const size_t elem = (dtype == TMF_C128) ? 16 : 8;
   const size_t lds = (WITH_V ? 2 : 1) * (size_t)max_p * max_p * elem + (size_t)max_p * 8 + 64;
-  if (max_p <= 0 || max_p > 128 || lds > 160 * 1024) {
-    set_error("%s: p = %d needs %zu B of LDS (limit 160 KiB)", who, max_p, lds);
+  if (max_p <= 0 || max_p > 128 || lds > 159 * 1024) {
+    set_error("%s: p = %d needs %zu B of LDS (limit 159 KiB)", who, max_p, lds);
     return TMF_E_LIMIT;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   static bool attr_done = false;
   if (!attr_done) {
+    // (the kernel also has ~0.5 KiB of static LDS: ask for 159 KiB of dynamic LDS, not the full 160)
     (void)hipFuncSetAttribute((const void*)jacobi_kernel<cd, WITH_V>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
+                              159 * 1024);
     (void)hipFuncSetAttribute((const void*)jacobi_kernel<double, WITH_V>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
+                              159 * 1024);
     attr_done = true;
   }
   if (dtype == TMF_C128)

@@ -211,6 +211,15 @@ def test_site_sharding_reproduces_unsharded_result_bitwise():
             for b in range(lo, hi + 1):
                 assert np.array_equal(part.bonds[b].lam, full.bonds[b].lam)
                 assert np.array_equal(part.bonds[b].masks, full.bonds[b].masks)
+    # the same ranges interleaved on one stream by cooperative scheduling (engine.run_pipelined)
+    from temfpy_amd.engine import run_pipelined
+
+    ranges = bench.shard_sites(L, L // 2, 3)
+    parts = run_pipelined([Engine("cuda:0") for _ in ranges], C, tr, L // 2, L, ranges)
+    for (lo, hi), part in zip(ranges, parts):
+        for i in range(lo, hi):
+            for bp, bf in zip(part.sites[i].blocks, full.sites[i].blocks):
+                assert bp[:5] == bf[:5] and np.array_equal(bp[5], bf[5])
 
 
 def test_real_dtype_path_matches_complex_path():
