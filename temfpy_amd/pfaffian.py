@@ -77,13 +77,30 @@ def assert_nambu(C, basis=None, offset=None, name="", rtol=0, atol=1e-10):
     return C
 
 
-def correlation_matrix(H: np.ndarray, basis: str | None = None, *, rtol: float = 0, atol: float = 1e-10):
+_ENGINES_HC = {}
+
+
+def correlation_matrix(H: np.ndarray, basis: str | None = None, *, rtol: float = 0, atol: float = 1e-10,
+                       device: str | None = None):
     """Ground-state Nambu correlation matrix of a BdG Hamiltonian (pfaffian.py:302-393).
-    Outside the timed C -> MPS path; host LAPACK like the reference."""
+    Outside the timed C -> MPS path; host LAPACK like the reference, or with ``device="cuda:0"`` (extra
+    keyword) the negative-energy projector from the GEMM-only sign iteration of
+    ``Engine.negative_projector`` (zero modes make it fail to converge -> RuntimeError, like the
+    reference's check at pfaffian.py:372-377)."""
     assert basis in [None, "M->M", "M->C", "C->M", "C->C"], f"Invalid basis spec {basis!r}, should be of form '[MC]->[MC]'"
     tol = dict(rtol=rtol, atol=atol)
     H = assert_nambu(H, None if basis is None else basis[0], offset=0, name="Hamiltonian", **tol)
     n = len(H) // 2
+    if device is not None:
+        from .engine import Engine
+
+        eng = _ENGINES_HC.setdefault(device, Engine(device))
+        C, _ = eng.negative_projector(np.asarray(H, complex))
+        if basis == "C->M":
+            C = matrix_C2M(C)
+        elif basis == "M->C":
+            C = matrix_M2C(C)
+        return assert_nambu(C, None if basis is None else basis[3], offset=1, name="correlation matrix", **tol)
     e, v = np.linalg.eigh(H)
     assert_allclose(e + e[::-1], 0, **tol)
     if np.any(abs(e) < atol):

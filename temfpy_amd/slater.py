@@ -31,19 +31,25 @@ def _engine(device):
     return _ENGINES[device]
 
 
-def correlation_matrix(H: np.ndarray, N: int | None = None) -> tuple[np.ndarray, int]:
+def correlation_matrix(H: np.ndarray, N: int | None = None, *, device: str | None = None) -> tuple[np.ndarray, int]:
     """Ground-state correlation matrix of a mean-field Hamiltonian (slater.py:1150-1180).
 
-    Outside the timed C -> MPS path; host LAPACK like the reference.
-    """
-    e, v = np.linalg.eigh(H)
-    if N is None:
-        occupied = e < 0
-        v = v[:, occupied]
-        N = int(occupied.sum())
+    Outside the timed C -> MPS path.  Default: host LAPACK like the reference.
+    ``device="cuda:0"`` (extra keyword): the occupied-orbital projector is computed on the GPU as
+    (1 - sign(H)) / 2 by a GEMM-only Newton-Schulz iteration (``Engine.negative_projector``); only for
+    ``N=None`` (occupy all negative-energy orbitals), where no eigenvalue ordering is needed."""
+    if device is not None and N is None:
+        C, _ = _engine(device).negative_projector(H)
+        N = int(np.round(np.trace(C).real))
     else:
-        v = v[:, :N]
-    C = v @ HT(v)
+        e, v = np.linalg.eigh(H)
+        if N is None:
+            occupied = e < 0
+            v = v[:, occupied]
+            N = int(occupied.sum())
+        else:
+            v = v[:, :N]
+        C = v @ HT(v)
     if np.iscomplexobj(C) and np.allclose(C.imag, 0.0, rtol=0, atol=1e-14):
         C = C.real
     return C, N

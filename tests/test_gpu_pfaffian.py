@@ -128,3 +128,20 @@ def test_pfaffian_sweep_with_half_modes(L, lefts, chi, seed):
     Sref = np.array([-(c.lam**2 * np.log(c.lam**2)).sum() for c in cuts])
     assert np.abs(S - Sref).max() < 1e-9
     assert S[L // 2] > np.log(2) - 1e-9          # at least the shared fermion
+
+
+@pytest.mark.parametrize("basis", ["M->M", "M->C", "C->M", "C->C"])
+def test_pfaffian_correlation_matrix_on_device(basis):
+    """pfaffian.correlation_matrix(H, basis, device=...) (GEMM-only sign iteration) against the host eigh
+    path of pfaffian.py:302-393 for every basis combination."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_golden_pfaffian import random_majorana_H
+    from temfpy_amd import pfaffian
+
+    H = random_majorana_H(24, 4)
+    if basis[0] == "C":
+        H = pfaffian.matrix_M2C(H)
+    C0 = pfaffian.correlation_matrix(H, basis)
+    C1 = pfaffian.correlation_matrix(H, basis, device="cuda:0")
+    np.testing.assert_allclose(C1, C0, rtol=0, atol=1e-11)
