@@ -33,7 +33,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from . import _native as nat
-from .mps_data import BondData, LazyBonds, MPSData, SiteData
+from .mps_data import BondData, LazyList, MPSData, SiteData
 
 logger = logging.getLogger("temfpy_amd.slater")
 
@@ -763,7 +763,7 @@ class Engine:
                         logger.info("bond %d: %d Schmidt modes, checked %d subsets, kept %d, norm %.12g", b,
                                     kk_cut[j], c_chk[j], int(o_chi[j]),
                                     float(np.sqrt(np.dot(o_lam[j, :int(o_chi[j])], o_lam[j, :int(o_chi[j])]))))
-                bonds = LazyBonds(L + 1, bond)
+                bonds = LazyList(L + 1, bond)
                 return bonds
 
             self.timings["host_enumerate"] = time.perf_counter() - t0
@@ -1060,21 +1060,24 @@ class Engine:
         torch.cuda.current_stream(self.device).synchronize()
         h_out = t_out.numpy()          # the blocks below are views; they keep the pinned tensor alive
         h_det = d_det.cpu().numpy()
-        sites = [None] * s_lo
-        for j in range(L):
-            i = int(my_sites[j])
+        n_local = L
+
+        def site(i):   # built on first access (LazyList): views into the pinned result buffer
+            j = i - s_lo
+            if not 0 <= j < n_local:
+                return None          # a site outside this rank's range
             m_ = "left" if mode[j] == 0 else "right"
-            secs = sec_all[sec_ptr[j]: sec_ptr[j + 1]]
             blocks = []
-            for sec in secs:
+            for sec in sec_all[sec_ptr[j]: sec_ptr[j + 1]]:
                 r0, r1, c0, c1 = (int(sec[f]) for f in ("r0", "r1", "c0", "c1"))
                 o = out_off[j] + int(sec["out_off"])
                 blocks.append((int(sec["q"]), r0, r1, c0, c1, h_out[o: o + (r1 - r0) * (c1 - c0)].reshape(r1 - r0, c1 - c0)))
             bo = int(jobs["bra_off"][j])
-            sites.append(SiteData(mode=m_, det_always=h_det[j], qtotal=0, bra_p=bra_p[bo: bo + 2 * int(chi_b[j])],
-                                  bra_alpha=bra_alpha[bo: bo + 2 * int(chi_b[j])], blocks=blocks,
-                                  chi_bra=int(chi_b[j]), chi_ket=int(chi_k[j])))
-        sites += [None] * (L_all - s_hi)
+            return SiteData(mode=m_, det_always=h_det[j], qtotal=0, bra_p=bra_p[bo: bo + 2 * int(chi_b[j])],
+                            bra_alpha=bra_alpha[bo: bo + 2 * int(chi_b[j])], blocks=blocks,
+                            chi_bra=int(chi_b[j]), chi_ket=int(chi_k[j]))
+
+        sites = LazyList(L_all, site)
         self._tick("download", t0)
         self.timings["total"] = time.perf_counter() - t_all
         self._keep.clear()

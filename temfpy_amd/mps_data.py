@@ -69,8 +69,8 @@ class SiteData:
         return float(np.sqrt(sum((np.abs(b[5]) ** 2).sum() for b in self.blocks)))
 
 
-class LazyBonds:
-    """List-like view of the bonds of a conversion: the per-bond objects are built on first access from
+class LazyList:
+    """List-like view of the bonds (or sites) of a conversion: the objects are built on first access from
     the flat arrays the sweep produced (building all 1025 objects eagerly cost 4 ms of Python per
     conversion, on the critical path once the determinant stage had shrunk to 3 ms)."""
 
