@@ -288,7 +288,7 @@ class PfEngine(Engine):
             d_scr2 = self._alloc(int((ncol.max() + 1) * PANEL_W) * ncs)
             scr2 = d_scr2.data_ptr() + np.arange(ncs) * int((ncol.max() + 1) * PANEL_W) * el
             has = nb_ > 0
-            self.bcgs2(Vt[has], n[has], ld1[has], 2 * ke[has], ncol[has], scr2[has])
+            self.bcgs2(Vt[has], n[has], ld1[has], 2 * ke[has], ncol[has], scr2[has], cholqr=self.filled_cholqr)   # as in Engine.run, stage F; two projection passes
         # ---- self-check of every cut side (pfaffian.py:919 -> testing.py:131-177): kept columns
         # orthonormal, and A = V diag(lambda | 1) V^H (the empty modes, conj(filled), carry eigenvalue 0)
         chk_names, d_chk = [], None
