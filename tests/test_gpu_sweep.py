@@ -462,3 +462,24 @@ def test_correlation_matrix_on_device_matches_eigh(L, seed, real):
     assert N1 == N0 and C1.dtype == C0.dtype
     np.testing.assert_allclose(C1, C0, rtol=0, atol=1e-11)
     np.testing.assert_allclose(C1 @ C1, C1, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("svd_min,deg_tol", [(1e-4, 1e-12), (3e-7, 1e-12), (1e-6, 1e-9)])
+def test_non_default_truncation_parameters(svd_min, deg_tol):
+    """trunc_par beyond chi_max (schmidt_utils.py:22-54): svd_min moves the orbital cutoff svd_min^2
+    (slater.py:318) and with it the range-finder threshold; degeneracy_tol the multiplet rule.
+    (svd_min = 1e-8 puts the cutoff at 1e-16: the reference itself then fails its kL == kR assertion,
+    slater.py:394, on eigenvalue noise.)"""
+    from tests_inputs import random_hopping
+
+    L = 64
+    C, _ = orc.correlation_matrix(random_hopping(L, 4))
+    par = {"chi_max": 96, "svd_min": svd_min, "degeneracy_tol": deg_tol}
+    cuts, sites = orc.c_to_mps(C, par)
+    from temfpy_amd import slater
+    mps = slater.C_to_MPS(C, par, as_tenpy=False)
+    for b in range(L + 1):
+        np.testing.assert_array_equal(mps.bonds[b].sets, cuts[b].sets)
+        np.testing.assert_allclose(mps.bonds[b].e, cuts[b].e, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(mps.bonds[b].lam, cuts[b].lam, rtol=0, atol=1e-9)
+    assert abs(1 - overlap(cuts, sites, mps, L // 2)) < 1e-9
