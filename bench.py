@@ -135,6 +135,8 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(a.streams)]
 
     pipe_engines = [eng] + [Engine(dev, profile=False) for _ in range(a.pipeline - 1)]
+    # host threads of the enumeration / site preparation: share the node's cores between the ranks
+    host_threads = max(2, min(16, len(os.sched_getaffinity(0)) // max(world, 1)))
 
     def convert(d_mat, rng_sites):
         if a.streams == 1 and a.pipeline > 1:
@@ -146,7 +148,7 @@ def main():
             eng.gemm_events = [e for en in pipe_engines[: len(sub)] for e in en.gemm_events]
             return res[0]
         if a.streams == 1:
-            return eng.run(d_mat, trunc, oc, L, download=False, site_range=rng_sites)
+            return eng.run(d_mat, trunc, oc, L, download=False, site_range=rng_sites, threads=host_threads)
         # several shards of this rank's range in flight on separate HIP streams: the host phases of
         # one shard (enumeration, descriptors) overlap the kernels of the others
         import threading
