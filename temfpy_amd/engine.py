@@ -4,24 +4,32 @@ The reference walks the chain site by site (slater.py:1300-1346) and calls LAPAC
 All L+1 cuts and all L sites are independent given C, so here every stage is ONE batched
 launch over all of them (descriptor arrays, variable sizes), with only two host
 round-trips: the entangled eigenvalues come back for the best-first enumeration
-(integer work, C++ on the host), and the index lists go up for the determinant stage.
+(integer work, C++ on the host, overlapped with stage F), and the index lists go up for the
+determinant stage.
 
 Per cut side (block A = C_LL or C_RR, off-diagonal block F = C_LR or C_RL), using that C is a
 projector (A - A^2 = F F^H, so entangled orbitals = left singular vectors of F with
 sigma^2 = e (1 - e) >= cutoff (1 - cutoff), the same set as slater.py:350):
-  E1  Y = F Omega                      MFMA GEMM     randomised range finder, p <= 64 columns
-  E2  Q = qr(Y)                        BCGS2: MFMA GEMM projections + LDS panel kernel
-  E3  B^H = F^H Q ; R = qr(B^H).R      GEMM + BCGS2 + GEMM
-  E4  R Z = U diag(sigma)              one-sided Jacobi in LDS (relative accuracy near 1e-6)
-  E5  U0 = Q Z[:, sigma^2 >= thr]      GEMM
+  E1  Y = F Omega                      running sums over the nested blocks of all cuts (nested.hip);
+                                       randomised range finder, 64 columns (128 / 256 when a cut needs it)
+  E2  Q = qr(Y)                        blocked Gram-Schmidt driven from C++ (bcgs.hip): MFMA projections
+                                       + LDS panel kernel that drops columns of rounding noise
+  E3  B^H = F^H Q ; R^H = (B^H)^H qr(B^H).Q     GEMM + Gram-Schmidt + GEMM
+  E4  R^H = U diag(sigma) V^H          one-sided Jacobi in LDS, left vectors only (relative accuracy
+                                       near sigma = 1e-6); the smallest captured sigma is checked
+  E5  U0 = Q U[:, sigma^2 >= thr]      GEMM
   E6  T = U0^H A U0 ; T X = X diag(e)  2 GEMMs + Jacobi   (Rayleigh-Ritz: eigenpairs of A)
   E7  U_E = U0 X                       GEMM
-  F   filled basis: orthonormalise (1 - U_E U_E^H) A A Omega_f  (2 GEMMs + BCGS2 against U_E)
+  F   filled basis: orthonormalise (1 - U_E U_E^H) A Omega_f   (nested running sums + Gram-Schmidt
+                                       with Cholesky-QR panels); centre right orbitals = C_RL v_L
 Per site:
   S1  O = V_bra^H V_ket                MFMA GEMM  (slater.py:1071)
   S2  W = signed gather of O           [always block | sometimes], physical orbital row
   S3  det_always, Schur complement     blocked LU in LDS panels (slater.py:1077-1090)
-  S4  all minors of all sectors        gathered-determinant kernel (slater.py:828-869)
+  S4  all minors of all sectors        one pivoted exchange of the sector matrix per workgroup, every
+                                       minor a determinant of order d <= 4 of it (det_ppt.hip;
+                                       slater.py:828-869)
+Self-check (testing.py:131-177): reconstruction deviations of the centre cut (recon.hip).
 """
 from __future__ import annotations
 
