@@ -52,16 +52,32 @@ __global__ __launch_bounds__(256) void orth_panel_kernel(const tmf_panel_desc* _
       // coefficients c_g = <q_g, v>, g < j
       if (grp < j) {
         const T* q = P + (size_t)grp * n;
-        T acc = sc<T>::zero();
-        for (int r = gl; r < n; r += 16) acc = sc<T>::fmacc(acc, q[r], v[r]);
+        // four independent accumulators: with one workgroup per CU (the panel fills the LDS) nothing else
+        // hides the LDS latency of the two dependent reads per row (measured: the kernel was 3x slower
+        // than its instruction count)
+        T acc = sc<T>::zero(), acc1 = sc<T>::zero(), acc2 = sc<T>::zero(), acc3 = sc<T>::zero();
+        int r = gl;
+        for (; r + 48 < n; r += 64) {
+          acc = sc<T>::fmacc(acc, q[r], v[r]);
+          acc1 = sc<T>::fmacc(acc1, q[r + 16], v[r + 16]);
+          acc2 = sc<T>::fmacc(acc2, q[r + 32], v[r + 32]);
+          acc3 = sc<T>::fmacc(acc3, q[r + 48], v[r + 48]);
+        }
+        for (; r < n; r += 16) acc = sc<T>::fmacc(acc, q[r], v[r]);
+        acc = sc<T>::add(sc<T>::add(acc, acc1), sc<T>::add(acc2, acc3));
         for (int o = 8; o > 0; o >>= 1) acc = sc<T>::add(acc, shfl_xor_t<T>(acc, o, 16));
         if (gl == 0) coef[grp] = acc;
       }
       __syncthreads();
       for (int r = tid; r < n; r += 256) {
-        T x = v[r];
-        for (int g = 0; g < j; ++g) x = sc<T>::fms(x, P[(size_t)g * n + r], coef[g]);
-        v[r] = x;
+        T x = v[r], x1 = sc<T>::zero();
+        int g = 0;
+        for (; g + 1 < j; g += 2) {   // two chains: the reads of consecutive columns overlap
+          x = sc<T>::fms(x, P[(size_t)g * n + r], coef[g]);
+          x1 = sc<T>::fms(x1, P[(size_t)(g + 1) * n + r], coef[g + 1]);
+        }
+        if (g < j) x = sc<T>::fms(x, P[(size_t)g * n + r], coef[g]);
+        v[r] = sc<T>::add(x, x1);
       }
       __syncthreads();
     }
