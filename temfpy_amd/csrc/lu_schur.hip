@@ -135,12 +135,22 @@ __global__ __launch_bounds__(256) void lu_schur_kernel(const tmf_schur_desc* __r
 #pragma unroll
           for (int q = 0; q < NBMAX; ++q) l[q] = (q < jb) ? P[(size_t)q * rows + jb + r] : sc<T>::zero();
           T* rowp = W + (size_t)(j0 + jb + r) + (size_t)(c0 + cc) * ldw;
-          for (int c = 0; c < nc; ++c) {
-            T x = rowp[(size_t)c * ldw];
+          // eight columns at a time: all eight loads are issued before the first store (a load after a
+          // store through the same pointer cannot be hoisted by the compiler, and with one workgroup per
+          // site nothing else hides the memory latency)
+          for (int cb = 0; cb < nc; cb += 8) {
+            T x[8];
 #pragma unroll
-            for (int q = 0; q < NBMAX; ++q)
-              if (q < jb) x = sc<T>::fms(x, l[q], Uc[c * NBMAX + q]);
-            rowp[(size_t)c * ldw] = x;
+            for (int u = 0; u < 8; ++u) x[u] = (cb + u < nc) ? rowp[(size_t)(cb + u) * ldw] : sc<T>::zero();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+              for (int q = 0; q < NBMAX; ++q)
+                if (q < jb) x[u] = sc<T>::fms(x[u], l[q], Uc[(cb + u) * NBMAX + q]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (cb + u < nc) rowp[(size_t)(cb + u) * ldw] = x[u];
           }
         }
       }
