@@ -1074,6 +1074,10 @@ class Engine:
         torch.cuda.current_stream(self.device).synchronize()
         h_out = t_out.numpy()          # the blocks below are views; they keep the pinned tensor alive
         h_det = d_det.cpu().numpy()
+        if not np.all(np.isfinite(h_det)) or np.any(h_det == 0):
+            # the overlap of the always-occupied orbitals of two neighbouring cuts is singular: the
+            # reference fails in numpy.linalg.inv at slater.py:1079 / :1086 with the same exception
+            raise np.linalg.LinAlgError("Singular matrix")
         n_local = L
 
         def site(i):   # built on first access (LazyList): views into the pinned result buffer

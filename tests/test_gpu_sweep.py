@@ -483,3 +483,62 @@ def test_non_default_truncation_parameters(svd_min, deg_tol):
         np.testing.assert_allclose(mps.bonds[b].e, cuts[b].e, rtol=0, atol=1e-13)
         np.testing.assert_allclose(mps.bonds[b].lam, cuts[b].lam, rtol=0, atol=1e-9)
     assert abs(1 - overlap(cuts, sites, mps, L // 2)) < 1e-9
+
+
+@pytest.mark.parametrize("case", ["L2", "empty", "chi1", "L1", "single_particle", "two_filled"])
+def test_edge_cases_match_oracle(case):
+    """Degenerate inputs the reference accepts: the smallest chains, an empty band, chi_max = 1, one
+    particle, a chain with exactly filled sites at its ends.  (Exact product states with several filled
+    sites inside one block are NOT among them: the reference's `inv(O_aa)`, slater.py:1079/1086, is
+    singular whenever LAPACK orders the degenerate filled orbitals unfavourably - `numpy.linalg.LinAlgError`
+    in the oracle as well.)"""
+    rng = np.random.default_rng(8)
+    chi = 16
+    if case == "two_filled":     # filled site, generic 6-site segment, empty site
+        M = rng.standard_normal((6, 6)) + 1j * rng.standard_normal((6, 6))
+        Cm, _ = orc.correlation_matrix(M + M.conj().T)
+        C = np.zeros((8, 8), complex)
+        C[0, 0] = 1.0
+        C[1:7, 1:7] = Cm
+    elif case == "L2":
+        H = rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2))
+        C, _ = orc.correlation_matrix(H + H.conj().T, N=1)
+    elif case == "L1":
+        C = np.array([[1.0]])
+    elif case == "empty":
+        C = np.zeros((5, 5))
+    elif case == "single_particle":
+        v = rng.standard_normal(9) + 1j * rng.standard_normal(9)
+        v /= np.linalg.norm(v)
+        C = np.outer(v, v.conj())
+    else:
+        M = rng.standard_normal((12, 12)) + 1j * rng.standard_normal((12, 12))
+        C, _ = orc.correlation_matrix(M + M.conj().T)
+        chi = 1
+    L = len(C)
+    cuts, sites = orc.c_to_mps(C, {"chi_max": chi})
+    mps = run_hip(C, chi)
+    assert mps.L == L
+    for b in range(L + 1):
+        assert mps.bonds[b].chi == len(cuts[b].lam)
+        np.testing.assert_allclose(mps.bonds[b].e, cuts[b].e, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(mps.lam[b], cuts[b].lam, rtol=0, atol=1e-10)
+        assert (mps.bonds[b].n_filled_left, mps.bonds[b].n_filled_right) == (cuts[b].nfL if cuts[b].nfL is not None else mps.bonds[b].n_filled_left,
+                                                                             cuts[b].nfR if cuts[b].nfR is not None else mps.bonds[b].n_filled_right)
+    if L > 1:
+        assert abs(1 - overlap(cuts, sites, mps, L // 2)) < 1e-9
+
+
+def test_singular_always_block_raises_like_the_reference():
+    """A product state with two filled sites whose overlap block is singular: numpy.linalg.LinAlgError from
+    `inv(O_aa)` in the reference (slater.py:1079/1086) - or a valid result when the arbitrary basis of the
+    degenerate filled orbitals happens to be favourable.  Never silent garbage."""
+    C = np.diag(np.array([1, 0, 1, 1, 0, 0, 1, 0, 1, 0], float))
+    try:
+        mps = run_hip(C, 8)
+    except np.linalg.LinAlgError:
+        return
+    for s in mps.sites:
+        for blk in s.blocks:
+            assert np.all(np.isfinite(blk[5]))
+    assert all(abs((b.lam**2).sum() - 1) < 1e-12 for b in mps.bonds)
