@@ -335,15 +335,20 @@ class Engine:
                     o += len(it["w"])
             t_w = self._up(np.concatenate(ws + [np.zeros(1)]))
         d = np.zeros(nchk, nat.recon_desc)
-        tiles = []
-        for i, it in enumerate(items):
-            d[i] = (it["T"], it["X"], it["Y"], 0 if i not in w_off else t_w.data_ptr() + 8 * w_off[i],
-                    d_dev.data_ptr() + 8 * i, it["rows"], it["cols"], it["q"], it.get("inner", 0), it.get("ldt", 1),
-                    it["ldx"], it["ldy"], it["mode"], it.get("y_reverse", 0), 0)
-            tr, tc = _cdiv(it["rows"], 64), _cdiv(it["cols"], 64)
-            g = np.stack(np.meshgrid(np.arange(tr), np.arange(tc), indexing="ij"), -1).reshape(-1, 2)
-            tiles.append(np.concatenate((np.full((len(g), 1), i), g), axis=1))
-        tiles = np.ascontiguousarray(np.concatenate(tiles), np.int32)
+        col = lambda key, default=0: np.array([it.get(key, default) for it in items])  # noqa: E731
+        d["T"], d["X"], d["Y"] = col("T"), col("X"), col("Y")
+        d["w"] = [0 if i not in w_off else t_w.data_ptr() + 8 * w_off[i] for i in range(nchk)]
+        d["out"] = d_dev.data_ptr() + 8 * np.arange(nchk)
+        for key, default in (("rows", 0), ("cols", 0), ("q", 0), ("inner", 0), ("ldt", 1), ("ldx", 1), ("ldy", 1),
+                             ("mode", 0), ("y_reverse", 0)):
+            d[key] = col(key, default)
+        # tile table (problem, tile_row, tile_col) of all items at once
+        tr, tc = _cdiv(d["rows"].astype(np.int64), 64), _cdiv(d["cols"].astype(np.int64), 64)
+        cnt = tr * tc
+        prob = np.repeat(np.arange(nchk), cnt)
+        local = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        tiles = np.ascontiguousarray(np.stack((prob, local // np.maximum(tc[prob], 1), local % np.maximum(tc[prob], 1)), axis=1),
+                                     np.int32)
         if len(tiles) == 0:
             return d_dev
         t_d, t_t = self._up(d), self._up(tiles)
