@@ -86,7 +86,7 @@ def test_pfaffian_sweep_matches_reference_fixture(name):
         np.testing.assert_allclose(mps.sites[i].norm, abs(g[f"s{i}_norm"]), rtol=1e-8)
 
 
-@pytest.mark.parametrize("L,chi,seed", [(12, 32, 7), (20, 64, 8), (32, 64, 9)])
+@pytest.mark.parametrize("L,chi,seed", [(12, 32, 7), (20, 64, 8), (32, 64, 9), (44, 64, 21), (56, 48, 22)])
 def test_pfaffian_sweep_larger_random(L, chi, seed):
     import sys
     sys.path.insert(0, GOLDEN)
