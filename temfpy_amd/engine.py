@@ -713,26 +713,31 @@ class Engine:
             # ---- host: best-first enumeration for every cut (one threaded C++ call) ----------------
             t0 = time.perf_counter()
             sectors = _sector_list(trunc, L)
-            cut_idx = {}
-            for i in range(ncs):
-                cut_idx[(int(cs_b[i]), int(cs_side[i]))] = i
-            my_cuts = sorted({b for b, _ in need})
+            # lookup tables: cut-side problem of (cut, side), position of a cut in this rank's list (-1 = absent)
+            side_idx = np.full((L + 1, 2), -1, np.int64)
+            side_idx[cs_b, cs_side] = np.arange(ncs)
+            my_cuts = np.unique(cs_b)
             ncut = len(my_cuts)
-            cpos = {b: j for j, b in enumerate(my_cuts)}
-            e_left, nfl, nfr = [None] * ncut, np.zeros(ncut, np.int32), np.zeros(ncut, np.int32)
-            for j, b in enumerate(my_cuts):
-                iL, iR = cut_idx.get((b, 0)), cut_idx.get((b, 1))
-                if iL is not None:
-                    e_left[j] = e_side[iL]
-                    nfl[j] = nf[iL]
-                    nfr[j] = nf[iR] if iR is not None else n_fermion - len(e_left[j]) - nfl[j]  # slater.py:167
-                else:
-                    e_left[j] = (1.0 - e_side[iR])[::-1].copy()  # slater.py:386
-                    nfr[j] = nf[iR]
-                    nfl[j] = n_fermion - len(e_left[j]) - nfr[j]  # slater.py:172
-            kk_cut = np.array([len(x) for x in e_left], np.int32)
-            e_off = np.concatenate(([0], np.cumsum(kk_cut)))[:-1].astype(np.int64)
-            e_pool = np.concatenate(e_left + [np.zeros(1)])
+            cpos = np.full(L + 1, -1, np.int64)
+            cpos[my_cuts] = np.arange(ncut)
+            iL, iR = side_idx[my_cuts, 0], side_idx[my_cuts, 1]
+            hasL, hasR = iL >= 0, iR >= 0
+            src = np.where(hasL, iL, iR)                       # the side whose eigenvalues define e_left
+            kk_cut = k[src].astype(np.int32)
+            nf_src = nf[src]
+            other = n_fermion - kk_cut - nf_src                # slater.py:167 / :172
+            nfl = np.where(hasL, nf_src, np.where(hasR, other, 0)).astype(np.int32)
+            nfr = np.where(hasL, np.where(hasR, nf[np.maximum(iR, 0)], other), nf_src).astype(np.int32)
+            # left eigenvalues of every cut, flat: from the left block as they are, from the right block as
+            # 1 - e reversed (slater.py:386); e_side[i] are the k[i] kept Ritz values of problem i
+            e_off = (np.cumsum(kk_cut) - kk_cut).astype(np.int64)
+            tot = int(kk_cut.sum())
+            owner = np.repeat(np.arange(ncut), kk_cut)
+            t_in = np.arange(tot) - e_off[owner]
+            rev = ~hasL[owner]
+            rows_ = src[owner]
+            vals = E2[rows_, ent0[rows_] + np.where(rev, kk_cut[owner] - 1 - t_in, t_in)]   # kept Ritz values
+            e_pool = np.concatenate((np.where(rev, 1.0 - vals, vals), np.zeros(1)))
             sec_arr = None if sectors is None else np.ascontiguousarray(sectors, np.int64)
             cap = int(trunc.chi_max) + 1 if trunc.chi_max else 4096
             self.timings["host_enum_setup"] = time.perf_counter() - t0
@@ -759,15 +764,13 @@ class Engine:
                 # plain memcpys - a boolean-mask compaction of the kept prefixes cost 5 ms here
                 o_sets, o_lam, o_q, o_chi = c_sets.copy(), c_lam.copy(), c_q.copy(), c_chi.copy()
                 info = logger.isEnabledFor(logging.INFO)
-                cut_pos = {b: j for j, b in enumerate(my_cuts)}
-
                 def bond(b):
-                    j = cut_pos.get(b)
-                    if j is None:
+                    j = int(cpos[b])
+                    if j < 0:
                         return None          # a cut outside this rank's site range
                     ch = int(o_chi[j])
                     lam_raw = o_lam[j, :ch]
-                    return BondData(x=b, e=e_left[j], n_filled_left=int(nfl[j]), n_filled_right=int(nfr[j]),
+                    return BondData(x=b, e=e_pool[int(e_off[j]): int(e_off[j]) + int(kk_cut[j])], n_filled_left=int(nfl[j]), n_filled_right=int(nfr[j]),
                                     masks=o_sets[j, :ch], lam_raw=lam_raw,
                                     lam=lam_raw / np.sqrt(np.dot(lam_raw, lam_raw)), q_left=o_q[j, :ch],
                                     n_checked=int(c_chk[j]))
@@ -789,10 +792,8 @@ class Engine:
             mode = (my_sites >= oc).astype(np.int32)
             bb = np.where(mode == 0, my_sites, my_sites + 1)
             kb_ = np.where(mode == 0, my_sites + 1, my_sites)
-            ib = np.array([cut_idx[(int(b_), int(m_))] for b_, m_ in zip(bb, mode)])
-            ik = np.array([cut_idx[(int(b_), int(m_))] for b_, m_ in zip(kb_, mode)])
-            cb_i = np.array([cpos[int(b_)] for b_ in bb])
-            ck_i = np.array([cpos[int(b_)] for b_ in kb_])
+            ib, ik = side_idx[bb, mode], side_idx[kb_, mode]
+            cb_i, ck_i = cpos[bb], cpos[kb_]
             chi_b, chi_k = c_chi[cb_i], c_chi[ck_i]
             jobs = np.zeros(ns, nat.site_job)
             jobs["mode"], jobs["cut_b"], jobs["cut_k"] = mode, cb_i, ck_i
@@ -827,7 +828,7 @@ class Engine:
 
             return dict(make_bonds=make_bonds, jobs=jobs, souts=souts, row_sel=row_sel, row_sign=row_sign, col_sel=col_sel,
                         col_sign=col_sign, bra_p=bra_p, bra_alpha=bra_alpha, sec_buf=sec_buf, pool=pool, mode=mode,
-                        ib=ib, ik=ik, chi_b=chi_b, chi_k=chi_k, my_sites=my_sites, ns=ns, cut_idx=cut_idx)
+                        ib=ib, ik=ik, chi_b=chi_b, chi_k=chi_k, my_sites=my_sites, ns=ns)
 
         # the integer host phase (C++, GIL released) runs while the filled-basis launches are enqueued
         import threading
