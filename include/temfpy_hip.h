@@ -378,6 +378,21 @@ int tmf_site_prepare_batch(int nsites, const tmf_site_job* jobs, const uint64_t*
                            int8_t* col_sign, int32_t* bra_p, int32_t* bra_alpha, tmf_sector* sectors,
                            uint8_t* idx_pool, tmf_site_out* outs, int nthreads);
 
+/* Host: tile descriptors of tmf_det_ppt_batched for all sites of a sweep from the outputs of
+ * tmf_site_prepare_batch (one tile = one charge sector, or a range of its bra rows beyond
+ * `pairs_per_tile` pairs; largest tiles first).  Sectors that kernel does not take are returned in
+ * `rest` as (site << 32 | sector).  Call with tiles = NULL to count; returns the number of tiles.
+ * flops_n3 = sum over sectors of pairs * n^3 (the caller multiplies by 8/3 or 2/3). */
+typedef struct {
+  uint64_t S, scale, idx_base, out_base;   /* device addresses of the site's Schur complement, det_always,
+                                              index pool and output block */
+  int32_t lds, pad;                        /* leading dimension of S */
+} tmf_det_site;                            /* 40 bytes */
+int64_t tmf_det_tiles_build(int nsites, const tmf_site_job* jobs, const tmf_site_out* outs, const tmf_sector* sectors,
+                            const tmf_det_site* sites, int elem_bytes, int64_t pairs_per_tile, tmf_det_desc* tiles,
+                            int64_t tile_cap, int64_t* rest, int64_t rest_cap, int64_t* n_rest, int32_t* lds_max,
+                            double* flops_n3, int64_t* n_pairs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,8 @@ assert recon_desc.itemsize == 80
 bcgs_desc = np.dtype([("base", "<u8"), ("scratch", "<u8"), ("norms", "<u8"), ("rows", "<i4"), ("ld", "<i4"),
                       ("c_begin", "<i4"), ("c_end", "<i4")])
 assert bcgs_desc.itemsize == 40
+det_site = np.dtype([("S", "<u8"), ("scale", "<u8"), ("idx_base", "<u8"), ("out_base", "<u8"), ("lds", "<i4"), ("pad", "<i4")])
+assert det_site.itemsize == 40
 norms_desc = np.dtype([("src", "<u8"), ("out", "<u8"), ("n", "<i4"), ("c", "<i4"), ("lds_", "<i4"), ("pad", "<i4")])
 jacobi_desc = np.dtype([("X", "<u8"), ("V", "<u8"), ("U", "<u8"), ("s", "<u8"), ("count", "<u8"),
                         ("thresh2", "<f8"), ("p", "<i4"), ("ldx", "<i4"), ("ldv", "<i4"), ("ldu", "<i4")])
@@ -74,7 +76,7 @@ SYMBOLS = [
     "tmf_jacobi_block_batched", "tmf_nested_products_batched", "tmf_recon_error_batched", "tmf_lu_schur_batched",
     "tmf_det_gather_batched", "tmf_det_reduced_batched", "tmf_det_ppt_batched", "tmf_transpose", "tmf_fill_normal",
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_column_norms_batched", "tmf_cut_vectors",
-    "tmf_site_prepare", "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_pf_gather_batched",
+    "tmf_site_prepare", "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_det_tiles_build", "tmf_pf_gather_batched",
     "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched",
 ]
 
@@ -112,6 +114,8 @@ def load():
     lib.tmf_lu_schur_batched.argtypes = [i32, vp, i32, i32, vp]
     lib.tmf_det_gather_batched.argtypes = [i32, i32, vp, i32, i32, vp]
     lib.tmf_det_ppt_batched.argtypes = [i32, vp, i32, i32, vp]
+    lib.tmf_det_tiles_build.argtypes = [i32, vp, vp, vp, vp, i32, i64, vp, i64, vp, i64, vp, vp, vp, vp]
+    lib.tmf_det_tiles_build.restype = i64
     lib.tmf_det_reduced_batched.argtypes = [i32, i32, vp, i32, i32, vp]
     lib.tmf_pf_gather_batched.argtypes = [i32, i32, vp, i32, i32, vp]
     for fn in (lib.tmf_nambu_assemble_batched, lib.tmf_nambu_w_batched, lib.tmf_pf_matrix_batched):

@@ -546,3 +546,72 @@ extern "C" int tmf_site_prepare_batch(int nsites, const tmf_site_job* jobs, cons
                             outs + i);
   });
 }
+
+
+// -------------------------------------------------------------------------------------------
+// Tile descriptors of the pivoted-exchange determinant kernel (det_ppt.hip) for all sites of a sweep:
+// one tile = one charge sector (or a range of its bra rows when the sector has more than
+// `pairs_per_tile` pairs).  Sectors the kernel does not take (order 0 or > 32, more than 64 rows or
+// columns) are listed in `rest` for the caller's general path.  Tiles are returned largest first.
+// -------------------------------------------------------------------------------------------
+extern "C" int64_t tmf_det_tiles_build(int nsites, const tmf_site_job* jobs, const tmf_site_out* outs,
+                                       const tmf_sector* sectors, const tmf_det_site* sites, int elem_bytes,
+                                       int64_t pairs_per_tile, tmf_det_desc* tiles, int64_t tile_cap, int64_t* rest,
+                                       int64_t rest_cap, int64_t* n_rest, int32_t* lds_max, double* flops_n3,
+                                       int64_t* n_pairs) {
+  struct Ref {
+    int site, sec;
+    int32_t a0, a1;
+    int64_t pairs;
+  };
+  std::vector<Ref> refs;
+  int64_t nr = 0, pairs_tot = 0;
+  double fl = 0.0;
+  int lmax = 0;
+  auto a16 = [](int64_t x) { return (x + 15) & ~(int64_t)15; };
+  for (int i = 0; i < nsites; ++i) {
+    const tmf_site_out& o = outs[i];
+    for (int q = 0; q < o.n_sectors; ++q) {
+      const tmf_sector& sc_ = sectors[jobs[i].sec_off + q];
+      const int64_t nsb = sc_.r1 - sc_.r0, nsk = sc_.c1 - sc_.c0;
+      if (sc_.n < 1 || sc_.n > 32 || o.sb > 64 || o.sk > 64) {
+        if (nr < rest_cap) rest[nr] = ((int64_t)i << 32) | (int64_t)q;
+        ++nr;
+        continue;
+      }
+      int64_t ta = (pairs_per_tile + nsk - 1) / nsk;
+      if (ta < 1) ta = 1;
+      if (ta > nsb) ta = nsb;
+      for (int64_t a0 = 0; a0 < nsb; a0 += ta) {
+        const int64_t a1 = std::min(nsb, a0 + ta);
+        refs.push_back(Ref{i, q, (int32_t)a0, (int32_t)a1, (a1 - a0) * nsk});
+        const int64_t scr = std::max<int64_t>(264, (int64_t)sc_.n * sc_.n);
+        const int64_t lds = a16(a16((int64_t)o.sb * o.sk * elem_bytes) + (nsk + (a1 - a0)) * 8) + 4 * (scr * elem_bytes + 288);
+        lmax = std::max<int64_t>(lmax, lds);
+      }
+      pairs_tot += nsb * nsk;
+      fl += (double)(nsb * nsk) * (double)sc_.n * sc_.n * sc_.n;
+    }
+  }
+  *n_rest = nr;
+  *lds_max = lmax;
+  *flops_n3 = fl;
+  *n_pairs = pairs_tot;
+  const int64_t nt = (int64_t)refs.size();
+  if (!tiles || nt > tile_cap || nr > rest_cap) return nt;   // counting pass (or buffers too small)
+  std::stable_sort(refs.begin(), refs.end(), [](const Ref& x, const Ref& y) { return x.pairs > y.pairs; });
+  for (int64_t t = 0; t < nt; ++t) {
+    const Ref& r = refs[t];
+    const tmf_site_out& o = outs[r.site];
+    const tmf_sector& sc_ = sectors[jobs[r.site].sec_off + r.sec];
+    const tmf_det_site& st = sites[r.site];
+    tmf_det_desc& d = tiles[t];
+    d.S = st.S, d.scale = st.scale;
+    d.bra_idx = st.idx_base + (uint64_t)sc_.bra_off;
+    d.ket_idx = st.idx_base + (uint64_t)sc_.ket_off;
+    d.out = st.out_base + (uint64_t)sc_.out_off * (uint64_t)elem_bytes;
+    d.sb = o.sb, d.sk = o.sk, d.lds = st.lds, d.n = sc_.n;
+    d.nsb = sc_.r1 - sc_.r0, d.nsk = sc_.c1 - sc_.c0, d.a0 = r.a0, d.a1 = r.a1;
+  }
+  return nt;
+}

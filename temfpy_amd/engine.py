@@ -461,7 +461,7 @@ class Engine:
             views.append(h[: t.numel()].numpy())
         return _GpuWait(self.torch, self.device), views
 
-    def _hbuf(self, name, shape, dtype, zero=False):
+    def _hbuf(self, name, shape, dtype, zero=False, pinned=False):
         """Persistent host scratch (grow-only, pre-faulted).  Fresh ``np.zeros`` arrays of this size
         are lazily mapped, and their first-touch page faults inside the 16 enumeration threads
         serialise on the process's mmap lock (measured: 110 ms instead of 26 ms for the L = 1024
@@ -474,7 +474,12 @@ class Engine:
             pool = self._hpool = {}
         raw = pool.get(name)
         if raw is None or raw.nbytes < nbytes:
-            raw = np.empty(max(int(nbytes * 1.25), 4096), np.uint8)
+            if pinned:   # page-locked: the async upload needs no staging copy (kept alive next to the view)
+                t_raw = self.torch.empty(max(int(nbytes * 1.25), 4096), dtype=self.torch.uint8, pin_memory=True)
+                raw = t_raw.numpy()
+                pool[name + "/tensor"] = t_raw
+            else:
+                raw = np.empty(max(int(nbytes * 1.25), 4096), np.uint8)
             raw.fill(0)
             pool[name] = raw
         out = raw[:nbytes].view(dt).reshape(shape)
@@ -816,7 +821,7 @@ class Engine:
             bra_p, bra_alpha = np.empty(br_tot + 1, np.int32), np.empty(br_tot + 1, np.int32)
             bra_p.fill(0), bra_alpha.fill(0)
             sec_buf = np.zeros(sc_tot + 1, nat.sector)
-            pool = self._hbuf("idx_pool", (ix_tot + 1,), np.uint8)
+            pool = self._hbuf("idx_pool", (ix_tot + 1,), np.uint8, pinned=True)   # uploaded straight from here
             souts = np.zeros(ns, nat.site_out)
             t1 = time.perf_counter()
             nat.check(self.lib.tmf_site_prepare_batch(
@@ -974,23 +979,55 @@ class Engine:
         # ---- S4: all minors ----------------------------------------------------------------------
         t0 = time.perf_counter()
         out_off, out_tot = offsets(souts["out_elems"])
-        t_pool = self._up(pool)
+        # the index pool (19 MB) was written into pinned memory by the site preparation: one async copy
+        t_pin = self._hpool["idx_pool/tensor"][: pool.nbytes]
+        t_pool = torch.empty(pool.nbytes, dtype=torch.uint8, device=self.device)
+        t_pool.copy_(t_pin, non_blocking=True)
+        self._keep.append(t_pool)
         d_out = self._alloc(out_tot)
         Sp = Wp + (ka + ka * np.maximum(mb, 1)) * el
-        nsec = souts["n_sectors"].astype(np.int64)
-        sec_site = np.repeat(np.arange(L), nsec)
-        sec_ptr = np.concatenate(([0], np.cumsum(nsec)))
-        sec_all = sec_buf[jobs["sec_off"][sec_site] + (np.arange(int(nsec.sum())) - sec_ptr[:-1][sec_site])]
         n_det = 0
+        flop_per_det = (8.0 / 3.0) if cplx else (2.0 / 3.0)  # LU of an n x n complex / real matrix
+        nsec = souts["n_sectors"].astype(np.int64)
+        sec_ptr = np.concatenate(([0], np.cumsum(nsec)))
+        rest_keys = None
+        if self.det_method == "ppt":
+            # tiles of the pivoted-exchange kernel for every sector it takes, built by the host library
+            ds = np.zeros(L, nat.det_site)
+            ds["S"], ds["scale"], ds["lds"] = Sp, detp, np.maximum(mb, 1)
+            ds["idx_base"] = t_pool.data_ptr() + jobs["idx_off"]
+            ds["out_base"] = d_out.data_ptr() + out_off * el
+            n_rest, lds_max, fl3, npairs = (np.zeros(1, np.int64), np.zeros(1, np.int32), np.zeros(1), np.zeros(1, np.int64))
+            args = (L, nat._p(jobs), nat._p(souts), nat._p(sec_buf), nat._p(ds), el, 16384)
+            nt = int(self.lib.tmf_det_tiles_build(*args, None, 0, None, 0, nat._p(n_rest), nat._p(lds_max), nat._p(fl3),
+                                                  nat._p(npairs)))
+            tiles = np.zeros(max(nt, 1), nat.det_desc)
+            rest_keys = np.zeros(max(int(n_rest[0]), 1), np.int64)
+            nt = int(self.lib.tmf_det_tiles_build(*args, nat._p(tiles), nt, nat._p(rest_keys), len(rest_keys), nat._p(n_rest),
+                                                  nat._p(lds_max), nat._p(fl3), nat._p(npairs)))
+            rest_keys = rest_keys[: int(n_rest[0])]
+            if nt > 0:
+                t_dd = self._up(tiles[:nt])
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(torch.cuda.current_stream(self.device))
+                nat.check(self.lib.tmf_det_ppt_batched(self.dtype, t_dd.data_ptr(), nt, int(lds_max[0]), self.stream),
+                          "tmf_det_ppt_batched")
+                ev1.record(torch.cuda.current_stream(self.device))
+                self.det_events.append(("ppt", ev0, ev1, float(fl3[0]) * flop_per_det, int(npairs[0])))
+                n_det += int(npairs[0])
+        # general path: every sector (TMF_DET_METHOD=reduced) or the ones the exchange kernel does not take
+        if rest_keys is None:
+            sec_site = np.repeat(np.arange(L), nsec)
+            sec_loc = np.arange(int(nsec.sum())) - sec_ptr[:-1][sec_site]
+        else:
+            sec_site, sec_loc = (rest_keys >> 32).astype(np.int64), (rest_keys & 0xFFFFFFFF).astype(np.int64)
+        sec_all = sec_buf[jobs["sec_off"][sec_site] + sec_loc]
         if len(sec_all):
             nq = sec_all["n"].astype(np.int64)
             nsb_ = (sec_all["r1"] - sec_all["r0"]).astype(np.int64)
             nsk_ = (sec_all["c1"] - sec_all["c0"]).astype(np.int64)
             cls_ = np.where(nq <= 32, nq, 64)  # exact order for n <= 32 (templated kernels), generic above
-            # sectors whose matrix and order fit the pivoted-exchange kernel (det_ppt.hip): one launch for all
-            sec_ppt = ((nq >= 1) & (nq <= 32) & (sbv[sec_site] <= 64) & (skv[sec_site] <= 64)
-                       & (self.det_method == "ppt"))
-            ta = np.clip(_cdiv(np.where(sec_ppt, 16384, 4096), nsk_), 1, nsb_)
+            ta = np.clip(_cdiv(4096, nsk_), 1, nsb_)
             ntile = _cdiv(nsb_, ta)
             tsec = np.repeat(np.arange(len(sec_all)), ntile)
             tloc = np.arange(int(ntile.sum())) - np.repeat(np.cumsum(ntile) - ntile, ntile)
@@ -1016,31 +1053,16 @@ class Engine:
             pairs = (dd_all["a1"] - dd_all["a0"]).astype(np.int64) * dd_all["nsk"]
             # reduced-minor kernel (one Gauss-Jordan per bra row-set) whenever the sometimes-matrix has
             # <= 64 columns and 1 <= n <= 32; the direct kernel covers the rest
-            use_ppt = sec_ppt[tsec]
-            use_red = (tcls >= 1) & (tcls <= 32) & (skv[tsite] <= 64) & (not self.force_direct_det) & ~use_ppt
+            use_red = (tcls >= 1) & (tcls <= 32) & (skv[tsite] <= 64) & (not self.force_direct_det)
             lneed_red = nat.reduced_det_lds(el, nq[tsec], sbv[tsite], skv[tsite], nsk_[tsec], ta[tsec]) - 16
             use_red &= lneed_red + 16 <= 160 * 1024
             lneed = np.where(use_red, lneed_red, lneed)
-            lneed = np.where(use_ppt, nat.ppt_det_lds(el, sbv[tsite], skv[tsite], nsk_[tsec], ta[tsec], nq[tsec]), lneed)
             if int(lneed.max()) > 160 * 1024:
                 raise NotImplementedError("determinant tile exceeds the 160 KiB LDS of a CU")
-            flop_per_det = (8.0 / 3.0) if cplx else (2.0 / 3.0)  # LU of an n x n complex / real matrix
-            selp = np.nonzero(use_ppt)[0]
-            if selp.size:
-                selp = selp[np.argsort(-pairs[selp], kind="stable")]          # biggest tiles first
-                t_dd = self._up(dd_all[selp])
-                flops = float((pairs[selp].astype(np.float64) * nq[tsec][selp].astype(np.float64) ** 3).sum()) * flop_per_det
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ev0.record(torch.cuda.current_stream(self.device))
-                nat.check(self.lib.tmf_det_ppt_batched(self.dtype, t_dd.data_ptr(), len(selp), int(lneed[selp].max()),
-                                                       self.stream), "tmf_det_ppt_batched")
-                ev1.record(torch.cuda.current_stream(self.device))
-                self.det_events.append(("ppt", ev0, ev1, flops, int(pairs[selp].sum())))
-                n_det += int(pairs[selp].sum())
-            launches = sorted({(int(c_), bool(r_)) for c_, r_ in zip(tcls[~use_ppt].tolist(), use_red[~use_ppt].tolist())},
-                              key=lambda cr: -int(pairs[(tcls == cr[0]) & (use_red == cr[1]) & ~use_ppt].sum()))
+            launches = sorted({(int(c_), bool(r_)) for c_, r_ in zip(tcls.tolist(), use_red.tolist())},
+                              key=lambda cr: -int(pairs[(tcls == cr[0]) & (use_red == cr[1])].sum()))
             for cls, red in launches:
-                selc = np.nonzero((tcls == cls) & (use_red == red) & ~use_ppt)[0]
+                selc = np.nonzero((tcls == cls) & (use_red == red))[0]
                 if selc.size == 0:
                     continue
                 # biggest tiles first
@@ -1092,7 +1114,8 @@ class Engine:
                 return None          # a site outside this rank's range
             m_ = "left" if mode[j] == 0 else "right"
             blocks = []
-            for sec in sec_all[sec_ptr[j]: sec_ptr[j + 1]]:
+            so_ = int(jobs["sec_off"][j])
+            for sec in sec_buf[so_: so_ + int(nsec[j])]:
                 r0, r1, c0, c1 = (int(sec[f]) for f in ("r0", "r1", "c0", "c1"))
                 o = out_off[j] + int(sec["out_off"])
                 blocks.append((int(sec["q"]), r0, r1, c0, c1, h_out[o: o + (r1 - r0) * (c1 - c0)].reshape(r1 - r0, c1 - c0)))
