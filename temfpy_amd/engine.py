@@ -928,6 +928,24 @@ class Engine:
             d_chk = self.recon_errors(items)
         self._tick("F_filled", t0)
 
+        # ---- S1 ahead of the host results: O = V_bra^H V_ket needs the orbital matrices only ---------
+        t0 = time.perf_counter()
+        e_sites = np.arange(s_lo, s_hi)
+        e_mode = (e_sites >= oc).astype(np.int64)
+        e_sidx = np.full((L + 1, 2), -1, np.int64)
+        e_sidx[cs_b, cs_side] = np.arange(ncs)
+        e_ib = e_sidx[np.where(e_mode == 0, e_sites, e_sites + 1), e_mode]
+        e_ik = e_sidx[np.where(e_mode == 0, e_sites + 1, e_sites), e_mode]
+        cb, ck = ncolV[e_ib], ncolV[e_ik]           # columns of V_bra / V_ket
+        nb_rows = n[e_ib]                            # contraction length = bra orbitals
+        oO, tO = offsets(cb * ck)
+        d_O = self._alloc(tO)
+        Op = d_O.data_ptr() + oO * el
+        Vk_sub = Vp[e_ik] + np.where(e_mode == 1, 1, 0) * el     # right mode: physical orbital is row 0 of the ket block
+        physp = Vp[e_ik] + np.where(e_mode == 1, 0, nb_rows) * el
+        self.gemm(1, 1.0, 0.0, Vp[e_ib], Vk_sub, Op, cb, ck, nb_rows, ld1[e_ib], ld1[e_ik], np.maximum(cb, 1))
+        self._tick("S_overlap_gemm", t0)
+
         yield _ThreadWait(th)
         th.join()
         if "exc" in hp:
@@ -938,6 +956,20 @@ class Engine:
         bra_p, bra_alpha, sec_buf = ho["bra_p"], ho["bra_alpha"], ho["sec_buf"]
         ib, ik, chi_b, chi_k, my_sites, ns = ho["ib"], ho["ik"], ho["chi_b"], ho["chi_k"], ho["my_sites"], ho["ns"]
         L_all, L = L, ns  # from here on "L" counts the sites of this shard
+        # the index pool (19 MB) was written into pinned memory by the site preparation; it goes up on a side
+        # stream while the overlap GEMM and the LU run (on the launch stream the copy sat between the LU and
+        # the determinant kernel: 1.5 ms of idle SIMDs)
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        t_pin = self._hpool["idx_pool/tensor"][: pool.nbytes]
+        t_pool = torch.empty(pool.nbytes, dtype=torch.uint8, device=self.device)
+        self._keep.append(t_pool)
+        self._copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._copy_stream):
+            t_pool.copy_(t_pin, non_blocking=True)
+            pool_ready = torch.cuda.Event()
+            pool_ready.record(self._copy_stream)
+        pool_upload = (t_pool, pool_ready)
 
         # ---- S1/S2: overlaps and W assembly ---------------------------------------------------
         t0 = time.perf_counter()
@@ -945,17 +977,12 @@ class Engine:
         sbv, skv = souts["sb"].astype(np.int64), souts["sk"].astype(np.int64)
         if int((sbv * skv).max()) * el > 64 * 1024:
             raise NotImplementedError("sometimes-matrix larger than the 64 KiB LDS stage of the determinant kernel")
-        cb, ck = ncolV[ib], ncolV[ik]           # columns of V_bra / V_ket
-        nb_rows = n[ib]                          # contraction length = bra orbitals
-        oO, tO = offsets(cb * ck)
+        assert np.array_equal(ib, e_ib) and np.array_equal(ik, e_ik)
         oW, tW = offsets(mb * mk)
-        d_O, d_W = self._alloc(tO), self._alloc(tW)
+        d_W = self._alloc(tW)
         d_det = self._alloc(L)
-        Op, Wp = d_O.data_ptr() + oO * el, d_W.data_ptr() + oW * el
+        Wp = d_W.data_ptr() + oW * el
         detp = d_det.data_ptr() + np.arange(L) * el
-        Vk_sub = Vp[ik] + np.where(mode == 1, 1, 0) * el     # right mode: physical orbital is row 0 of the ket block
-        physp = Vp[ik] + np.where(mode == 1, 0, nb_rows) * el
-        self.gemm(1, 1.0, 0.0, Vp[ib], Vk_sub, Op, cb, ck, nb_rows, ld1[ib], ld1[ik], np.maximum(cb, 1))
         # selection arrays (already flat, at the offsets given to the C++ call)
         rs_off, cs_off = jobs["row_off"], jobs["col_off"]
         t_rs, t_cs, t_rg, t_cg = self._up(row_sel), self._up(col_sel), self._up(row_sign), self._up(col_sign)
@@ -979,14 +1006,11 @@ class Engine:
         # ---- S4: all minors ----------------------------------------------------------------------
         t0 = time.perf_counter()
         out_off, out_tot = offsets(souts["out_elems"])
-        # the index pool (19 MB) was written into pinned memory by the site preparation: one async copy
-        t_pin = self._hpool["idx_pool/tensor"][: pool.nbytes]
-        t_pool = torch.empty(pool.nbytes, dtype=torch.uint8, device=self.device)
-        t_pool.copy_(t_pin, non_blocking=True)
-        self._keep.append(t_pool)
+        t_pool, pool_ready = pool_upload
         d_out = self._alloc(out_tot)
         Sp = Wp + (ka + ka * np.maximum(mb, 1)) * el
         n_det = 0
+        torch.cuda.current_stream(self.device).wait_event(pool_ready)   # the determinant kernels read the pool
         flop_per_det = (8.0 / 3.0) if cplx else (2.0 / 3.0)  # LU of an n x n complex / real matrix
         nsec = souts["n_sectors"].astype(np.int64)
         sec_ptr = np.concatenate(([0], np.cumsum(nsec)))
