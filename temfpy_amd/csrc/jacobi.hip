@@ -13,6 +13,14 @@
 
 namespace tmf {
 
+// 1 / sqrt(x): v_rsq_f64 (about 1e-8 relative... refined by two Newton steps to ~1 ulp); x > 0, normal range
+__device__ inline double rsqrt_fast(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * (1.5 - 0.5 * x * r * r);
+  r = r * (1.5 - 0.5 * x * r * r);
+  return r;
+}
+
 template <typename T, bool WITH_V>
 __global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __restrict__ desc,
                                                      int32_t* __restrict__ sweeps_out) {
@@ -100,13 +108,20 @@ __global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __re
             ga = sc<T>::add(ga, shfl_xor_t<T>(ga, o, tpp));
           }
           const double g2 = sc<T>::abs2(ga);
-          if (g2 > tol2 * al * be && g2 > 0.0) {
-            const double g = sqrt(g2);
-            const double zeta = (be - al) / (2.0 * g);
-            const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+          if (g2 > tol2 * al * be && g2 > 1e-280) {   // (below: rsq / rcp without denormal handling)
+            // Rotation parameters with v_rsq_f64 / v_rcp_f64 + Newton steps instead of IEEE sqrt / div
+            // sequences (every lane of the pair computes them redundantly, and that scalar math was about
+            // half of the kernel's instruction count).  Only c^2 + s^2 = 1 has to hold to eps (it does:
+            // s = c t with c refined to eps); a last-bit error in the angle costs nothing.
+            const double ginv = rsqrt_fast(g2);                       // 1 / |gamma|
+            const double zeta = 0.5 * (be - al) * ginv;
+            const double az = fabs(zeta);
+            const double w1 = 1.0 + zeta * zeta;
+            const double den = az + w1 * rsqrt_fast(w1);              // |zeta| + sqrt(1 + zeta^2)
+            const double t = copysign(sc<double>::inv_fast(den), zeta);
+            const double c = rsqrt_fast(1.0 + t * t), s = c * t;
             // phase e^{-i theta} of gamma, folded into column j
-            const T ph = sc<T>::scale(sc<T>::conj(ga), 1.0 / g);
+            const T ph = sc<T>::scale(sc<T>::conj(ga), ginv);
             const T sph = sc<T>::scale(ph, s), cph = sc<T>::scale(ph, c);
             for (int r = pl; r < p; r += tpp) {
               const T a = xi[r], b = xj[r];
