@@ -248,6 +248,17 @@ typedef struct {
 } tmf_gather_desc;           /* 80 bytes */
 int tmf_gather_signed_batched(int dtype, const tmf_gather_desc* d_desc, int nprob, void* stream);
 
+/* Strided block copies, optionally transposing: dst = src (flags 0), dst = src^T (flags 1) or
+ * dst = src^H (flags 3); rows x cols is the shape of the SOURCE block, both column-major.  Regroups the
+ * charge blocks of MPS tensors between the (p vL) x vR and vL x (p vR) matrix forms of the
+ * canonicalisation sweeps behind gutzwiller.py:266 / :471 (TeNPy `combine_legs` / `split_legs`).
+ * max_tiles: largest number of 32 x 32 tiles of one block (sizes the grid; more tiles are looped). */
+typedef struct {
+  uint64_t src, dst;
+  int32_t rows, cols, lds_, ldd, flags, pad;
+} tmf_copy_desc;             /* 40 bytes */
+int tmf_copy_blocks_batched(int dtype, const tmf_copy_desc* d_desc, int nprob, int max_tiles, void* stream);
+
 /* Products of nested blocks of one D x D matrix C (column-major) with a shared block Omega whose
  * rows are indexed by the GLOBAL orbital index: for every cut position x with dest[x] != 0
  *

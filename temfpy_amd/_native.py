@@ -62,6 +62,9 @@ nambu_w_desc = np.dtype([("Vr", "<u8"), ("W", "<u8"), ("idx1", "<u8"), ("idx2", 
                          ("nb", "<i4"), ("ldv", "<i4"), ("ldw", "<i4"), ("pad", "<i4")])
 pf_matrix_desc = np.dtype([("S", "<u8"), ("N", "<u8"), ("na", "<i4"), ("nb", "<i4"), ("lds_", "<i4"), ("ldn", "<i4")])
 assert nambu_asm_desc.itemsize == 48 and nambu_w_desc.itemsize == 56 and pf_matrix_desc.itemsize == 32
+copy_desc = np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("lds_", "<i4"), ("ldd", "<i4"),
+                      ("flags", "<i4"), ("pad", "<i4")])
+assert copy_desc.itemsize == 40
 site_job = np.dtype([("mode", "<i4"), ("cut_b", "<i4"), ("cut_k", "<i4"), ("k_b", "<i4"), ("nf_b", "<i4"),
                      ("k_k", "<i4"), ("nf_k", "<i4"), ("sec_cap", "<i4"), ("row_off", "<i8"), ("col_off", "<i8"),
                      ("bra_off", "<i8"), ("sec_off", "<i8"), ("idx_off", "<i8"), ("idx_cap", "<i8")])
@@ -77,7 +80,7 @@ SYMBOLS = [
     "tmf_det_gather_batched", "tmf_det_reduced_batched", "tmf_det_ppt_batched", "tmf_transpose", "tmf_fill_normal",
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_column_norms_batched", "tmf_cut_vectors",
     "tmf_site_prepare", "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_det_tiles_build", "tmf_pf_gather_batched",
-    "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched",
+    "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched", "tmf_copy_blocks_batched",
 ]
 
 
@@ -120,6 +123,7 @@ def load():
     lib.tmf_pf_gather_batched.argtypes = [i32, i32, vp, i32, i32, vp]
     for fn in (lib.tmf_nambu_assemble_batched, lib.tmf_nambu_w_batched, lib.tmf_pf_matrix_batched):
         fn.argtypes = [vp, i32, vp]
+    lib.tmf_copy_blocks_batched.argtypes = [i32, vp, i32, i32, vp]
     lib.tmf_transpose.argtypes = [i32, vp, vp, i32, vp]
     lib.tmf_fill_normal.argtypes = [i32, vp, i64, u64, vp]
     lib.tmf_gather_signed_batched.argtypes = [i32, vp, i32, vp]

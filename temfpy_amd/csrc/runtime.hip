@@ -117,6 +117,43 @@ __global__ __launch_bounds__(256) void colnorm_kernel(const tmf_colnorm_desc* __
   }
 }
 
+// ---- strided block copy with optional (conjugate) transposition ------------------------------
+// dst[r, c] = src[r, c]  (flags 0)   or   dst[c, r] = [conj] src[r, c]  (flags & 1, conj with flags & 2);
+// rows x cols is the shape of the SOURCE block.  32 x 32 tiles through LDS: both sides run along
+// their leading dimension.
+template <typename T>
+__global__ __launch_bounds__(256) void copy_blocks_kernel(const tmf_copy_desc* __restrict__ desc) {
+  __shared__ T tile[32][33];
+  const tmf_copy_desc d = desc[blockIdx.x];
+  const T* __restrict__ src = reinterpret_cast<const T*>(d.src);
+  T* __restrict__ dst = reinterpret_cast<T*>(d.dst);
+  const int tr = (d.rows + 31) / 32, tc = (d.cols + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int t = blockIdx.y; t < tr * tc; t += gridDim.y) {
+    const int r0 = (t % tr) * 32, c0 = (t / tr) * 32;
+    if (!(d.flags & 1)) {
+      for (int c = ty; c < 32; c += 8) {
+        const int r = r0 + tx, cc = c0 + c;
+        if (r < d.rows && cc < d.cols) dst[(size_t)r + (size_t)cc * d.ldd] = src[(size_t)r + (size_t)cc * d.lds_];
+      }
+      continue;
+    }
+    __syncthreads();
+    for (int c = ty; c < 32; c += 8) {
+      const int r = r0 + tx, cc = c0 + c;
+      if (r < d.rows && cc < d.cols) {
+        T v = src[(size_t)r + (size_t)cc * d.lds_];
+        tile[c][tx] = (d.flags & 2) ? sc<T>::conj(v) : v;
+      }
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const int cc = c0 + tx, rr = r0 + r;   // dst[cc, rr] = src[rr, cc]: runs along cc
+      if (rr < d.rows && cc < d.cols) dst[(size_t)cc + (size_t)rr * d.ldd] = tile[tx][r];
+    }
+  }
+}
+
 // ---- column norms -----------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void norms_kernel(const tmf_norms_desc* __restrict__ desc) {
@@ -215,4 +252,19 @@ extern "C" int tmf_column_norms_batched(int dtype, const tmf_norms_desc* d_desc,
     return TMF_E_ARG;
   }
   return check_hip(hipGetLastError(), "tmf_column_norms_batched");
+}
+
+extern "C" int tmf_copy_blocks_batched(int dtype, const tmf_copy_desc* d_desc, int nprob, int max_tiles, void* stream) {
+  if (nprob <= 0) return TMF_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int gy = max_tiles < 1 ? 1 : (max_tiles > 64 ? 64 : max_tiles);
+  if (dtype == TMF_C128)
+    hipLaunchKernelGGL(copy_blocks_kernel<cd>, dim3(nprob, gy), dim3(256), 0, s, d_desc);
+  else if (dtype == TMF_F64)
+    hipLaunchKernelGGL(copy_blocks_kernel<double>, dim3(nprob, gy), dim3(256), 0, s, d_desc);
+  else {
+    set_error("tmf_copy_blocks_batched: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+  return check_hip(hipGetLastError(), "tmf_copy_blocks_batched");
 }

@@ -1152,7 +1152,9 @@ class Engine:
         self._tick("download", t0)
         self.timings["total"] = time.perf_counter() - t_all
         self._keep.clear()
-        return self._finish(MPSData(bonds, sites, oc, unit_cell_width, dict(self.timings)))
+        res = MPSData(bonds, sites, oc, unit_cell_width, dict(self.timings))
+        res._flat_t = t_out     # the pinned buffer all blocks are views of (gutzwiller: re-upload in one copy)
+        return self._finish(res)
 
 
 def _sector_list(trunc, L):

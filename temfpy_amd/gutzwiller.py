@@ -1,0 +1,831 @@
+"""Gutzwiller projections of a finite fermionic MPS to a spin-1/2 chain (temfpy/gutzwiller.py), on MI355X.
+
+``abrikosov`` (gutzwiller.py:95-281) and ``abrikosov_ph`` (:284-486) keep the reference's names, keyword
+arguments, defaults, warnings and exceptions.  They take the result of ``slater.C_to_MPS`` /
+``pfaffian.C_to_MPS`` (``MPSData`` / ``PfMPSData``) and return a :class:`SpinMPSData`: the right-canonical
+MPS of the normalised projected state with its Schmidt values and (for number-conserving input of
+``abrikosov_ph``) 2 S^z charges.
+
+Everything numerical runs on the GPU through the C ABI (``include/temfpy_hip.h``); there is no CPU path:
+
+* pair contraction + projection (TeNPy ``group_sites(2)`` + ``iproject``, gutzwiller.py:227-244, :409-444):
+  the charge blocks of both fermion tensors are regrouped by ``tmf_copy_blocks_batched`` and multiplied by ONE
+  batched MFMA launch (``tmf_gemm_batched``) over all pairs, physical states and charge sectors;
+* canonical form (TeNPy ``MPS.canonical_form_finite(cutoff=...)``, called at gutzwiller.py:266 / :471):
+  sweep 1 to the right = blocked Gram-Schmidt QR per charge block (``tmf_bcgs_batched``) and ``R = Q^H M``;
+  sweep 2 to the left = for every charge block N = A X of shape chi_l x (2 chi_r): QR of N^H, one-sided Jacobi
+  on the small triangular factor with accumulated rotations (``tmf_jacobi_batched`` in LDS up to order 100,
+  ``tmf_jacobi_block_batched`` beyond), B = (Q V)^H, and U S = N (Q V) pushed to the left.  Schmidt values
+  below ``cutoff`` are zeroed on the device (shapes stay fixed, so all descriptors of both sweeps are built
+  once, vectorised, before the first launch; no host round trip inside a sweep) and compacted at the end.
+
+Only finite MPS exist in this package (``C_to_iMPS`` is not built), so the reference's infinite-MPS branches
+(``q_left`` / ``offset`` / ``parity``) reduce to the warnings the reference emits for finite input.
+"""
+from __future__ import annotations
+
+import ctypes
+import logging
+import time
+from typing import Literal
+from warnings import warn
+
+import numpy as np
+
+from . import _native as nat
+
+logger = logging.getLogger(__name__)
+
+
+# ---------------------------------------------------------------------------------------------------
+# result container
+# ---------------------------------------------------------------------------------------------------
+class SpinMPSData:
+    """Finite spin-1/2 MPS in right-canonical form (``form = ['B'] * L``), p = 0: down, p = 1: up.
+
+    ``blocks[j]``: list of (p, q_l, q_r, l0, l1, r0, r1, ndarray (l1-l0, r1-r0)) charge blocks of B_j;
+    ``lam[b]``: normalised Schmidt values of bond b (ordered by charge, inside a charge descending);
+    ``charges[b]``: 2 S^z to the left of bond b per Schmidt index (``conserve == 'Sz'``) or the retained
+    fermionic sector label (``conserve is None``; TeNPy drops it, gutzwiller.py:244 / :444);
+    ``norm``: norm of the projected state before normalisation (the weight TeNPy discards with
+    ``renormalize=True``)."""
+
+    def __init__(self, blocks, lam, charges, conserve, norm, unit_cell_width, canonical=True, timings=None):
+        self.blocks, self._lam, self.charges = blocks, lam, charges
+        self.conserve, self.norm = conserve, norm
+        self.L = len(blocks)
+        self.unit_cell_width = unit_cell_width
+        self.form = ["B"] * self.L if canonical else [None] * self.L
+        self.timings = timings or {}
+
+    @property
+    def lam(self):
+        return self._lam
+
+    @property
+    def chi(self):
+        return [len(x) for x in self._lam]
+
+    def entanglement_entropy(self, all_bonds=False):
+        out = np.zeros(self.L + 1)
+        for i, s in enumerate(self._lam):
+            p = np.asarray(s) ** 2
+            p = p[p > 0]
+            out[i] = -(p * np.log(p)).sum()
+        return out if all_bonds else out[1:-1]
+
+    def dense_tensors(self):
+        out = []
+        for j, bl in enumerate(self.blocks):
+            dt = bl[0][7].dtype if bl else float
+            T = np.zeros((2, len(self._lam[j]), len(self._lam[j + 1])), dt)
+            for p, _, _, l0, l1, r0, r1, a in bl:
+                T[p, l0:l1, r0:r1] = a
+            out.append(T)
+        return out
+
+    def to_tenpy(self):
+        """``tenpy.networks.mps.MPS`` on ``SpinHalfSite(conserve)`` (gutzwiller.py:403, :449-451).
+        Needs physics-tenpy, which is not installed in the build environment: untested there."""
+        import tenpy.linalg.np_conserved as npc
+        from tenpy import networks
+
+        site = networks.site.SpinHalfSite("Sz" if self.conserve == "Sz" else None)
+        Bs = []
+        for j, T in enumerate(self.dense_tensors()):
+            if self.conserve == "Sz":
+                legs = [npc.LegCharge.from_qflat(site.leg.chinfo, [[q] for q in self.charges[j]], qconj=+1),
+                        site.leg,
+                        npc.LegCharge.from_qflat(site.leg.chinfo, [[q] for q in self.charges[j + 1]], qconj=-1)]
+                # site.leg is sorted by charge: [down (-1), up (+1)] = our p order
+                B = npc.Array.from_ndarray(T.transpose(1, 0, 2), legs, labels=["vL", "p", "vR"], cutoff=0.0)
+            else:
+                B = npc.Array.from_ndarray_trivial(T.transpose(1, 0, 2), labels=["vL", "p", "vR"])
+            Bs.append(B)
+        return networks.mps.MPS([site] * self.L, Bs, self._lam, form="B", unit_cell_width=self.unit_cell_width)
+
+
+# ---------------------------------------------------------------------------------------------------
+# input adapters: charge blocks of the fermion tensors as column-major matrices inside one flat buffer
+# ---------------------------------------------------------------------------------------------------
+_blk_dt = np.dtype([("site", "<i4"), ("p", "<i4"), ("cl", "<i4"), ("cr", "<i4"), ("off", "<i8"), ("ld", "<i4"),
+                    ("rows", "<i4"), ("cols", "<i4"), ("trans", "<i4")])
+
+
+class _Fermions:
+    """L, dtype, charges[b] (ascending ints per Schmidt index), lam_c, oc, conserve, flat (torch tensor or
+    ndarray), blocks (_blk_dt records): B^p_{cl -> cr} = src (trans 0) or src^T (trans 1), src = rows x cols
+    column-major with leading dimension ld at element offset `off` of flat."""
+
+
+def _sector_table(q):
+    """{charge: (start, n)} of an ascending per-index charge array."""
+    q = np.asarray(q)
+    if q.size == 0:
+        return {}
+    assert np.all(np.diff(q) >= 0), "bond charges must be sorted"
+    vals, start = np.unique(q, return_index=True)
+    stop = np.concatenate((start[1:], [q.size]))
+    return {int(v): (int(a), int(b - a)) for v, a, b in zip(vals, start, stop)}
+
+
+def _fermions_from_slater(mps):
+    """Adapter for ``MPSData`` (Slater path, conserve = 'N'): the row-major (merged (p, bra) rows x ket) blocks
+    of ``SiteData`` read as column-major matrices without copying."""
+    f = _Fermions()
+    f.L, f.oc, f.conserve = mps.L, mps.ortho_center, "N"
+    f.charges = [np.asarray(b.q_left, np.int64) for b in mps.bonds]
+    f.lam_c = np.asarray(mps.bonds[mps.ortho_center].lam)
+    recs, arrs = [], []
+    for i, s in enumerate(mps.sites):
+        left = s.mode == "left"
+        bra_q = f.charges[i] if left else f.charges[i + 1]
+        bra_tab = _sector_table(bra_q)
+        for q, r0, r1, c0, c1, arr in s.blocks:
+            c = c1 - c0
+            pr = np.asarray(s.bra_p[r0:r1])
+            al = np.asarray(s.bra_alpha[r0:r1])
+            for p in (0, 1):
+                idx = np.nonzero(pr == p)[0]
+                if idx.size == 0:
+                    continue
+                ra, rb = int(idx[0]), int(idx[-1]) + 1
+                assert rb - ra == idx.size, "rows of one physical state are contiguous inside a sector"
+                qb = int(bra_q[al[ra]])
+                st, nb = bra_tab[qb]
+                assert al[ra] == st and rb - ra == nb, "a block spans whole charge sectors"
+                # arr (r x c, row-major) == X (c x r, column-major); the p-run is the column range [ra, rb)
+                sub = arr[ra:rb]
+                if left:   # rows (p, alpha_L), columns alpha_R: B^p = X[:, ra:rb]^T, cl = qb, cr = q
+                    recs.append((i, p, qb, int(q), 0, c, c, rb - ra, 1))
+                else:      # rows (p, alpha_R), columns alpha_L: B^p = X[:, ra:rb], cl = q, cr = qb
+                    recs.append((i, p, int(q), qb, 0, c, c, rb - ra, 0))
+                arrs.append(sub)
+    f.blocks = np.array(recs, _blk_dt) if recs else np.zeros(0, _blk_dt)
+    f.dtype = np.result_type(*[a.dtype for a in arrs]) if arrs else np.dtype(float)
+    flat_t = getattr(mps, "_flat_t", None)
+    ok = flat_t is not None and flat_t.numpy().dtype == f.dtype
+    if ok:
+        base = flat_t.numpy()
+        b0, isz, n = base.__array_interface__["data"][0], base.itemsize, base.size
+        offs = np.array([a.__array_interface__["data"][0] - b0 for a in arrs], np.int64)
+        ok = bool(np.all(offs >= 0) and np.all(offs % isz == 0) and np.all(offs // isz < n)
+                  and all(a.flags.c_contiguous for a in arrs))
+    if ok:
+        f.flat = flat_t
+        f.blocks["off"] = offs // isz
+    else:      # a hand-made MPSData: pack the blocks
+        sizes = np.array([a.size for a in arrs], np.int64)
+        o = np.concatenate(([0], np.cumsum((sizes + 1) & ~1)))
+        flat = np.zeros(max(int(o[-1]), 2), f.dtype)
+        for a, oo in zip(arrs, o[:-1]):
+            flat[oo: oo + a.size] = np.ascontiguousarray(a, f.dtype).reshape(-1)
+        f.flat = flat
+        f.blocks["off"] = o[:-1]
+    return f
+
+
+def _fermions_from_dense(T, q, lam_c, oc, conserve):
+    """Adapter for dense site tensors T[i] (2, chi_l, chi_r) with per-bond charge arrays q[b] (any order):
+    indices are sorted by charge (stable) and the non-zero charge blocks packed.  Used for ``PfMPSData``
+    (conserve = 'parity') and by the tests."""
+    f = _Fermions()
+    f.L, f.oc, f.conserve = len(T), oc, conserve
+    perm = [np.argsort(np.asarray(x), kind="stable") for x in q]
+    f.charges = [np.asarray(x, np.int64)[pm] for x, pm in zip(q, perm)]
+    f.lam_c = np.asarray(lam_c)[perm[oc]]
+    f.dtype = np.result_type(*[t.dtype for t in T], float)
+    recs, arrs, o = [], [], 0
+    for i, t in enumerate(T):
+        tl, tr = _sector_table(f.charges[i]), _sector_table(f.charges[i + 1])
+        t = np.asarray(t)[:, perm[i]][:, :, perm[i + 1]]
+        for p in (0, 1):
+            for cl, (a, n) in tl.items():
+                for cr, (b, m) in tr.items():
+                    blk = t[p, a:a + n, b:b + m]
+                    if not np.any(blk):
+                        continue
+                    recs.append((i, p, cl, cr, o, n, n, m, 0))
+                    arrs.append(np.asfortranarray(blk))
+                    o += (n * m + 1) & ~1
+    flat = np.zeros(max(o, 2), f.dtype)
+    for r, a in zip(recs, arrs):
+        flat[r[4]: r[4] + a.size] = a.reshape(-1, order="F")
+    f.flat, f.blocks = flat, (np.array(recs, _blk_dt) if recs else np.zeros(0, _blk_dt))
+    return f
+
+
+def _pf_bond_parities(mps):
+    """Fermion parity to the left of every Schmidt index of every bond of a ``PfMPSData``."""
+    out = []
+    for b in mps.bonds:
+        exc = np.asarray(b.sets).sum(axis=1) if len(b.sets) else np.zeros(len(b.lam), int)
+        out.append((exc + b.parity("L")) % 2)
+    return out
+
+
+def _as_fermions(mps):
+    from .mps_data import MPSData
+
+    if isinstance(mps, _Fermions):
+        return mps
+    if isinstance(mps, MPSData):
+        return _fermions_from_slater(mps)
+    if hasattr(mps, "bonds") and hasattr(mps.bonds[0], "parity"):      # PfMPSData
+        return _fermions_from_dense(mps.dense_tensors(), _pf_bond_parities(mps), mps.bonds[mps.ortho_center].lam,
+                                    mps.ortho_center, "parity")
+    raise TypeError(f"expected the MPS returned by slater.C_to_MPS / pfaffian.C_to_MPS, got {type(mps)!r}")
+
+
+# ---------------------------------------------------------------------------------------------------
+# device pipeline
+# ---------------------------------------------------------------------------------------------------
+def _cdiv(a, b):
+    return -(-a // b)
+
+
+class _Launches:
+    """Descriptor tables of many launches of one kind, uploaded together."""
+
+    def __init__(self, dtype):
+        self.descs, self.spans, self.n, self.dtype = [], [], 0, dtype
+
+    def add(self, recs):
+        """recs: structured array of one launch; returns the launch id."""
+        self.spans.append((self.n, len(recs)))
+        self.descs.append(recs)
+        self.n += len(recs)
+        return len(self.spans) - 1
+
+    def table(self):
+        return np.concatenate(self.descs) if self.descs else np.zeros(0, self.dtype)
+
+
+class _Arena:
+    def __init__(self, elem):
+        self.n, self.elem = 0, elem
+
+    def take(self, count):
+        o = self.n
+        self.n += (int(count) + 1) & ~1        # 16-byte granularity
+        return o
+
+
+def _gemm_recs(items):
+    """items: list of (A, B, C, M, N, K, lda, ldb, ldc) -> (gemm_desc records, tiles, tile_n) of one launch."""
+    d = np.zeros(len(items), nat.gemm_desc)
+    if items:
+        a = np.array(items, np.int64)
+        for k, f in enumerate(("A", "B", "C", "M", "N", "K", "lda", "ldb", "ldc")):
+            d[f] = a[:, k]
+        d["lda"], d["ldb"], d["ldc"] = np.maximum(d["lda"], 1), np.maximum(d["ldb"], 1), np.maximum(d["ldc"], 1)
+    return d
+
+
+def _gemm_tiles(d):
+    tn = 16 if (len(d) and int(d["N"].max()) <= 16) else 64
+    tm = _cdiv(d["M"].astype(np.int64), 64)
+    tnn = _cdiv(d["N"].astype(np.int64), tn)
+    cnt = tm * tnn
+    total = int(cnt.sum())
+    prob = np.repeat(np.arange(len(d)), cnt)
+    local = np.arange(total) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    tiles = np.zeros((total, 4), np.int32)
+    tiles[:, 0], tiles[:, 1], tiles[:, 2] = prob, local % tm[prob], local // tm[prob]
+    return tiles, tn
+
+
+class _Projector:
+    """Builds and runs the device pipeline for one projection (see the module docstring)."""
+
+    def __init__(self, fer, pairs, keep_fn, cutoff, device):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise nat.NativeError("temfpy_amd.gutzwiller needs a HIP device; there is no CPU fallback")
+        self.torch, self.device = torch, torch.device(device)
+        self.lib = nat.load()
+        self.f, self.pairs, self.keep_fn, self.cutoff = fer, pairs, keep_fn, cutoff
+        self.cplx = np.dtype(fer.dtype).kind == "c"
+        self.dt = nat.TMF_C128 if self.cplx else nat.TMF_F64
+        self.np_dt = np.dtype(np.complex128 if self.cplx else np.float64)
+        self.elem = self.np_dt.itemsize
+        self.timings = {}
+
+    # ---- structure ------------------------------------------------------------------------------
+    def plan(self):
+        f = self.f
+        Ls = f.L // 2
+        tabs = [_sector_table(q) for q in f.charges]
+        blk = {}
+        for k, r in enumerate(f.blocks):
+            key = (int(r["site"]), int(r["p"]), int(r["cl"]))
+            assert key not in blk, "a physical state maps a left charge sector to one right sector"
+            blk[key] = (int(r["cr"]), k)
+        kept = []
+        for j in range(Ls + 1):
+            kept.append({c: n for c, (st, n) in tabs[2 * j].items() if self.keep_fn(j, c)})
+        # spin blocks (j, sigma, c -> c') with their two fermion factors
+        sb = []
+        for j in range(Ls):
+            for sg, (p1, p2) in enumerate(self.pairs):
+                for c in kept[j]:
+                    a = blk.get((2 * j, p1, c))
+                    if a is None:
+                        continue
+                    b = blk.get((2 * j + 1, p2, a[0]))
+                    if b is None or b[0] not in kept[j + 1]:
+                        continue
+                    sb.append((j, sg, c, b[0], a[1], b[1], a[0]))
+        # prune sectors that are not connected to both ends of the chain
+        alive = [set() for _ in range(Ls + 1)]
+        alive[0] = set(kept[0])
+        for j in range(Ls):
+            alive[j + 1] = {x[3] for x in sb if x[0] == j and x[2] in alive[j]}
+        back = [set() for _ in range(Ls + 1)]
+        back[Ls] = alive[Ls]
+        byj = [[] for _ in range(Ls)]
+        for x in sb:
+            byj[x[0]].append(x)
+        for j in range(Ls - 1, -1, -1):
+            back[j] = {x[2] for x in byj[j] if x[3] in back[j + 1]} & alive[j]
+        self.sb = [[x for x in byj[j] if x[2] in back[j] and x[3] in back[j + 1]] for j in range(Ls)]
+        self.sect = [{c: kept[j][c] for c in sorted(back[j])} for j in range(Ls + 1)]   # bond -> {c: n}
+        self.tabs, self.Ls = tabs, Ls
+        if any(len(s) == 0 for s in self.sect):
+            raise ValueError("the projected state vanishes: no charge sector connects the two ends of the chain")
+
+    # ---- run ------------------------------------------------------------------------------------
+    def run(self, canonical=True):
+        torch, lib, f = self.torch, self.lib, self.f
+        t0 = time.perf_counter()
+        self.plan()
+        Ls, el = self.Ls, self.elem
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        ar = _Arena(el)
+        # -- fermion blocks F (regrouped, column-major) and centre scaling matrices
+        need = sorted({x[4] for row in self.sb for x in row} | {x[5] for row in self.sb for x in row})
+        Foff = {}
+        for k in need:
+            r = f.blocks[k]
+            n_l, n_r = (int(r["cols"]), int(r["rows"])) if r["trans"] else (int(r["rows"]), int(r["cols"]))
+            Foff[k] = (ar.take(n_l * n_r), n_l, n_r)
+        scale_blocks = [k for k in need if int(f.blocks[k]["site"]) == f.oc and f.oc < f.L]
+        Goff = {k: ar.take(Foff[k][1] * Foff[k][2]) for k in scale_blocks}
+        # -- spin blocks T, V (left-merged), V2, W (right-merged), Y, Z, Vz, Bh, X, R
+        Toff = {}
+        for j in range(Ls):
+            for x in self.sb[j]:
+                Toff[(j, x[1], x[2])] = ar.take(self.sect[j][x[2]] * self.sect[j + 1][x[3]])
+        Vinfo, Winfo = [], []          # per site: {c': (off, m, {(sg, c): row0})}, {c: (off, w, {(sg, c'): col0})}
+        for j in range(Ls):
+            vi, wi = {}, {}
+            for cp in self.sect[j + 1]:
+                rows, m = {}, 0
+                for x in sorted((x for x in self.sb[j] if x[3] == cp), key=lambda x: (x[1], x[2])):
+                    rows[(x[1], x[2])] = m
+                    m += self.sect[j][x[2]]
+                vi[cp] = [ar.take(m * self.sect[j + 1][cp]), m, rows]
+            for c in self.sect[j]:
+                cols, w = {}, 0
+                for x in sorted((x for x in self.sb[j] if x[2] == c), key=lambda x: (x[1], x[3])):
+                    cols[(x[1], x[3])] = w
+                    w += self.sect[j + 1][x[3]]
+                wi[c] = [None, w, cols]
+            Vinfo.append(vi)
+            Winfo.append(wi)
+        mx_v = max(sum(v[1] * self.sect[j + 1][cp] + 2 for cp, v in Vinfo[j].items()) for j in range(Ls))
+        mx_w = max(sum(self.sect[j][c] * v[1] + 2 for c, v in Winfo[j].items()) for j in range(Ls))
+        mx_s = max(sum(n * n + 2 for n in s.values()) for s in self.sect)
+        V2o, Wo, Yo, Zo, Vzo, Jwo = (ar.take(mx_v), ar.take(mx_w), ar.take(mx_w), ar.take(mx_s), ar.take(mx_s),
+                                     ar.take(mx_s))
+        Ro = [ar.take(mx_s), ar.take(mx_s)]
+        Xo = [ar.take(mx_s), ar.take(mx_s)]
+        Bho, So, Cnt = [], [], []
+        n_sv = 0
+        for j in range(Ls):
+            bo = {}
+            for c, v in Winfo[j].items():
+                bo[c] = ar.take(v[1] * self.sect[j][c])
+            Bho.append(bo)
+            so = {}
+            for c, n in self.sect[j].items():
+                so[c] = n_sv
+                n_sv += n
+            So.append(so)
+        n_sec_tot = sum(len(s) for s in self.sect[:Ls])
+        mx_n = max(max(s.values()) for s in self.sect)
+        mx_rows = max(max(max((v[1] for v in Vinfo[j].values()), default=1),
+                          max((v[1] for v in Winfo[j].values()), default=1)) for j in range(Ls))
+        scr_o = ar.take(16 * mx_n * max(len(s) for s in self.sect) + 64)
+
+        d_ar = torch.zeros(ar.n, dtype=torch.complex128 if self.cplx else torch.float64, device=self.device)
+        base = d_ar.data_ptr()
+        P = lambda off: base + el * off                      # noqa: E731
+        d_sv = torch.zeros(max(n_sv, 1), dtype=torch.float64, device=self.device)
+        d_cnt = torch.zeros(max(n_sec_tot, 1), dtype=torch.int32, device=self.device)
+        d_nrm = torch.zeros(mx_n * max(len(s) for s in self.sect) + 8, dtype=torch.float64, device=self.device)
+
+        # -- upload of the fermion tensors (one copy) and regrouping
+        if isinstance(f.flat, np.ndarray):
+            d_flat = torch.from_numpy(f.flat).to(self.device)
+        else:
+            d_flat = f.flat.to(self.device, non_blocking=True)
+        fbase = d_flat.data_ptr()
+        cp = np.zeros(len(need), nat.copy_desc)
+        for i, k in enumerate(need):
+            r = f.blocks[k]
+            cp[i] = (fbase + el * int(r["off"]), P(Foff[k][0]), int(r["rows"]), int(r["cols"]), int(r["ld"]),
+                     Foff[k][1], 1 if r["trans"] else 0, 0)
+        keep_alive = [d_flat]
+        self._copy(cp, stream, keep_alive)
+        Fptr = {k: P(v[0]) for k, v in Foff.items()}
+        if scale_blocks:      # Lambda on the left index of the centre tensor: F' = diag(lam) F by the GEMM kernel
+            tab = self.tabs[f.oc]
+            host_d = np.zeros(sum(Foff[k][1] ** 2 for k in scale_blocks) + 2, self.np_dt)
+            items, o = [], 0
+            done = {}
+            for k in scale_blocks:
+                cl = int(f.blocks[k]["cl"])
+                n_l, n_r = Foff[k][1], Foff[k][2]
+                if cl not in done:
+                    st, n = tab[cl]
+                    host_d[o: o + n * n] = np.diag(f.lam_c[st: st + n]).astype(self.np_dt).reshape(-1)
+                    done[cl] = o
+                    o += n * n
+                items.append((0, Fptr[k], P(Goff[k]), n_l, n_r, n_l, n_l, n_l, n_l, done[cl]))
+            d_D = torch.from_numpy(host_d).to(self.device)
+            keep_alive.append(d_D)
+            it2 = [(d_D.data_ptr() + el * it[9],) + it[1:9] for it in items]
+            self._gemm_now(it2, 0, stream, keep_alive)
+            for k in scale_blocks:
+                Fptr[k] = P(Goff[k])
+        # -- pair products: ONE batched launch
+        items = []
+        for j in range(Ls):
+            for x in self.sb[j]:
+                n, nm, npr = self.sect[j][x[2]], Foff[x[4]][2], self.sect[j + 1][x[3]]
+                items.append((Fptr[x[4]], Fptr[x[5]], P(Toff[(j, x[1], x[2])]), n, npr, nm, n, nm, n))
+        self._gemm_now(items, 0, stream, keep_alive)
+        self.timings["setup+pairs"] = time.perf_counter() - t0
+        if not canonical:
+            torch.cuda.synchronize(self.device)
+            h = d_ar.cpu().numpy()
+            blocks = []
+            off = [{c: o for c, o in zip(s, np.concatenate(([0], np.cumsum(list(s.values()))))[:-1])} for s in self.sect]
+            for j in range(Ls):
+                bl = []
+                for x in self.sb[j]:
+                    n, npr = self.sect[j][x[2]], self.sect[j + 1][x[3]]
+                    o = Toff[(j, x[1], x[2])]
+                    a = h[o: o + n * npr].reshape(npr, n).T
+                    bl.append((x[1], x[2], x[3], int(off[j][x[2]]), int(off[j][x[2]]) + n, int(off[j + 1][x[3]]),
+                               int(off[j + 1][x[3]]) + npr, a))
+                blocks.append(bl)
+            dims = [sum(s.values()) for s in self.sect]
+            lam = [np.ones(d) / np.sqrt(d) for d in dims]       # gutzwiller.py:258 / :460
+            ch = [np.concatenate([[c] * n for c, n in s.items()]) for s in self.sect]
+            return blocks, lam, ch, None
+
+        # ================= descriptor tables of both sweeps =================
+        t1 = time.perf_counter()
+        G, CP, NR, BC, JC = (_Launches(nat.gemm_desc), _Launches(nat.copy_desc), _Launches(nat.norms_desc),
+                             _Launches(nat.bcgs_desc), _Launches(nat.jacobi_desc))
+        steps1, steps2 = [], []
+        lim_lds = 71 if self.cplx else 100        # largest Jacobi order whose X and V fit the 159 KiB of LDS
+
+        def bcgs_records(mats):
+            """mats: list of (ptr, rows, cols, ld) -> norms / bcgs records sharing the scratch and norm buffers."""
+            nd, bd = np.zeros(len(mats), nat.norms_desc), np.zeros(len(mats), nat.bcgs_desc)
+            so, no = 0, 0
+            for i, (ptr, rows, cols, ld) in enumerate(mats):
+                nd[i] = (ptr, d_nrm.data_ptr() + 8 * no, rows, cols, ld, 0)
+                bd[i] = (ptr, P(scr_o + so), d_nrm.data_ptr() + 8 * no, rows, ld, 0, cols)
+                so += 16 * cols
+                no += cols
+            order = np.argsort(-bd["rows"], kind="stable")
+            return nd[order], bd[order]
+
+        # sweep 1 (to the right)
+        for j in range(Ls):
+            st = {}
+            g, cpv = [], []
+            for x in self.sb[j]:
+                _, sg, c, cp_, *_ = x
+                voff, m, rows = Vinfo[j][cp_]
+                n, npr = self.sect[j][c], self.sect[j + 1][cp_]
+                dst = P(voff + rows[(sg, c)])
+                Tp = P(Toff[(j, sg, c)])
+                if j == 0:
+                    cpv.append((Tp, dst, n, npr, n, m, 0, 0))
+                else:
+                    roff = Ro[(j - 1) % 2] + self._sec_off(self.sect[j], c)
+                    g.append((P(roff), Tp, dst, n, npr, n, n, n, m))
+            st["fill_copy"] = CP.add(np.array(cpv, nat.copy_desc)) if cpv else None
+            st["fill_gemm"] = G.add(_gemm_recs(g)) if g else None
+            if j < Ls - 1:
+                cp2, mats, g2 = [], [], []
+                o2 = 0
+                for cp_, (voff, m, rows) in Vinfo[j].items():
+                    npr = self.sect[j + 1][cp_]
+                    cp2.append((P(voff), P(V2o + o2), m, npr, m, m, 0, 0))
+                    mats.append((P(voff), m, npr, m))
+                    roff = Ro[j % 2] + self._sec_off(self.sect[j + 1], cp_)
+                    g2.append((P(voff), P(V2o + o2), P(roff), npr, npr, m, m, m, npr))
+                    o2 += (m * npr + 1) & ~1
+                st["copy2"] = CP.add(np.array(cp2, nat.copy_desc))
+                nd, bd = bcgs_records(mats)
+                st["norms"], st["bcgs"] = NR.add(nd), BC.add(bd)
+                st["r_gemm"] = G.add(_gemm_recs(g2))
+            steps1.append(st)
+        # sweep 2 (to the left)
+        sv_ptr, cnt_ptr = d_sv.data_ptr(), d_cnt.data_ptr()
+        cnt_index = {}
+        for j in range(Ls - 1, -1, -1):
+            st = {}
+            g, wl = [], {}
+            o = 0
+            for c, v in Winfo[j].items():
+                wl[c] = o
+                o += (self.sect[j][c] * v[1] + 1) & ~1
+            for x in self.sb[j]:
+                _, sg, c, cp_, *_ = x
+                voff, m, rows = Vinfo[j][cp_]
+                n, npr = self.sect[j][c], self.sect[j + 1][cp_]
+                w, cols = Winfo[j][c][1], Winfo[j][c][2]
+                xoff = Xo[(j + 1) % 2] + self._sec_off(self.sect[j + 1], cp_)
+                g.append((P(voff + rows[(sg, c)]), P(xoff), P(Wo + wl[c] + n * cols[(sg, cp_)]), n, npr, npr, m, npr, n))
+            st["w_gemm"] = G.add(_gemm_recs(g))
+            cpy, mats, gz, jd, gb, gx = [], [], [], np.zeros(len(Winfo[j]), nat.jacobi_desc), [], []
+            for i, (c, v) in enumerate(Winfo[j].items()):
+                n, w = self.sect[j][c], v[1]
+                Wp, Yp = P(Wo + wl[c]), P(Yo + wl[c])
+                so = self._sec_off(self.sect[j], c)
+                Zp, Vzp, Jwp = P(Zo + so), P(Vzo + so), P(Jwo + so)
+                cpy.append((Wp, Yp, n, w, n, w, 3 if self.cplx else 1, 0))
+                mats.append((Yp, w, n, w))
+                gz.append((Wp, Yp, Zp, n, n, w, n, w, n))
+                cnt_index[(j, c)] = len(cnt_index)
+                jd[i] = (Zp, Vzp, 0, sv_ptr + 8 * So[j][c], cnt_ptr + 4 * cnt_index[(j, c)], self.cutoff ** 2, n, n, n, n)
+                gb.append((Yp, Vzp, P(Bho[j][c]), w, n, n, w, n, w))
+                gx.append((Wp, P(Bho[j][c]), P(Xo[j % 2] + so), n, n, w, n, w, n))
+            big = max(self.sect[j].values()) > lim_lds
+            if big:     # block kernel: V is the workspace, U receives the sorted right vectors
+                jd["U"], jd["ldu"] = jd["V"], jd["ldv"]
+                jd["V"] = [P(Jwo + self._sec_off(self.sect[j], c)) for c in Winfo[j]]
+            st["big"], st["max_p"] = big, max(self.sect[j].values())
+            st["copy_h"] = CP.add(np.array(cpy, nat.copy_desc))
+            nd, bd = bcgs_records(mats)
+            st["norms"], st["bcgs"] = NR.add(nd), BC.add(bd)
+            st["z_gemm"], st["jac"] = G.add(_gemm_recs(gz)), JC.add(jd)
+            st["b_gemm"], st["x_gemm"] = G.add(_gemm_recs(gb)), G.add(_gemm_recs(gx))
+            steps2.append(st)
+
+        # upload all tables
+        gt = G.table()
+        tiles, tile_span, tile_n = [], [], []
+        to = 0
+        for (o, n) in G.spans:
+            tl, tn = _gemm_tiles(gt[o: o + n])
+            tiles.append(tl)
+            tile_span.append((to, len(tl)))
+            tile_n.append(tn)
+            to += len(tl)
+        tiles = np.concatenate(tiles) if tiles else np.zeros((0, 4), np.int32)
+        h_bc = BC.table()
+        tabs_h = {"g": gt, "t": tiles, "cp": CP.table(), "nr": NR.table(), "bc": h_bc, "jc": JC.table()}
+        tabs_d = {k: torch.from_numpy(v.view(np.uint8).reshape(-1).copy() if v.size else np.zeros(16, np.uint8)).to(self.device)
+                  for k, v in tabs_h.items()}
+        keep_alive.append(tabs_d)
+        wb = 1024
+        for (o, n) in BC.spans:
+            wb = max(wb, int(lib.tmf_bcgs_work_bytes(ctypes.c_void_p(h_bc.ctypes.data + 40 * o), n)))
+        d_work = torch.empty(wb, dtype=torch.uint8, device=self.device)
+        self.timings["descriptors"] = time.perf_counter() - t1
+
+        def gemm(i, opA=0):
+            (o, n), (t_o, t_n) = G.spans[i], tile_span[i]
+            nat.check(lib.tmf_gemm_batched(self.dt, opA, 1.0, 0.0, tabs_d["g"].data_ptr() + 48 * o,
+                                           tabs_d["t"].data_ptr() + 16 * t_o, t_n, tile_n[i], stream), "tmf_gemm_batched")
+
+        def copy(i):
+            o, n = CP.spans[i]
+            rec = tabs_h["cp"][o: o + n]
+            mt = int((_cdiv(rec["rows"].astype(np.int64), 32) * _cdiv(rec["cols"].astype(np.int64), 32)).max())
+            nat.check(lib.tmf_copy_blocks_batched(self.dt, tabs_d["cp"].data_ptr() + 40 * o, n, mt, stream),
+                      "tmf_copy_blocks_batched")
+
+        def qr(st):
+            # Twice: a column that is nearly dependent on EARLIER panels (residual rho relative to its norm) is
+            # left with a component of eps / rho along them once its residual is normalised; the second run acts
+            # on normalised columns and restores orthogonality to eps (measured without it: 1e-10 in the Schmidt
+            # values).  Columns dropped as rounding noise are exact zeros and stay zero.
+            for _ in range(2):
+                o, n = NR.spans[st["norms"]]
+                nat.check(lib.tmf_column_norms_batched(self.dt, tabs_d["nr"].data_ptr() + 32 * o, n, stream), "norms")
+                o, n = BC.spans[st["bcgs"]]
+                nat.check(lib.tmf_bcgs_batched(self.dt, tabs_d["bc"].data_ptr() + 40 * o,
+                                               ctypes.c_void_p(h_bc.ctypes.data + 40 * o), n, 3, 0, d_work.data_ptr(),
+                                               wb, stream), "tmf_bcgs_batched")
+
+        # ================= sweep 1 =================
+        t2 = time.perf_counter()
+        for j, st in enumerate(steps1):
+            if st["fill_copy"] is not None:
+                copy(st["fill_copy"])
+            if st["fill_gemm"] is not None:
+                gemm(st["fill_gemm"])
+            if j < Ls - 1:
+                copy(st["copy2"])
+                qr(st)
+                gemm(st["r_gemm"], 1)
+        # norm of the projected state = Frobenius norm of the last (not orthonormalised) tensor
+        last = Vinfo[Ls - 1]
+        cl_, (voff, m, _) = next(iter(last.items()))
+        if len(last) != 1 or self.sect[Ls][cl_] != 1:
+            raise ValueError("the right end of the chain must carry a single state")
+        vlast = d_ar[voff: voff + m]
+        norm = float(torch.linalg.vector_norm(vlast).item())       # (host sync: end of sweep 1)
+        self.timings["sweep1"] = time.perf_counter() - t2
+        if not norm > 0.0:
+            raise ValueError("the Gutzwiller projection annihilates the state")
+        d_ar[Xo[Ls % 2] + self._sec_off(self.sect[Ls], cl_)] = 1.0 / norm
+        # ================= sweep 2 =================
+        t3 = time.perf_counter()
+        for st in steps2:
+            gemm(st["w_gemm"])
+            copy(st["copy_h"])
+            qr(st)
+            gemm(st["z_gemm"])
+            o, n = JC.spans[st["jac"]]
+            if st["big"]:
+                nat.check(lib.tmf_jacobi_block_batched(self.dt, 1, tabs_d["jc"].data_ptr() + 64 * o, n, st["max_p"], None,
+                                                       stream), "tmf_jacobi_block_batched")
+            else:
+                nat.check(lib.tmf_jacobi_batched(self.dt, tabs_d["jc"].data_ptr() + 64 * o, n, st["max_p"], None, stream),
+                          "tmf_jacobi_batched")
+            gemm(st["b_gemm"])
+            gemm(st["x_gemm"])
+        torch.cuda.synchronize(self.device)
+        self.timings["sweep2"] = time.perf_counter() - t3
+        # ================= results =================
+        t4 = time.perf_counter()
+        h_sv, h_cnt = d_sv.cpu().numpy(), d_cnt.cpu().numpy()
+        b_lo = min(o for bo in Bho for o in bo.values())
+        h_b = d_ar[b_lo:].cpu().numpy()
+        cnt = [{c: int(h_cnt[cnt_index[(j, c)]]) for c in self.sect[j]} for j in range(Ls)]
+        cnt.append({c: 1 for c in self.sect[Ls]})
+        lam, ch, offs = [], [], []
+        for j in range(Ls + 1):
+            o, oo, ll, cc = 0, {}, [], []
+            for c in self.sect[j]:
+                k = cnt[j][c]
+                oo[c] = o
+                o += k
+                ll.append(h_sv[So[j][c]: So[j][c] + k] if j < Ls else np.ones(1))
+                cc.append(np.full(k, c, np.int64))
+            s = np.concatenate(ll) if ll else np.zeros(0)
+            lam.append(s / np.linalg.norm(s))
+            ch.append(np.concatenate(cc) if cc else np.zeros(0, np.int64))
+            offs.append(oo)
+        blocks = []
+        for j in range(Ls):
+            bl = []
+            for c, v in Winfo[j].items():
+                n, w, k = self.sect[j][c], v[1], cnt[j][c]
+                if k == 0:
+                    continue
+                Bh = h_b[Bho[j][c] - b_lo: Bho[j][c] - b_lo + w * n].reshape(n, w)      # [k, (sg, c', a)] = Bh^T
+                for (sg, cp_), c0 in v[2].items():
+                    kr = cnt[j + 1][cp_]
+                    if kr == 0:
+                        continue
+                    a = Bh[:k, c0: c0 + kr]
+                    bl.append((sg, c, cp_, offs[j][c], offs[j][c] + k, offs[j + 1][cp_], offs[j + 1][cp_] + kr,
+                               a.conj() if self.cplx else a))
+            blocks.append(bl)
+        self.timings["download"] = time.perf_counter() - t4
+        del keep_alive
+        return blocks, lam, ch, norm
+
+    # ---- helpers ----------------------------------------------------------------------------------
+    @staticmethod
+    def _sec_off(sect, c):
+        """Offset (elements) of the n x n matrix of sector c inside a per-bond buffer of square blocks."""
+        o = 0
+        for cc, n in sect.items():
+            if cc == c:
+                return o
+            o += (n * n + 1) & ~1
+        raise KeyError(c)
+
+    def _copy(self, recs, stream, keep):
+        if len(recs) == 0:
+            return
+        t = self.torch.from_numpy(recs.view(np.uint8).reshape(-1).copy()).to(self.device)
+        keep.append(t)
+        mt = int((_cdiv(recs["rows"].astype(np.int64), 32) * _cdiv(recs["cols"].astype(np.int64), 32)).max())
+        nat.check(self.lib.tmf_copy_blocks_batched(self.dt, t.data_ptr(), len(recs), mt, stream), "tmf_copy_blocks_batched")
+
+    def _gemm_now(self, items, opA, stream, keep):
+        if not items:
+            return
+        d = _gemm_recs(items)
+        tiles, tn = _gemm_tiles(d)
+        td = self.torch.from_numpy(d.view(np.uint8).reshape(-1).copy()).to(self.device)
+        tt = self.torch.from_numpy(tiles.reshape(-1).copy()).to(self.device)
+        keep += [td, tt]
+        nat.check(self.lib.tmf_gemm_batched(self.dt, opA, 1.0, 0.0, td.data_ptr(), tt.data_ptr(), len(tiles), tn, stream),
+                  "tmf_gemm_batched")
+
+
+# ---------------------------------------------------------------------------------------------------
+# public entry points
+# ---------------------------------------------------------------------------------------------------
+def _check_unit_cell_width(mps, unit_cell_width, group=2):
+    """gutzwiller.py:73-88."""
+    if unit_cell_width is None:
+        unit_cell_width = mps.unit_cell_width
+        if (mps.L // group) % unit_cell_width != 0:
+            warn(f"Input MPS {unit_cell_width = } does not divide new MPS size {mps.L // group}\n"
+                 "Default to chain geometry")
+            unit_cell_width = mps.L // group
+    elif (mps.L // group) % unit_cell_width != 0:
+        raise ValueError(f"{unit_cell_width = } does not divide new MPS size {mps.L // group}")
+    return unit_cell_width
+
+
+def _finish(mps, inplace, res):
+    if inplace:
+        mps.__class__ = SpinMPSData
+        mps.__dict__.clear()
+        mps.__dict__.update(res.__dict__)
+        return None
+    return res
+
+
+def _total_charge(fer):
+    q = np.asarray(fer.charges[fer.L])
+    return int(q[0]) if q.size else 0
+
+
+def abrikosov(mps, *, inplace: bool = False, return_canonical: bool = True, cutoff: float = 1e-12,
+              q_left: None | int = None, unit_cell_width: int | None = None, device: str = "cuda:0"):
+    """Projection from Abrikosov fermions to a spin-1/2 Hilbert space (gutzwiller.py:95-281): sites 2i, 2i+1
+    hold f_up, f_down; single occupation of f_up -> up, of f_down -> down, empty and double occupation dropped.
+    No charges survive."""
+    assert mps.L % 2 == 0, "Odd-length MPS cannot represent an Abrikosov fermion Hilbert space"   # :158-160
+    fer = _as_fermions(mps)
+    conserve = fer.conserve
+    q, target = _total_charge(fer), fer.L // 2
+    err = f"Total charge must match number of spin sites. Got {q}, expected {target}"           # :178-187
+    if conserve == "N":
+        assert q == target, err
+    else:
+        assert q % 2 == target % 2, err + " (mod 2)"
+    if q_left not in (None, 0):
+        warn(f"`q_left` must be 0 for finite MPS, got {q_left = }, setting it to 0.")               # :192-196
+    ucw = _check_unit_cell_width(mps, unit_cell_width)
+    if conserve == "N":
+        keep = lambda j, c: c == j                   # noqa: E731   number_mask(leg, q_left + idx), :236-238
+    else:
+        keep = lambda j, c: c % 2 == j % 2           # noqa: E731   parity_mask(leg, q_left + idx)
+    pr = _Projector(fer, ((0, 1), (1, 0)), keep, cutoff, device)    # kept physical states in leg order 01, 10
+    blocks, lam, ch, norm = pr.run(return_canonical)
+    logger.info("Completed projection to spin-1/2 space. No conserved charges left.")              # :260
+    if not return_canonical:
+        warn("The MPS is not in canonical form after Gutzwiller projection.\nConsider setting 'return_canonical=True'")
+    res = SpinMPSData(blocks, lam, ch, None, norm, ucw, canonical=return_canonical, timings=pr.timings)
+    return _finish(mps, inplace, res)
+
+
+def abrikosov_ph(mps, *, inplace: bool = False, return_canonical: bool = True, cutoff: float = 1e-12, offset: int = 0,
+                 parity: Literal[0, 1] = 0, unit_cell_width: int | None = None, device: str = "cuda:0"):
+    """Projection from particle-hole rotated Abrikosov fermions (gutzwiller.py:284-486): sites 2i, 2i+1 hold
+    f_up, f_down^dagger; zero occupation -> down, double occupation -> up, single occupation dropped.
+    Number-conserving input keeps S^z (2 S^z = number - bond index, :333, :438-441)."""
+    assert mps.L % 2 == 0, "Odd-length MPS cannot represent an Abrikosov fermion Hilbert space"   # :354-356
+    fer = _as_fermions(mps)
+    conserve = fer.conserve
+    q = _total_charge(fer)
+    assert q % 2 == 0, f"Total fermion parity of MPS must be even, got {q}"                       # :374-376
+    if parity != 0:
+        warn(f"Must use even parity sector in finite MPS, ignoring {parity = }")                  # :380-381
+    if offset != 0 and conserve == "N":
+        warn(f"Cannot offset charge of finite MPS, ignoring {offset = }")                         # :382-383
+    ucw = _check_unit_cell_width(mps, unit_cell_width)
+    keep = lambda j, c: c % 2 == 0                   # noqa: E731   parity_mask(leg, 0), :418-419
+    pr = _Projector(fer, ((0, 0), (1, 1)), keep, cutoff, device)    # kept physical states 00, 11 = [down, up]
+    blocks, lam, ch, norm = pr.run(return_canonical)
+    spin = "Sz" if conserve == "N" else None
+    if spin == "Sz":     # leg charges -= offset + idx (finite: offset = 0), :438-441
+        ch = [c - j for j, c in enumerate(ch)]
+        blocks = [[(p, ql - j, qr - j - 1) + tuple(rest) for (p, ql, qr, *rest) in bl] for j, bl in enumerate(blocks)]
+    logger.info("Completed projection to spin-1/2 space. Conserved charge is now %s", spin)       # :462-465
+    if not return_canonical:
+        warn("The MPS is not in canonical form after Gutzwiller projection.\nConsider setting 'return_canonical=True'")
+    res = SpinMPSData(blocks, lam, ch, spin, norm, ucw, canonical=return_canonical, timings=pr.timings)
+    return _finish(mps, inplace, res)
+
+
+__all__ = ["abrikosov", "abrikosov_ph", "SpinMPSData"]

@@ -1,0 +1,145 @@
+"""GPU parity tests of the Gutzwiller projections (temfpy_amd/gutzwiller.py, HIP path through the C ABI)
+against the oracle (oracle/gutzwiller_oracle.py, itself pinned by brute force in test_oracle_gutzwiller.py).
+
+Tolerances (fp64): Schmidt values 1e-10 abs (per bond, sorted), entropies 1e-10, norm of the projected state
+1e-10 rel, state overlap 1 - |<oracle|hip>| <= 1e-10, right-canonical isometry 1e-10, kept bond dimensions
+equal wherever no Schmidt value lies within a factor 10 of the cutoff."""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import gutzwiller_oracle as gw
+from oracle import slater_oracle as orc
+from tests_inputs import random_hopping, uniform_chain
+
+pytestmark = pytest.mark.gpu
+TOL_S = 1e-12
+torch = pytest.importorskip("torch")
+
+
+def hip_mps(H, chi, spinful, oc=None):
+    from temfpy_amd import slater
+
+    C, _ = slater.correlation_matrix(H)
+    return slater.C_to_MPS(C, {"chi_max": chi}, spinful=spinful, ortho_center=oc, as_tenpy=False)
+
+
+def oracle_inputs(mps):
+    """Dense tensors, charges and centre Schmidt values of the HIP fermion MPS itself: the oracle projects
+    the SAME fermion state, so that the comparison isolates the projection + canonicalisation."""
+    T = mps.dense_tensors()
+    q = [np.asarray(b.q_left) for b in mps.bonds]
+    return T, q, mps.lam[mps.ortho_center], mps.ortho_center
+
+
+def spin_overlap(B1, B2):
+    E = np.ones((1, 1), complex)
+    for a, b in zip(B1, B2):
+        E = np.einsum("ab,pac,pbd->cd", E, a.conj(), b)
+    return abs(E[0, 0])
+
+
+def check(res, T, q, lam, oc, kind, cutoff=1e-12):
+    M, keep = gw.group_and_project(T, q, lam, oc, kind)
+    B, S, nrm = gw.canonical_form_finite(M, cutoff)
+    assert abs(res.norm / nrm - 1) < 1e-10
+    assert res.L == len(M) and res.form == ["B"] * res.L
+    for b, (a, r) in enumerate(zip(res.lam, S)):
+        a, r = np.sort(a)[::-1], np.sort(r)[::-1]
+        n = min(len(a), len(r))
+        assert np.abs(a[:n] - r[:n]).max() < TOL_S, (b, np.abs(a[:n] - r[:n]).max())
+        edge = (r < 10 * cutoff).sum() + (a < 10 * cutoff).sum()
+        assert abs(len(a) - len(r)) <= edge, (b, len(a), len(r))
+    Bh = res.dense_tensors()
+    for t in Bh:
+        X = np.einsum("pab,pcb->ac", t, t.conj())
+        assert np.abs(X - np.eye(len(X))).max() < 1e-10
+    assert abs(spin_overlap(B, Bh) - 1) < 1e-10
+    return S
+
+
+@pytest.mark.parametrize("L,seed,chi,oc", [(6, 1, 4096, None), (8, 2, 64, None), (10, 3, 48, 7), (16, 0, 64, None)])
+def test_abrikosov_ph_random_hopping(L, seed, chi, oc):
+    from temfpy_amd import gutzwiller
+
+    H = random_hopping(L, seed)
+    mps = hip_mps(H, chi, "PH", oc)
+    res = gutzwiller.abrikosov_ph(mps)
+    assert res.conserve == "Sz"
+    S = check(res, *oracle_inputs(mps), "ph")
+    # 2 S^z labels: steps of +-1 per site, zero at both ends
+    assert res.charges[0].tolist() == [0] and res.charges[-1].tolist() == [0]
+    for j, bl in enumerate(res.blocks):
+        for p, ql, qr, *_ in bl:
+            assert qr - ql == (1 if p == 1 else -1)
+    np.testing.assert_allclose(res.entanglement_entropy(True),
+                               [-(s**2 * np.log(s**2)).sum() for s in S], atol=1e-10)
+
+
+@pytest.mark.parametrize("L,real", [(8, True), (12, True), (10, False)])
+def test_abrikosov_ph_chains(L, real):
+    from temfpy_amd import gutzwiller
+
+    H = uniform_chain(L) + 0.05 * np.diag(np.cos(np.arange(L)))
+    if not real:
+        H = H + 0.1 * random_hopping(L, 5)
+    mps = hip_mps(H, 96, "PH")
+    res = gutzwiller.abrikosov_ph(mps)
+    check(res, *oracle_inputs(mps), "ph")
+
+
+@pytest.mark.parametrize("L,seed,chi", [(6, 2, 4096), (10, 4, 64), (16, 1, 64)])
+def test_abrikosov_random_hopping(L, seed, chi):
+    """Half filling is needed (total charge = number of spin sites): N = L spinful fermions on 2 L modes."""
+    from temfpy_amd import gutzwiller, slater
+
+    H = random_hopping(L, seed)
+    C, _ = slater.correlation_matrix(H, N=L // 2)
+    mps = slater.C_to_MPS(C, {"chi_max": chi}, spinful="simple", as_tenpy=False)
+    res = gutzwiller.abrikosov(mps)
+    assert res.conserve is None
+    check(res, *oracle_inputs(mps), "std")
+
+
+def test_reference_error_behaviour():
+    from temfpy_amd import gutzwiller, slater
+
+    C, _ = slater.correlation_matrix(random_hopping(5, 0), N=2)
+    mps = slater.C_to_MPS(C, {"chi_max": 16}, as_tenpy=False)
+    with pytest.raises(AssertionError, match="Odd-length"):
+        gutzwiller.abrikosov_ph(mps)
+    mps = slater.C_to_MPS(C, {"chi_max": 16}, spinful="simple", as_tenpy=False)   # N_total = 4 != 5
+    with pytest.raises(AssertionError, match="Total charge must match"):
+        gutzwiller.abrikosov(mps)
+    C3, _ = slater.correlation_matrix(random_hopping(4, 0), N=1)
+    m3 = slater.C_to_MPS(np.kron(C3, np.diag([1.0, 0.0])) , {"chi_max": 16}, as_tenpy=False)     # odd total charge
+    with pytest.raises(AssertionError, match="parity of MPS must be even"):
+        gutzwiller.abrikosov_ph(m3)
+    mps = hip_mps(random_hopping(6, 1), 32, "PH")
+    with pytest.raises(ValueError, match="does not divide"):
+        gutzwiller.abrikosov_ph(mps, unit_cell_width=4)
+    with pytest.warns(UserWarning, match="ignoring parity"):
+        gutzwiller.abrikosov_ph(mps, parity=1)
+    with pytest.warns(UserWarning, match="not in canonical form"):
+        raw = gutzwiller.abrikosov_ph(mps, return_canonical=False)
+    assert raw.form == [None] * raw.L
+    T, q, lam, oc = oracle_inputs(mps)
+    M, _ = gw.group_and_project(T, q, lam, oc, "ph")
+    for a, b in zip(raw.dense_tensors(), M):
+        np.testing.assert_allclose(a, b, atol=1e-12)
+    # inplace
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        out = gutzwiller.abrikosov_ph(mps, inplace=True)
+    assert out is None and isinstance(mps, gutzwiller.SpinMPSData) and mps.L == 6
+
+
+def test_larger_chain_block_jacobi_and_cutoff():
+    """L = 64 spinful chain at chi = 256: charge sectors beyond the LDS Jacobi, many Schmidt values below the
+    cutoff (zeroed on the device, compacted on the host)."""
+    from temfpy_amd import gutzwiller
+
+    mps = hip_mps(uniform_chain(32) + 0.1 * np.diag(np.sin(np.arange(32.0))), 256, "PH")
+    res = gutzwiller.abrikosov_ph(mps)
+    check(res, *oracle_inputs(mps), "ph")

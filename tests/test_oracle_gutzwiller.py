@@ -1,0 +1,68 @@
+"""CPU tests of the Gutzwiller oracle (oracle/gutzwiller_oracle.py): the restated group / project /
+canonical_form_finite pipeline against the independent brute-force check (projector applied to the full
+state vector, one dense SVD per cut).  TeNPy itself is not installed anywhere we can run, so its arithmetic
+is 'parity unpinned'; everything gauge invariant is pinned here."""
+import numpy as np
+import pytest
+
+from oracle import gutzwiller_oracle as gw
+from oracle import slater_oracle as orc
+from tests_inputs import random_hopping, uniform_chain
+
+
+def fermion_mps(H, chi, spinful, oc=None):
+    C, _ = orc.correlation_matrix(H)
+    cuts, sites = orc.c_to_mps(C, {"chi_max": chi}, ortho_center=oc, spinful=spinful)
+    T = orc.dense_tensors(cuts, sites)
+    q = [np.concatenate([np.full(b - a, n) for n, (a, b) in sorted(c.sectors.items())]).astype(int) for c in cuts]
+    oc = oc or len(T) // 2
+    return T, q, cuts[oc].lam, oc
+
+
+CASES = [("ph", uniform_chain(6) + 0.3 * np.diag(np.arange(6) % 3 - 1.0), "PH", None),
+         ("ph", random_hopping(6, 3).real, "PH", 3),
+         ("ph", random_hopping(6, 1), "PH", None),
+         ("std", random_hopping(6, 2), "simple", None),
+         ("std", uniform_chain(6) + 0.2 * np.diag(np.arange(6) - 2.5), "simple", 5)]
+
+
+@pytest.mark.parametrize("kind,H,spinful,oc", CASES)
+def test_restatement_against_brute_force(kind, H, spinful, oc):
+    T, q, lam, oc = fermion_mps(H, 4096, spinful, oc)
+    psi = gw.state_vector(T, lam, oc)
+    assert abs(np.linalg.norm(psi) - 1) < 1e-10
+    chi = gw.project_state(psi, kind)
+    S_ref = gw.schmidt_values_of_state(chi)
+    M, keep = gw.group_and_project(T, q, lam, oc, kind)
+    B, S, nrm = gw.canonical_form_finite(M)
+    assert abs(nrm - np.linalg.norm(chi)) < 1e-12
+    for b, (a, r) in enumerate(zip(S, S_ref)):
+        a = np.sort(a)[::-1]
+        n = min(len(a), len(r))
+        assert abs(len(a) - len(r)) <= 2 and np.abs(a[:n] - r[:n]).max() < 1e-12, b
+    ov = abs(np.vdot(gw.state_vector(B), chi / np.linalg.norm(chi)))
+    assert abs(ov - 1) < 1e-12
+    for t in B:   # right-canonical
+        X = np.einsum("pab,pcb->ac", t, t.conj())
+        assert np.abs(X - np.eye(len(X))).max() < 1e-12
+    if kind == "ph":   # charge-block version: same Schmidt values, definite 2 S^z per index
+        ql = gw.spin_charges(q, keep)
+        B2, S2, Q2, n2 = gw.canonical_form_finite_blocks(M, ql)
+        assert abs(n2 - nrm) < 1e-12
+        for b, (a, r) in enumerate(zip(S2, S_ref)):
+            a = np.sort(a)[::-1]
+            n = min(len(a), len(r))
+            assert np.abs(a[:n] - r[:n]).max() < 1e-12, b
+        assert Q2[0].tolist() == [0] and Q2[-1].tolist() == [0]
+        assert abs(abs(np.vdot(gw.state_vector(B2), chi / np.linalg.norm(chi))) - 1) < 1e-12
+
+
+def test_heisenberg_like_weight():
+    """Half-filled uniform chain, PH-projected: the projected weight is the probability of no singly occupied
+    site; it must lie strictly between 0 and 1 and the spin state must have total S^z = 0."""
+    T, q, lam, oc = fermion_mps(uniform_chain(6), 4096, "PH")
+    chi = gw.project_state(gw.state_vector(T, lam, oc), "ph")
+    w = np.linalg.norm(chi) ** 2
+    assert 0.0 < w < 1.0
+    idx = np.argwhere(np.abs(chi) > 1e-12)
+    assert np.all(idx.sum(axis=1) == 3)
