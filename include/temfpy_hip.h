@@ -259,6 +259,17 @@ typedef struct {
 } tmf_copy_desc;             /* 40 bytes */
 int tmf_copy_blocks_batched(int dtype, const tmf_copy_desc* d_desc, int nprob, int max_tiles, void* stream);
 
+/* Householder QR of many matrices, one workgroup each: A (m x n, column-major) is replaced by the thin
+ * orthonormal factor Q and R (n x n upper triangular; flags & 1: its conjugate transpose R^H instead) is
+ * written to `R` (may be 0).  For m < n, Q is m x m followed by zero columns and R has zero rows beyond m,
+ * so shapes stay fixed.  Orthogonal to machine precision for any rank (no rank decision): the `npc.qr` /
+ * first half of `npc.svd` of TeNPy's MPS.canonical_form_finite behind gutzwiller.py:266 / :471. */
+typedef struct {
+  uint64_t A, R;
+  int32_t m, n, lda, ldr, flags, pad;
+} tmf_qr_desc;               /* 40 bytes */
+int tmf_house_qr_batched(int dtype, const tmf_qr_desc* d_desc, int nprob, int max_m, int max_n, void* stream);
+
 /* Products of nested blocks of one D x D matrix C (column-major) with a shared block Omega whose
  * rows are indexed by the GLOBAL orbital index: for every cut position x with dest[x] != 0
  *

@@ -12,20 +12,21 @@ Everything numerical runs on the GPU through the C ABI (``include/temfpy_hip.h``
   the charge blocks of both fermion tensors are regrouped by ``tmf_copy_blocks_batched`` and multiplied by ONE
   batched MFMA launch (``tmf_gemm_batched``) over all pairs, physical states and charge sectors;
 * canonical form (TeNPy ``MPS.canonical_form_finite(cutoff=...)``, called at gutzwiller.py:266 / :471):
-  sweep 1 to the right = blocked Gram-Schmidt QR per charge block (``tmf_bcgs_batched``) and ``R = Q^H M``;
-  sweep 2 to the left = for every charge block N = A X of shape chi_l x (2 chi_r): QR of N^H, one-sided Jacobi
-  on the small triangular factor with accumulated rotations (``tmf_jacobi_batched`` in LDS up to order 100,
-  ``tmf_jacobi_block_batched`` beyond), B = (Q V)^H, and U S = N (Q V) pushed to the left.  Schmidt values
-  below ``cutoff`` are zeroed on the device (shapes stay fixed, so all descriptors of both sweeps are built
-  once, vectorised, before the first launch; no host round trip inside a sweep) and compacted at the end.
+  sweep 1 to the right = Householder QR per charge block (``tmf_house_qr_batched``: the projected tensors are
+  exactly rank deficient, where Gram-Schmidt needs a rank decision and Householder does not), R pushed right by
+  the MFMA GEMM; sweep 2 to the left = for every charge block N = A X of shape chi_l x (2 chi_r): Householder QR
+  of N^H, one-sided Jacobi with accumulated rotations on the small factor R^H (``tmf_jacobi_batched`` in LDS up
+  to order 100, ``tmf_jacobi_block_batched`` beyond), B = (Q V)^H, and U S = N (Q V) pushed to the left.
+  Schmidt values below ``cutoff`` are zeroed on the device (shapes stay fixed, so all descriptors of both sweeps
+  are built once before the first launch; no host round trip inside a sweep) and compacted at the end.
 
 Only finite MPS exist in this package (``C_to_iMPS`` is not built), so the reference's infinite-MPS branches
 (``q_left`` / ``offset`` / ``parity``) reduce to the warnings the reference emits for finite input.
 """
 from __future__ import annotations
 
-import ctypes
 import logging
+import os
 import time
 from typing import Literal
 from warnings import warn
@@ -394,11 +395,9 @@ class _Projector:
                 wi[c] = [None, w, cols]
             Vinfo.append(vi)
             Winfo.append(wi)
-        mx_v = max(sum(v[1] * self.sect[j + 1][cp] + 2 for cp, v in Vinfo[j].items()) for j in range(Ls))
         mx_w = max(sum(self.sect[j][c] * v[1] + 2 for c, v in Winfo[j].items()) for j in range(Ls))
         mx_s = max(sum(n * n + 2 for n in s.values()) for s in self.sect)
-        V2o, Wo, Yo, Zo, Vzo, Jwo = (ar.take(mx_v), ar.take(mx_w), ar.take(mx_w), ar.take(mx_s), ar.take(mx_s),
-                                     ar.take(mx_s))
+        Wo, Yo, Zo, Vzo, Jwo = ar.take(mx_w), ar.take(mx_w), ar.take(mx_s), ar.take(mx_s), ar.take(mx_s)
         Ro = [ar.take(mx_s), ar.take(mx_s)]
         Xo = [ar.take(mx_s), ar.take(mx_s)]
         Bho, So, Cnt = [], [], []
@@ -414,17 +413,12 @@ class _Projector:
                 n_sv += n
             So.append(so)
         n_sec_tot = sum(len(s) for s in self.sect[:Ls])
-        mx_n = max(max(s.values()) for s in self.sect)
-        mx_rows = max(max(max((v[1] for v in Vinfo[j].values()), default=1),
-                          max((v[1] for v in Winfo[j].values()), default=1)) for j in range(Ls))
-        scr_o = ar.take(16 * mx_n * max(len(s) for s in self.sect) + 64)
 
         d_ar = torch.zeros(ar.n, dtype=torch.complex128 if self.cplx else torch.float64, device=self.device)
         base = d_ar.data_ptr()
         P = lambda off: base + el * off                      # noqa: E731
         d_sv = torch.zeros(max(n_sv, 1), dtype=torch.float64, device=self.device)
         d_cnt = torch.zeros(max(n_sec_tot, 1), dtype=torch.int32, device=self.device)
-        d_nrm = torch.zeros(mx_n * max(len(s) for s in self.sect) + 8, dtype=torch.float64, device=self.device)
 
         # -- upload of the fermion tensors (one copy) and regrouping
         if isinstance(f.flat, np.ndarray):
@@ -489,22 +483,10 @@ class _Projector:
 
         # ================= descriptor tables of both sweeps =================
         t1 = time.perf_counter()
-        G, CP, NR, BC, JC = (_Launches(nat.gemm_desc), _Launches(nat.copy_desc), _Launches(nat.norms_desc),
-                             _Launches(nat.bcgs_desc), _Launches(nat.jacobi_desc))
+        G, CP, QR, JC = (_Launches(nat.gemm_desc), _Launches(nat.copy_desc), _Launches(nat.qr_desc),
+                         _Launches(nat.jacobi_desc))
         steps1, steps2 = [], []
         lim_lds = 71 if self.cplx else 100        # largest Jacobi order whose X and V fit the 159 KiB of LDS
-
-        def bcgs_records(mats):
-            """mats: list of (ptr, rows, cols, ld) -> norms / bcgs records sharing the scratch and norm buffers."""
-            nd, bd = np.zeros(len(mats), nat.norms_desc), np.zeros(len(mats), nat.bcgs_desc)
-            so, no = 0, 0
-            for i, (ptr, rows, cols, ld) in enumerate(mats):
-                nd[i] = (ptr, d_nrm.data_ptr() + 8 * no, rows, cols, ld, 0)
-                bd[i] = (ptr, P(scr_o + so), d_nrm.data_ptr() + 8 * no, rows, ld, 0, cols)
-                so += 16 * cols
-                no += cols
-            order = np.argsort(-bd["rows"], kind="stable")
-            return nd[order], bd[order]
 
         # sweep 1 (to the right)
         for j in range(Ls):
@@ -524,19 +506,12 @@ class _Projector:
             st["fill_copy"] = CP.add(np.array(cpv, nat.copy_desc)) if cpv else None
             st["fill_gemm"] = G.add(_gemm_recs(g)) if g else None
             if j < Ls - 1:
-                cp2, mats, g2 = [], [], []
-                o2 = 0
-                for cp_, (voff, m, rows) in Vinfo[j].items():
+                qd = np.zeros(len(Vinfo[j]), nat.qr_desc)
+                for i, (cp_, (voff, m, rows)) in enumerate(Vinfo[j].items()):
                     npr = self.sect[j + 1][cp_]
-                    cp2.append((P(voff), P(V2o + o2), m, npr, m, m, 0, 0))
-                    mats.append((P(voff), m, npr, m))
                     roff = Ro[j % 2] + self._sec_off(self.sect[j + 1], cp_)
-                    g2.append((P(voff), P(V2o + o2), P(roff), npr, npr, m, m, m, npr))
-                    o2 += (m * npr + 1) & ~1
-                st["copy2"] = CP.add(np.array(cp2, nat.copy_desc))
-                nd, bd = bcgs_records(mats)
-                st["norms"], st["bcgs"] = NR.add(nd), BC.add(bd)
-                st["r_gemm"] = G.add(_gemm_recs(g2))
+                    qd[i] = (P(voff), P(roff), m, npr, m, npr, 0, 0)
+                st["qr"] = QR.add(qd)
             steps1.append(st)
         # sweep 2 (to the left)
         sv_ptr, cnt_ptr = d_sv.data_ptr(), d_cnt.data_ptr()
@@ -556,15 +531,15 @@ class _Projector:
                 xoff = Xo[(j + 1) % 2] + self._sec_off(self.sect[j + 1], cp_)
                 g.append((P(voff + rows[(sg, c)]), P(xoff), P(Wo + wl[c] + n * cols[(sg, cp_)]), n, npr, npr, m, npr, n))
             st["w_gemm"] = G.add(_gemm_recs(g))
-            cpy, mats, gz, jd, gb, gx = [], [], [], np.zeros(len(Winfo[j]), nat.jacobi_desc), [], []
+            cpy, jd, gb, gx = [], np.zeros(len(Winfo[j]), nat.jacobi_desc), [], []
+            qd = np.zeros(len(Winfo[j]), nat.qr_desc)
             for i, (c, v) in enumerate(Winfo[j].items()):
                 n, w = self.sect[j][c], v[1]
                 Wp, Yp = P(Wo + wl[c]), P(Yo + wl[c])
                 so = self._sec_off(self.sect[j], c)
-                Zp, Vzp, Jwp = P(Zo + so), P(Vzo + so), P(Jwo + so)
+                Zp, Vzp = P(Zo + so), P(Vzo + so)
                 cpy.append((Wp, Yp, n, w, n, w, 3 if self.cplx else 1, 0))
-                mats.append((Yp, w, n, w))
-                gz.append((Wp, Yp, Zp, n, n, w, n, w, n))
+                qd[i] = (Yp, Zp, w, n, w, n, 1, 0)          # Y = N^H = Q R ;  Z = R^H = N Q
                 cnt_index[(j, c)] = len(cnt_index)
                 jd[i] = (Zp, Vzp, 0, sv_ptr + 8 * So[j][c], cnt_ptr + 4 * cnt_index[(j, c)], self.cutoff ** 2, n, n, n, n)
                 gb.append((Yp, Vzp, P(Bho[j][c]), w, n, n, w, n, w))
@@ -574,10 +549,10 @@ class _Projector:
                 jd["U"], jd["ldu"] = jd["V"], jd["ldv"]
                 jd["V"] = [P(Jwo + self._sec_off(self.sect[j], c)) for c in Winfo[j]]
             st["big"], st["max_p"] = big, max(self.sect[j].values())
+            st["dbg"] = [(j, c, self.sect[j][c], v[1], wl[c], self._sec_off(self.sect[j], c), Bho[j][c])
+                         for c, v in Winfo[j].items()]
             st["copy_h"] = CP.add(np.array(cpy, nat.copy_desc))
-            nd, bd = bcgs_records(mats)
-            st["norms"], st["bcgs"] = NR.add(nd), BC.add(bd)
-            st["z_gemm"], st["jac"] = G.add(_gemm_recs(gz)), JC.add(jd)
+            st["qr"], st["jac"] = QR.add(qd), JC.add(jd)
             st["b_gemm"], st["x_gemm"] = G.add(_gemm_recs(gb)), G.add(_gemm_recs(gx))
             steps2.append(st)
 
@@ -592,15 +567,10 @@ class _Projector:
             tile_n.append(tn)
             to += len(tl)
         tiles = np.concatenate(tiles) if tiles else np.zeros((0, 4), np.int32)
-        h_bc = BC.table()
-        tabs_h = {"g": gt, "t": tiles, "cp": CP.table(), "nr": NR.table(), "bc": h_bc, "jc": JC.table()}
+        tabs_h = {"g": gt, "t": tiles, "cp": CP.table(), "qr": QR.table(), "jc": JC.table()}
         tabs_d = {k: torch.from_numpy(v.view(np.uint8).reshape(-1).copy() if v.size else np.zeros(16, np.uint8)).to(self.device)
                   for k, v in tabs_h.items()}
         keep_alive.append(tabs_d)
-        wb = 1024
-        for (o, n) in BC.spans:
-            wb = max(wb, int(lib.tmf_bcgs_work_bytes(ctypes.c_void_p(h_bc.ctypes.data + 40 * o), n)))
-        d_work = torch.empty(wb, dtype=torch.uint8, device=self.device)
         self.timings["descriptors"] = time.perf_counter() - t1
 
         def gemm(i, opA=0):
@@ -616,17 +586,10 @@ class _Projector:
                       "tmf_copy_blocks_batched")
 
         def qr(st):
-            # Twice: a column that is nearly dependent on EARLIER panels (residual rho relative to its norm) is
-            # left with a component of eps / rho along them once its residual is normalised; the second run acts
-            # on normalised columns and restores orthogonality to eps (measured without it: 1e-10 in the Schmidt
-            # values).  Columns dropped as rounding noise are exact zeros and stay zero.
-            for _ in range(2):
-                o, n = NR.spans[st["norms"]]
-                nat.check(lib.tmf_column_norms_batched(self.dt, tabs_d["nr"].data_ptr() + 32 * o, n, stream), "norms")
-                o, n = BC.spans[st["bcgs"]]
-                nat.check(lib.tmf_bcgs_batched(self.dt, tabs_d["bc"].data_ptr() + 40 * o,
-                                               ctypes.c_void_p(h_bc.ctypes.data + 40 * o), n, 3, 0, d_work.data_ptr(),
-                                               wb, stream), "tmf_bcgs_batched")
+            o, n = QR.spans[st["qr"]]
+            rec = tabs_h["qr"][o: o + n]
+            nat.check(lib.tmf_house_qr_batched(self.dt, tabs_d["qr"].data_ptr() + 40 * o, n, int(rec["m"].max()),
+                                               int(rec["n"].max()), stream), "tmf_house_qr_batched")
 
         # ================= sweep 1 =================
         t2 = time.perf_counter()
@@ -636,9 +599,7 @@ class _Projector:
             if st["fill_gemm"] is not None:
                 gemm(st["fill_gemm"])
             if j < Ls - 1:
-                copy(st["copy2"])
                 qr(st)
-                gemm(st["r_gemm"], 1)
         # norm of the projected state = Frobenius norm of the last (not orthonormalised) tensor
         last = Vinfo[Ls - 1]
         cl_, (voff, m, _) = next(iter(last.items()))
@@ -652,11 +613,14 @@ class _Projector:
         d_ar[Xo[Ls % 2] + self._sec_off(self.sect[Ls], cl_)] = 1.0 / norm
         # ================= sweep 2 =================
         t3 = time.perf_counter()
+        debug = bool(int(os.environ.get("TMF_GW_DEBUG", "0")))   # per-step orthogonality report (development aid)
         for st in steps2:
             gemm(st["w_gemm"])
             copy(st["copy_h"])
+            if debug:
+                torch.cuda.synchronize(self.device)
+                h_in = d_ar[Yo: Yo + mx_w].cpu().numpy()
             qr(st)
-            gemm(st["z_gemm"])
             o, n = JC.spans[st["jac"]]
             if st["big"]:
                 nat.check(lib.tmf_jacobi_block_batched(self.dt, 1, tabs_d["jc"].data_ptr() + 64 * o, n, st["max_p"], None,
@@ -666,6 +630,22 @@ class _Projector:
                           "tmf_jacobi_batched")
             gemm(st["b_gemm"])
             gemm(st["x_gemm"])
+            if debug:
+                torch.cuda.synchronize(self.device)
+                h = d_ar.cpu().numpy()
+                for (j, c, n, w, wo_, so, bo) in st["dbg"]:
+                    Q = h[Yo + wo_: Yo + wo_ + w * n].reshape(n, w).T
+                    Vz = h[Vzo + so: Vzo + so + n * n].reshape(n, n).T
+                    Bh = h[bo: bo + w * n].reshape(n, w).T
+                    gq, gv, gb = Q.conj().T @ Q, Vz.conj().T @ Vz, Bh.conj().T @ Bh
+                    dq = np.abs(gq - np.diag(np.round(np.diag(gq).real))).max()
+                    dv = np.abs(gv - np.diag(np.round(np.diag(gv).real))).max()
+                    db = np.abs(gb - np.diag(np.round(np.diag(gb).real))).max()
+                    if dq > 1e-10 and not os.path.exists("gpurun_out/gw_dbg.npz"):
+                        np.savez("gpurun_out/gw_dbg.npz", Yin=h_in[wo_: wo_ + w * n].reshape(n, w).T, Q=Q)
+                    if max(dq, dv, db) > 1e-10:
+                        print(f"[gw debug] site {j} sector {c} n={n} w={w}: Q {dq:.1e} (zero cols {int((np.diag(gq).real < .5).sum())})"
+                              f" Vz {dv:.1e} (zero cols {int((np.diag(gv).real < .5).sum())}) Bh {db:.1e}", flush=True)
         torch.cuda.synchronize(self.device)
         self.timings["sweep2"] = time.perf_counter() - t3
         # ================= results =================

@@ -681,3 +681,43 @@ def test_det_ppt_matches_numpy(eng, cplx, n, sb, sk, mode):
             np.testing.assert_allclose(got[a], ref[a], rtol=0, atol=1e-9 * np.abs(ref[a]).max())
     else:
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_house_qr_any_rank(eng, cplx):
+    """tmf_house_qr_batched: Q orthonormal to eps and Q R = A for full-rank, graded, exactly rank-deficient,
+    wide (m < n), zero and single-column matrices; R or R^H on request (fp64 reference: A itself)."""
+    from temfpy_amd import _native as nat
+
+    setup(eng, cplx)
+    rng = np.random.default_rng(21)
+    shapes = [(40, 40), (98, 55), (260, 130), (17, 1), (5, 9), (1, 1), (64, 33), (300, 70), (33, 20)]
+    mats = []
+    for i, (m, n) in enumerate(shapes):
+        A = rnd(rng, (m, n), cplx)
+        if i == 1:    # numerically rank 27 with graded columns (the case that broke Gram-Schmidt)
+            A = (rnd(rng, (m, 27), cplx) * np.logspace(0, -7, 27)) @ rnd(rng, (27, n), cplx) * np.logspace(0, -13, n)
+        if i == 2:    # exactly rank deficient: duplicated and zero columns
+            A[:, 60:100] = A[:, :40]
+            A[:, 100:] = 0.0
+        if i == 8:
+            A[:] = 0.0
+        mats.append(A)
+    for flag in (0, 1):
+        dA = [dev(eng, a) for a in mats]
+        dR = [dev(eng, np.full((n, n), 7.0, mats[0].dtype)) for (m, n) in shapes]
+        d = np.zeros(len(shapes), nat.qr_desc)
+        for i, (m, n) in enumerate(shapes):
+            d[i] = (dA[i][1], dR[i][1], m, n, m, n, flag, 0)
+        t = torch.from_numpy(d.view(np.uint8).reshape(-1).copy()).to("cuda:0")
+        nat.check(eng.lib.tmf_house_qr_batched(eng.dtype, t.data_ptr(), len(shapes), 300, 130, eng.stream), "qr")
+        torch.cuda.synchronize()
+        for (m, n), A, da, dr in zip(shapes, mats, dA, dR):
+            Q, R = back(da[0], (m, n)), back(dr[0], (n, n))
+            if flag:
+                R = R.conj().T
+            K = min(m, n)
+            np.testing.assert_allclose(Q[:, :K].conj().T @ Q[:, :K], np.eye(K), rtol=0, atol=1e-13)
+            assert np.all(Q[:, K:] == 0) and np.all(R[K:] == 0) and np.all(np.tril(R, -1) == 0)
+            scale = max(np.abs(A).max(), 1e-300)
+            np.testing.assert_allclose(Q @ R, A, rtol=0, atol=2e-14 * scale * max(m, n) ** 0.5)
