@@ -129,6 +129,16 @@ int tmf_svd_left_batched(int dtype, const tmf_jacobi_desc* d_desc, int nprob, in
 int tmf_jacobi_block_batched(int dtype, int with_v, const tmf_jacobi_desc* d_desc, int nprob, int max_p,
                              int32_t* d_sweeps, void* stream);
 
+/* Compacting variant for rank-deficient factors, p <= 512, thresh2 > 0 required: columns of X with squared norm
+ * below thresh2 * 1e-4 / p take no part (they cannot lift a singular value over the threshold: all of them
+ * together move the spectrum by less than 1e-2 sqrt(thresh2)); the active
+ * columns of X and of the accumulated rotations are held p x nact in LDS when they fit, else in global memory
+ * (desc.X in place, desc.V = p x p workspace).  desc.U receives the right singular vectors sorted by
+ * descending singular value, zero columns for everything below the threshold; desc.s, desc.count as above.
+ * The `npc.svd` of the leftward sweep of TeNPy's MPS.canonical_form_finite (gutzwiller.py:266 / :471). */
+int tmf_jacobi_compact_batched(int dtype, const tmf_jacobi_desc* d_desc, int nprob, int max_p, int32_t* d_sweeps,
+                               void* stream);
+
 /* Blocked LU with partial pivoting restricted to the leading k x k "always" block of
  * W (mb x mk).  Returns det(W[:k,:k]) and leaves the Schur
  * complement W[k:,k:] - W[k:,:k] W[:k,:k]^-1 W[:k,k:] in S.  Replaces det/inv and the two

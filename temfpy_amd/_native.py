@@ -83,7 +83,7 @@ SYMBOLS = [
     "tmf_det_gather_batched", "tmf_det_reduced_batched", "tmf_det_ppt_batched", "tmf_transpose", "tmf_fill_normal",
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_column_norms_batched", "tmf_cut_vectors",
     "tmf_site_prepare", "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_det_tiles_build", "tmf_pf_gather_batched",
-    "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched", "tmf_copy_blocks_batched", "tmf_house_qr_batched",
+    "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched", "tmf_copy_blocks_batched", "tmf_house_qr_batched", "tmf_jacobi_compact_batched",
 ]
 
 
@@ -111,6 +111,7 @@ def load():
     lib.tmf_orth_panel_batched.argtypes = [i32, vp, i32, i32, i32, vp]
     lib.tmf_jacobi_batched.argtypes = [i32, vp, i32, i32, vp, vp]
     lib.tmf_svd_left_batched.argtypes = [i32, vp, i32, i32, vp, vp]
+    lib.tmf_jacobi_compact_batched.argtypes = [i32, vp, i32, i32, vp, vp]
     lib.tmf_nested_products_batched.argtypes = [i32, vp, i32, i32, i32, vp]
     lib.tmf_recon_error_batched.argtypes = [i32, vp, vp, i32, vp]
     lib.tmf_jacobi_block_batched.argtypes = [i32, i32, vp, i32, i32, vp, vp]

@@ -225,6 +225,207 @@ extern "C" int tmf_svd_left_batched(int dtype, const tmf_jacobi_desc* d_desc, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// Compacting variant for rank-deficient factors (canonicalisation sweeps of projected MPS, p up to 512):
+// columns whose squared norm is below thresh2 * 1e-4 / p cannot lift a singular value over the threshold
+// (together they perturb the spectrum by < 1e-2 sqrt(thresh2) in absolute terms; the rounding noise of the
+// QR that produced the factor sits at 1e-16, four decades below a 1e-12 cutoff) and take no part; only the nact active
+// columns of X and of the rotation accumulator V are held, p x nact each, in LDS when they fit (otherwise V,
+// or both, stay in global memory: d.X in place, d.V as p x nact workspace).  Output: d.U = right singular
+// vectors sorted by descending singular value (zero columns for everything below the threshold), d.s, d.count.
+// After a Gutzwiller projection about half of the columns are inactive: 4x fewer rotations per sweep and
+// p = 130 (real) fits the LDS that the plain kernel exhausts at p = 100.
+// ---------------------------------------------------------------------------------------------
+namespace tmf {
+
+template <typename T>
+__global__ __launch_bounds__(512) void jacobi_compact_kernel(const tmf_jacobi_desc* __restrict__ desc, int lds_elems,
+                                                             int32_t* __restrict__ sweeps_out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ int act[512];
+  __shared__ double nrm[512];
+  __shared__ int s_nact, flag;
+  const tmf_jacobi_desc d = desc[blockIdx.x];
+  const int p = d.p;
+  if (p <= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  T* Xg = reinterpret_cast<T*>(d.X);
+  T* Vg = reinterpret_cast<T*>(d.V);
+  T* Ug = reinterpret_cast<T*>(d.U);
+  double* sg = reinterpret_cast<double*>(d.s);
+
+  for (int c = wave; c < p; c += 8) {
+    double s = 0.0;
+    for (int r = lane; r < p; r += 64) s += sc<T>::abs2(Xg[(size_t)r + (size_t)c * d.ldx]);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) nrm[c] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const double lim = d.thresh2 * 1e-4 / (double)p;
+    int k = 0;
+    for (int c = 0; c < p; ++c)
+      if (nrm[c] > 0.0 && nrm[c] >= lim) act[k++] = c;
+    s_nact = k;
+    flag = 0;
+  }
+  __syncthreads();
+  const int nact = s_nact;
+  const bool x_lds = (size_t)p * nact <= (size_t)lds_elems;
+  const bool v_lds = 2 * (size_t)p * nact <= (size_t)lds_elems;
+  T* Xs = reinterpret_cast<T*>(smem);
+  T* Vs = Xs + (size_t)p * nact;
+  auto xcol = [&](int a) -> T* { return x_lds ? Xs + (size_t)a * p : Xg + (size_t)act[a] * d.ldx; };
+  auto vcol = [&](int a) -> T* { return v_lds ? Vs + (size_t)a * p : Vg + (size_t)a * d.ldv; };
+  for (int a = wave; a < nact; a += 8) {
+    T* x = xcol(a);
+    T* v = vcol(a);
+    const int c = act[a];
+    for (int r = lane; r < p; r += 64) {
+      if (x_lds) x[r] = Xg[(size_t)r + (size_t)c * d.ldx];
+      v[r] = (r == c) ? sc<T>::one() : sc<T>::zero();
+    }
+  }
+  __syncthreads();
+
+  const int pe = (nact + 1) & ~1, m = pe - 1, npairs = pe / 2;
+  int tpp = 64;
+  while (tpp * npairs > 512 && tpp > 1) tpp >>= 1;
+  const int slots = 512 / tpp;                    // pairs processed at once (npairs may exceed it for tpp = 1)
+  const double tol2 = 1.1e-16 * 1.1e-16 * (double)p;
+  int sweep = 0;
+  for (; sweep < 60 && nact > 1; ++sweep) {
+    for (int rho = 0; rho < m; ++rho) {
+      for (int pair = tid / tpp; pair < npairs; pair += slots) {
+        const int pl = tid % tpp;
+        int i, j;
+        if (pair == 0) {
+          i = m;
+          j = rho;
+        } else {
+          i = (rho + pair) % m;
+          j = (rho - pair + m) % m;
+        }
+        if (i > j) {
+          const int t = i;
+          i = j;
+          j = t;
+        }
+        if (j < nact) {
+          T* xi = xcol(i);
+          T* xj = xcol(j);
+          double al = 0.0, be = 0.0;
+          T ga = sc<T>::zero();
+          for (int r = pl; r < p; r += tpp) {
+            const T a = xi[r], b = xj[r];
+            al += sc<T>::abs2(a);
+            be += sc<T>::abs2(b);
+            ga = sc<T>::fmacc(ga, a, b);
+          }
+          for (int o = tpp >> 1; o > 0; o >>= 1) {
+            al += __shfl_xor(al, o, tpp);
+            be += __shfl_xor(be, o, tpp);
+            ga = sc<T>::add(ga, shfl_xor_t<T>(ga, o, tpp));
+          }
+          const double g2 = sc<T>::abs2(ga);
+          if (g2 > tol2 * al * be && g2 > 1e-280) {
+            const double ginv = rsqrt_fast(g2);
+            const double zeta = 0.5 * (be - al) * ginv;
+            const double w1 = 1.0 + zeta * zeta;
+            const double den = fabs(zeta) + w1 * rsqrt_fast(w1);
+            const double t = copysign(sc<double>::inv_fast(den), zeta);
+            const double c = rsqrt_fast(1.0 + t * t), s = c * t;
+            const T ph = sc<T>::scale(sc<T>::conj(ga), ginv);
+            const T sph = sc<T>::scale(ph, s), cph = sc<T>::scale(ph, c);
+            for (int r = pl; r < p; r += tpp) {
+              const T a = xi[r], b = xj[r];
+              xi[r] = sc<T>::sub(sc<T>::scale(a, c), sc<T>::mul(sph, b));
+              xj[r] = sc<T>::add(sc<T>::scale(a, s), sc<T>::mul(cph, b));
+            }
+            T* vi = vcol(i);
+            T* vj = vcol(j);
+            for (int r = pl; r < p; r += tpp) {
+              const T a = vi[r], b = vj[r];
+              vi[r] = sc<T>::sub(sc<T>::scale(a, c), sc<T>::mul(sph, b));
+              vj[r] = sc<T>::add(sc<T>::scale(a, s), sc<T>::mul(cph, b));
+            }
+            if (pl == 0) atomicAdd(&flag, 1);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    const int rot = flag;
+    __syncthreads();
+    if (tid == 0) flag = 0;
+    __syncthreads();
+    if (rot == 0) break;
+  }
+  if (tid == 0 && sweeps_out) sweeps_out[blockIdx.x] = sweep;
+
+  // singular values = norms of the rotated active columns; rank among them
+  for (int a = wave; a < nact; a += 8) {
+    const T* x = xcol(a);
+    double s = 0.0;
+    for (int r = lane; r < p; r += 64) s += sc<T>::abs2(x[r]);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) nrm[a] = sqrt(s);
+  }
+  __syncthreads();
+  for (int a = wave; a < p; a += 8) {          // output column `rank`; inactive columns fill the tail with zeros
+    if (a < nact) {
+      const double sa = nrm[a];
+      int rank = 0;
+      for (int b = 0; b < nact; ++b) rank += (nrm[b] > sa) || (nrm[b] == sa && b < a);
+      const bool keep = sa * sa >= d.thresh2;
+      const T* v = vcol(a);
+      for (int r = lane; r < p; r += 64) Ug[(size_t)r + (size_t)rank * d.ldu] = keep ? v[r] : sc<T>::zero();
+      if (lane == 0) sg[rank] = sa;
+    } else {
+      for (int r = lane; r < p; r += 64) Ug[(size_t)r + (size_t)a * d.ldu] = sc<T>::zero();
+      if (lane == 0) sg[a] = 0.0;
+    }
+  }
+  if (tid == 0 && d.count) {
+    int cnt = 0;
+    for (int a = 0; a < nact; ++a) cnt += nrm[a] * nrm[a] >= d.thresh2;
+    *reinterpret_cast<int32_t*>(d.count) = cnt;
+  }
+}
+
+}  // namespace tmf
+
+extern "C" int tmf_jacobi_compact_batched(int dtype, const tmf_jacobi_desc* d_desc, int nprob, int max_p,
+                                          int32_t* d_sweeps, void* stream) {
+  using namespace tmf;
+  if (nprob <= 0) return TMF_OK;
+  if (max_p <= 0 || max_p > 512) {
+    set_error("tmf_jacobi_compact_batched: p = %d not in 1..512", max_p);
+    return TMF_E_LIMIT;
+  }
+  const size_t elem = (dtype == TMF_C128) ? 16 : 8;
+  size_t lds = 2 * (size_t)max_p * max_p * elem;          // enough for everything active
+  if (lds > 152 * 1024) lds = 152 * 1024;                 // (+ ~6.2 KiB of static LDS)
+  if (lds < 1024) lds = 1024;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)jacobi_compact_kernel<cd>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    (void)hipFuncSetAttribute((const void*)jacobi_compact_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    attr_done = true;
+  }
+  const int lds_elems = (int)(lds / elem);
+  if (dtype == TMF_C128)
+    hipLaunchKernelGGL(jacobi_compact_kernel<cd>, dim3(nprob), dim3(512), lds, s, d_desc, lds_elems, d_sweeps);
+  else if (dtype == TMF_F64)
+    hipLaunchKernelGGL(jacobi_compact_kernel<double>, dim3(nprob), dim3(512), lds, s, d_desc, lds_elems, d_sweeps);
+  else {
+    set_error("tmf_jacobi_compact_batched: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+  return check_hip(hipGetLastError(), "tmf_jacobi_compact_batched");
+}
+
+// ---------------------------------------------------------------------------------------------
 // Block variant for p > 64: X (and V) stay in global memory (L2), two column blocks of width bw are
 // staged in LDS at a time and swept against each other (block one-sided Jacobi).  One workgroup per
 // problem, no inter-workgroup synchronisation.  Used only when a cut's entanglement rank exceeds

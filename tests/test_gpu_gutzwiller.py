@@ -40,7 +40,7 @@ def spin_overlap(B1, B2):
     return abs(E[0, 0])
 
 
-def check(res, T, q, lam, oc, kind, cutoff=1e-12):
+def check(res, T, q, lam, oc, kind, cutoff=1e-12, isometry=1e-10):
     M, keep = gw.group_and_project(T, q, lam, oc, kind)
     B, S, nrm = gw.canonical_form_finite(M, cutoff)
     assert abs(res.norm / nrm - 1) < 1e-10
@@ -52,9 +52,13 @@ def check(res, T, q, lam, oc, kind, cutoff=1e-12):
         edge = (r < 10 * cutoff).sum() + (a < 10 * cutoff).sum()
         assert abs(len(a) - len(r)) <= edge, (b, len(a), len(r))
     Bh = res.dense_tensors()
-    for t in Bh:
-        X = np.einsum("pab,pcb->ac", t, t.conj())
-        assert np.abs(X - np.eye(len(X))).max() < 1e-10
+    for t, sl in zip(Bh, res.lam):
+        X = np.einsum("pab,pcb->ac", t, t.conj()) - np.eye(t.shape[1])
+        if isometry is None:      # method="parallel": exact up to (cutoff / s)^2 per Schmidt index
+            bound = 1e-10 + 4.0 * len(sl) * (cutoff / sl) ** 2
+            assert np.all(np.abs(X) <= np.sqrt(np.outer(bound, bound))), np.abs(X).max()
+        else:
+            assert np.abs(X).max() < isometry
     assert abs(spin_overlap(B, Bh) - 1) < 1e-10
     return S
 
@@ -163,3 +167,31 @@ def test_exactly_symmetric_chain_rank_deficient_blocks():
         a, r = np.sort(lam[q == c])[::-1], np.sort(lam[q == -c])[::-1]
         n = min(len(a), len(r))
         assert np.abs(a[:n] - r[:n]).max() < 1e-3       # limited by the asymmetry of the chi-truncated INPUT (measured 3e-5)
+
+
+@pytest.mark.parametrize("L,perturb", [(16, 0.3), (32, 0.1), (48, 0.0)])
+def test_parallel_method(L, perturb):
+    """method="parallel" (QR-only sweeps on two streams, all SVDs in one launch): same state, norm and Schmidt
+    values as the sequential algorithm / the oracle; isometry exact up to (cutoff / s)^2 per Schmidt index, and to
+    1e-10 outright when the cutoff sits below every Schmidt value that is kept."""
+    from temfpy_amd import gutzwiller
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mps = hip_mps(uniform_chain(L) + perturb * np.diag(np.sin(np.arange(float(L)))), 128, "PH")
+    res = gutzwiller.abrikosov_ph(mps, method="parallel")
+    check(res, *oracle_inputs(mps), "ph", isometry=None)
+    seq = gutzwiller.abrikosov_ph(mps)
+    assert abs(res.norm / seq.norm - 1) < 1e-12
+    for a, b in zip(res.lam, seq.lam):
+        a, b = np.sort(a)[::-1], np.sort(b)[::-1]
+        n = min(len(a), len(b))
+        assert np.abs(a[:n] - b[:n]).max() < 1e-12
+        assert abs(len(a) - len(b)) <= (a < 1e-11).sum() + (b < 1e-11).sum()
+    tiny = gutzwiller.abrikosov_ph(mps, method="parallel", cutoff=1e-22)     # keeps rounding-level directions too
+    for t, sl in zip(tiny.dense_tensors(), tiny.lam):
+        X = np.abs(np.einsum("pab,pcb->ac", t, t.conj()) - np.eye(t.shape[1]))
+        big = sl > 1e-15                                                     # everything a 1e-12 cutoff would keep
+        assert X[np.ix_(big, big)].max() < 1e-10
+    with pytest.raises(ValueError, match="method"):
+        gutzwiller.abrikosov_ph(mps, method="fast")

@@ -721,3 +721,52 @@ def test_house_qr_any_rank(eng, cplx):
             assert np.all(Q[:, K:] == 0) and np.all(R[K:] == 0) and np.all(np.tril(R, -1) == 0)
             scale = max(np.abs(A).max(), 1e-300)
             np.testing.assert_allclose(Q @ R, A, rtol=0, atol=2e-14 * scale * max(m, n) ** 0.5)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_jacobi_compact_rank_deficient(eng, cplx):
+    """tmf_jacobi_compact_batched against numpy.linalg.svd: singular values (relative 1e-10 above the
+    threshold), orthogonal right vectors reproducing X V = U S, zero columns below the threshold; orders beyond
+    the plain LDS kernel (real 130, complex 96 with half of the columns at rounding level), a full-rank matrix
+    that does not fit the LDS (global-memory path) and tiny problems."""
+    from temfpy_amd import _native as nat
+
+    setup(eng, cplx)
+    rng = np.random.default_rng(31)
+    thr2 = 1e-24
+    Xs = []
+    for p, r in [(130, 64), (96, 40), (150, 150), (1, 1), (2, 1), (33, 33), (60, 0)]:
+        if r == 0:
+            X = np.zeros((p, p), complex if cplx else float)
+        else:
+            sv = np.logspace(0, -11, r) if r > 2 else np.ones(r)
+            X = (np.linalg.qr(rnd(rng, (p, r), cplx))[0] * sv) @ np.linalg.qr(rnd(rng, (p, r), cplx))[0].conj().T
+            X = X + 1e-19 * rnd(rng, (p, p), cplx)        # rounding-level columns everywhere
+            if r < p:      # lower-triangular like R^H: leading columns carry the weight
+                X = np.linalg.qr(X.conj().T)[1].conj().T
+        Xs.append(X)
+    ps = [len(x) for x in Xs]
+    dX = [dev(eng, x) for x in Xs]
+    dW = [dev(eng, np.zeros_like(x)) for x in Xs]
+    dU = [dev(eng, np.full_like(x, 3.0)) for x in Xs]
+    ds = [torch.zeros(p, dtype=torch.float64, device="cuda:0") for p in ps]
+    dc = torch.zeros(len(ps), dtype=torch.int32, device="cuda:0")
+    d = np.zeros(len(ps), nat.jacobi_desc)
+    for i, p in enumerate(ps):
+        d[i] = (dX[i][1], dW[i][1], dU[i][1], ds[i].data_ptr(), dc.data_ptr() + 4 * i, thr2, p, p, p, p)
+    t = torch.from_numpy(d.view(np.uint8).reshape(-1).copy()).to("cuda:0")
+    nat.check(eng.lib.tmf_jacobi_compact_batched(eng.dtype, t.data_ptr(), len(ps), max(ps), None, eng.stream), "jc")
+    torch.cuda.synchronize()
+    cnt = dc.cpu().numpy()
+    for p, X, du, s_, c in zip(ps, Xs, dU, ds, cnt):
+        V, s = back(du[0], (p, p)), s_.cpu().numpy()
+        sref = np.linalg.svd(X, compute_uv=False)
+        k = int(np.sum(sref**2 >= thr2))
+        assert c == k
+        np.testing.assert_allclose(s[:k], sref[:k], rtol=1e-10, atol=1e-16)
+        np.testing.assert_allclose(V[:, :k].conj().T @ V[:, :k], np.eye(k), rtol=0, atol=1e-13)
+        assert np.all(V[:, k:] == 0)
+        XV = X @ V[:, :k]
+        np.testing.assert_allclose(np.linalg.norm(XV, axis=0), s[:k], rtol=1e-10, atol=1e-16)
+        G = XV.conj().T @ XV                                    # columns of X V are orthogonal (= U S)
+        np.testing.assert_allclose(G - np.diag(np.diag(G)), 0, atol=1e-14 * max(1.0, sref[0] ** 2))

@@ -19,13 +19,14 @@ ap.add_argument("--L", type=int, default=512)
 ap.add_argument("--chi", type=int, default=512)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--checks", action="store_true")
+ap.add_argument("--method", default="sequential")
 a = ap.parse_args()
 C, N = slater.correlation_matrix(uniform_chain(a.L))
 for r in range(a.reps):
     t0 = time.perf_counter()
     mps = slater.C_to_MPS(C, {"chi_max": a.chi}, as_tenpy=False, spinful="PH")
     t1 = time.perf_counter()
-    res = gutzwiller.abrikosov_ph(mps)
+    res = gutzwiller.abrikosov_ph(mps, method=a.method)
     t2 = time.perf_counter()
     print(f"rep {r}: Slater->MPS {1e3*(t1-t0):.1f} ms ({mps.L} sites), abrikosov_ph {1e3*(t2-t1):.1f} ms "
           f"({res.L} spins, {res.L/(t2-t1):.1f} sites/s), norm {res.norm:.6e}, max chi {max(res.chi)}, "
