@@ -34,6 +34,7 @@ Only finite MPS exist in this package (``C_to_iMPS`` is not built), so the refer
 from __future__ import annotations
 
 import logging
+import os
 import time
 from typing import Literal
 from warnings import warn
@@ -223,13 +224,21 @@ def _fermions_from_dense(T, q, lam_c, oc, conserve):
     return f
 
 
-def _pf_bond_parities(mps):
-    """Fermion parity to the left of every Schmidt index of every bond of a ``PfMPSData``."""
-    out = []
-    for b in mps.bonds:
-        exc = np.asarray(b.sets).sum(axis=1) if len(b.sets) else np.zeros(len(b.lam), int)
-        out.append((exc + b.parity("L")) % 2)
-    return out
+def infer_parities(T, tol=1e-9):
+    """Fermion parity to the left of every index of every bond of a parity-conserving MPS given as dense tensors
+    T[i] (2, chi_l, chi_r): parity(right index) = parity(left index) + p (mod 2), read off the dominant entry of
+    each column and verified on all entries above ``tol`` of the site's largest one."""
+    q = [np.zeros(T[0].shape[1], np.int64)]
+    for i, t in enumerate(T):
+        a = np.abs(np.asarray(t))
+        src = (q[-1][None, :, None] + np.arange(2)[:, None, None]) % 2 + 0 * a.astype(np.int64)     # parity a column would get
+        flat = a.reshape(-1, a.shape[2])
+        nxt = src.reshape(-1, a.shape[2])[flat.argmax(axis=0), np.arange(a.shape[2])]
+        bad = (a > tol * max(a.max(), 1e-300)) & (src != nxt[None, None, :])
+        if bad.any():
+            raise ValueError(f"site {i} does not conserve the fermion parity")
+        q.append(nxt.astype(np.int64))
+    return q
 
 
 def _as_fermions(mps):
@@ -240,8 +249,8 @@ def _as_fermions(mps):
     if isinstance(mps, MPSData):
         return _fermions_from_slater(mps)
     if hasattr(mps, "bonds") and hasattr(mps.bonds[0], "parity"):      # PfMPSData
-        return _fermions_from_dense(mps.dense_tensors(), _pf_bond_parities(mps), mps.bonds[mps.ortho_center].lam,
-                                    mps.ortho_center, "parity")
+        T = mps.dense_tensors()
+        return _fermions_from_dense(T, infer_parities(T), mps.bonds[mps.ortho_center].lam, mps.ortho_center, "parity")
     raise TypeError(f"expected the MPS returned by slater.C_to_MPS / pfaffian.C_to_MPS, got {type(mps)!r}")
 
 
@@ -636,16 +645,25 @@ class _Projector:
             # (the last tensor was normalised by its own QR: X of the right end stays 1)
             d_sv[So[Ls][end]] = 1.0
             d_cnt[cnt_index[(Ls, end)]] = 1
+            d_sw = None
+            if os.environ.get("TMF_JACOBI_SWEEPS"):     # development aid: sweep counts of every Jacobi problem
+                d_sw = torch.zeros(n_sec_tot, dtype=torch.int32, device=self.device)
             for gw_, cw_, qw_, (i0, nj, pmax), gb_, gx_ in steps2:
                 gemm(gw_, s1)
                 copy(cw_, s1)
                 qr(qw_, s1)
-                nat.check(lib.tmf_jacobi_compact_batched(self.dt, tabs_d["jc"].data_ptr() + 64 * i0, nj, pmax, None, s1),
+                nat.check(lib.tmf_jacobi_compact_batched(self.dt, tabs_d["jc"].data_ptr() + 64 * i0, nj, pmax,
+                                                         None if d_sw is None else d_sw.data_ptr() + 4 * i0, s1),
                           "tmf_jacobi_compact_batched")
                 gemm(gb_, s1)
                 gemm(gx_, s1)
             torch.cuda.synchronize(self.device)
             self.timings["sweep2"] = time.perf_counter() - t3
+            if d_sw is not None:
+                h = d_sw.cpu().numpy()
+                big = jd["p"] >= 0.8 * jd["p"].max()
+                print(f"[gutzwiller] Jacobi sweeps: all problems mean {h.mean():.1f} max {h.max()}; p >= {int(0.8 * jd['p'].max())}: "
+                      f"mean {h[big].mean():.1f} hist {np.bincount(h[big]).tolist()}", flush=True)
         else:
             # ================= two QR-only sweeps, independent of each other, on two HIP streams =================
             side = torch.cuda.Stream(device=self.device)

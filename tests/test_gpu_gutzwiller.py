@@ -195,3 +195,41 @@ def test_parallel_method(L, perturb):
         assert X[np.ix_(big, big)].max() < 1e-10
     with pytest.raises(ValueError, match="method"):
         gutzwiller.abrikosov_ph(mps, method="fast")
+
+
+@pytest.mark.parametrize("seed,kind", [(0, "ph"), (3, "ph"), (1, "std"), (2, "std")])
+def test_pfaffian_input_parity_conserving(seed, kind):
+    """Input from pfaffian.C_to_MPS (conserve = 'parity', complex tensors): charges are read off the tensors
+    (infer_parities), no charge survives the projection (gutzwiller.py:244 / :443-444)."""
+    from temfpy_amd import gutzwiller, pfaffian
+
+    L = 8
+    rng = np.random.default_rng(seed)
+    x, y = np.meshgrid(np.arange(2 * L), np.arange(2 * L), indexing="ij")
+    M = rng.normal(size=(2 * L, 2 * L)) * np.exp(-abs(x - y) / 3.0)
+    H = 1j * (M - M.T)                       # src/examples/pfaffian.py:13-17
+    C = pfaffian.correlation_matrix(H, basis="M->M")
+    C = C[0] if isinstance(C, tuple) else C
+    mps = pfaffian.C_to_MPS(C, {"chi_max": 64}, basis="M")
+    T = mps.dense_tensors()
+    q = gutzwiller.infer_parities(T)
+    total, fn = int(q[-1][0]), (gutzwiller.abrikosov_ph if kind == "ph" else gutzwiller.abrikosov)
+    ok = total % 2 == 0 if kind == "ph" else total % 2 == (L // 2) % 2
+    if not ok:
+        with pytest.raises(AssertionError):
+            fn(mps)
+        return
+    res = fn(mps)
+    assert res.conserve is None
+    M_, keep = gw.group_and_project(T, q, mps.lam[mps.ortho_center], mps.ortho_center, kind, conserve="parity")
+    B, S, nrm = gw.canonical_form_finite(M_)
+    assert abs(res.norm / nrm - 1) < 1e-10
+    for b, (a, r) in enumerate(zip(res.lam, S)):
+        a, r = np.sort(a)[::-1], np.sort(r)[::-1]
+        n = min(len(a), len(r))
+        assert np.abs(a[:n] - r[:n]).max() < TOL_S and abs(len(a) - len(r)) <= (r < 1e-11).sum() + (a < 1e-11).sum()
+    Bh = res.dense_tensors()
+    for t in Bh:
+        X = np.einsum("pab,pcb->ac", t, t.conj())
+        assert np.abs(X - np.eye(len(X))).max() < 1e-10
+    assert abs(spin_overlap(B, Bh) - 1) < 1e-10

@@ -66,3 +66,17 @@ def test_heisenberg_like_weight():
     assert 0.0 < w < 1.0
     idx = np.argwhere(np.abs(chi) > 1e-12)
     assert np.all(idx.sum(axis=1) == 3)
+
+
+def test_infer_parities_host_logic():
+    """temfpy_amd.gutzwiller.infer_parities (host logic, no GPU): recovers the charge parities of a
+    number-conserving MPS from its tensors and rejects tensors that mix parities."""
+    from temfpy_amd.gutzwiller import infer_parities
+
+    T, q, lam, oc = fermion_mps(random_hopping(6, 1), 64, "PH")
+    got = infer_parities(T)
+    assert all(np.array_equal(a, np.asarray(b) % 2) for a, b in zip(got, q))
+    bad = [t.copy() for t in T]
+    bad[3][1] += bad[3][0]
+    with pytest.raises(ValueError, match="parity"):
+        infer_parities(bad)
