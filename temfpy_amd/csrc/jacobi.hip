@@ -270,6 +270,19 @@ __global__ __launch_bounds__(512) void jacobi_compact_kernel(const tmf_jacobi_de
   }
   __syncthreads();
   const int nact = s_nact;
+  // de Rijk ordering: active columns by descending norm (fewer sweeps on graded factors)
+  int my_col = -1, my_rank = 0;
+  if (tid < nact) {
+    my_col = act[tid];
+    const double v = nrm[my_col];
+    for (int b = 0; b < nact; ++b) {
+      const int cb = act[b];
+      my_rank += (nrm[cb] > v) || (nrm[cb] == v && cb < my_col);
+    }
+  }
+  __syncthreads();
+  if (my_col >= 0) act[my_rank] = my_col;
+  __syncthreads();
   const bool x_lds = (size_t)p * nact <= (size_t)lds_elems;
   const bool v_lds = 2 * (size_t)p * nact <= (size_t)lds_elems;
   T* Xs = reinterpret_cast<T*>(smem);
