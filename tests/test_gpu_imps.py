@@ -1,0 +1,98 @@
+"""GPU parity tests of the finite -> infinite MPS conversion (temfpy_amd/iMPS.py, HIP path through the C ABI)
+against the oracle (oracle/imps_oracle.py) fed with the SAME finite MPS, and the acceptance check of the
+reference's example (src/examples/iMPS.py:27-38).  Tolerances (fp64): overlaps 1e-10, rotations 1e-9 after
+weighting with the Schmidt values (directions of weight < 1e-6 are fixed by rounding only), error metrics
+1e-9, unit-cell tensors 1e-9 weighted, reconstruction overlap 1 - 1e-8."""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import imps_oracle as io
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def ssh(L, t1=-1.5, t2=-1.0, imag=0.0):
+    M = t1 * np.ones(L - 1, complex if imag else float)
+    M[1::2] = t2
+    if imag:
+        M = M * np.exp(1j * imag)        # uniform Peierls phase: complex tensors, still translation invariant
+    M = np.diag(M, 1)
+    return M + M.conj().T
+
+
+def finite(L, chi, oc=None, imag=0.0):
+    from temfpy_amd import slater
+
+    C, _ = slater.correlation_matrix(ssh(L, imag=imag))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return slater.C_to_MPS(C, {"chi_max": chi}, ortho_center=oc, as_tenpy=False)
+
+
+def dense(m):
+    return m.dense_tensors(), [np.asarray(x) for x in m.lam], list(m.form)
+
+
+@pytest.mark.parametrize("L,cut,oc_long,imag", [(32, 16, None, 0.0), (32, 16, 16, 0.0), (28, 12, None, 0.0),
+                                                (32, 16, None, 0.3)])
+def test_mps_to_imps_against_oracle(L, cut, oc_long, imag):
+    from temfpy_amd import iMPS
+
+    chi = 48
+    ms = finite(L, chi, cut if cut != L // 2 else None, imag)
+    ml = finite(L + 2, chi, oc_long, imag)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res, err = iMPS.MPS_to_iMPS(ms, ml, 2, cut, offset=0)
+    Ts, ls, fs = dense(ms)
+    Tl, ll, fl = dense(ml)
+    B, S, eo = io.mps_to_imps(Ts, ls, fs, Tl, ll, fl, 2, cut)
+    np.testing.assert_allclose(list(err), eo, rtol=0, atol=1e-9)
+    assert isinstance(err, iMPS.iMPSError) and abs(err.total_error - np.linalg.norm(eo)) < 1e-9
+    assert res.L == 2 and res.form == ["B", "B"] and res.bc == "infinite"
+    for a, b in zip(res.lam, S):
+        np.testing.assert_allclose(a, b, atol=0)
+    for t, r, sl, sr in zip(res.dense_tensors(), B, S[:-1], S[1:]):
+        w = sl[None, :, None] * np.abs(t - r) * 1.0
+        assert w.max() < 1e-9, w.max()
+    # acceptance check of the reference's example: short chain + n unit cells = the longer chain
+    n_cell = 3
+    Tr, lr, fr = io.insert_cells(Ts, ls, fs, res.dense_tensors(), res.lam, cut, n_cell)
+    Tv, lv, fv = dense(finite(L + 2 * n_cell, chi, cut if cut != L // 2 else None, imag))
+    ov = io.overlap(Tv, lv, fv, Tr, lr, fr)
+    nr, nv = io.overlap(Tr, lr, fr, Tr, lr, fr).real, io.overlap(Tv, lv, fv, Tv, lv, fv).real
+    assert abs(abs(ov) / np.sqrt(nr * nv) - 1) < 1e-8
+
+
+def test_overlap_and_rotation_entry_points():
+    from temfpy_amd import iMPS
+
+    ms, ml = finite(24, 32, 12), finite(26, 32, 12)
+    Ts, ls, fs = dense(ms)
+    Tl, ll, fl = dense(ml)
+    C0 = iMPS.overlap_schmidt(ms, ml, "left", segment_bra=(0, 12), segment_ket=(0, 12))
+    ref = io.overlap_schmidt([io.get_B(Ts, ls, fs, i, "A") for i in range(12)],
+                             [io.get_B(Tl, ll, fl, i, "A") for i in range(12)], "left")
+    np.testing.assert_allclose(C0.dense(), ref, atol=1e-10)
+    D0 = iMPS.overlap_schmidt(ms, ml, "right", segment_bra=(12, 24), segment_ket=(14, 26))
+    ref = io.overlap_schmidt([io.get_B(Ts, ls, fs, i, "B") for i in range(12, 24)],
+                             [io.get_B(Tl, ll, fl, i, "B") for i in range(14, 26)], "right")
+    np.testing.assert_allclose(D0.dense(), ref, atol=1e-10)
+    for mode, ov, Sb, Sk in (("left", C0, ls[12], ll[12]), ("right", D0, ls[12], ll[14])):
+        for form in ("A", "B"):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                rot, ue, se = iMPS.basis_rotation(ov, Sb, Sk, mode, form=form)
+            r0, u0, s0 = io.basis_rotation(ov.dense(), Sb, Sk, mode, form)
+            assert abs(ue - u0) < 1e-10 and abs(se - s0) < 1e-9
+            w = (Sb[:, None] if mode == "left" else Sk[:, None]) * np.abs(rot.dense() - r0)
+            assert w.max() < 1e-9
+    with pytest.raises(ValueError, match="mode"):
+        iMPS.overlap_schmidt(ms, ml, "up")
+    with pytest.raises(ValueError, match="differ by one unit cell"):
+        iMPS.MPS_to_iMPS(ms, ml, 4, 12)
+    with pytest.warns(UserWarning, match="deviates from unitarity"):
+        iMPS.basis_rotation(C0, ls[12], ll[12], "left", unitary_tol=1e-12)
