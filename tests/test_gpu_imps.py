@@ -96,3 +96,34 @@ def test_overlap_and_rotation_entry_points():
         iMPS.MPS_to_iMPS(ms, ml, 4, 12)
     with pytest.warns(UserWarning, match="deviates from unitarity"):
         iMPS.basis_rotation(C0, ls[12], ll[12], "left", unitary_tol=1e-12)
+
+
+@pytest.mark.parametrize("spinful", [None, "simple", "PH"])
+def test_H_to_iMPS(spinful):
+    """slater.H_to_iMPS (slater.py:1630-1734): unit cell of the SSH chain; offsets as the reference defines
+    them; inserting cells into the short chain reproduces the longer chain."""
+    from temfpy_amd import slater
+
+    L, cut, chi, n_cell = 24, 12, 40 if spinful is None else 600, 2
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res, err = slater.H_to_iMPS(ssh(L), ssh(L + 2), {"chi_max": chi}, 2, cut, spinful=spinful)
+        mult = 1 if spinful is None else 2
+        assert res.L == 2 * mult and res.unit_cell_width == 2 and err.total_error < 1e-3
+        expect = {None: 6, "simple": 12, "PH": 12}[spinful]          # particles left of the cut at half filling
+        q0 = res.charges[0] + expect
+        Cs, _ = slater.correlation_matrix(ssh(L))
+        ms = slater.C_to_MPS(Cs, {"chi_max": chi}, ortho_center=mult * cut, spinful=spinful, as_tenpy=False)
+        assert np.array_equal(q0, np.asarray(ms.bonds[mult * cut].q_left))
+        Cv, _ = slater.correlation_matrix(ssh(L + 2 * n_cell))
+        mv = slater.C_to_MPS(Cv, {"chi_max": chi}, ortho_center=mult * cut, spinful=spinful, as_tenpy=False)
+    Ts, ls, fs = dense(ms)
+    Tr, lr, fr = io.insert_cells(Ts, ls, fs, res.dense_tensors(), res.lam, mult * cut, n_cell)
+    Tv, lv, fv = dense(mv)
+    ov = io.overlap(Tv, lv, fv, Tr, lr, fr)
+    nr, nv = io.overlap(Tr, lr, fr, Tr, lr, fr).real, io.overlap(Tv, lv, fv, Tv, lv, fv).real
+    assert abs(abs(ov) / np.sqrt(nr * nv) - 1) < 1e-6
+    with pytest.raises(ValueError, match="does not divide"):
+        slater.H_to_iMPS(ssh(L), ssh(L + 2), {"chi_max": chi}, 2, cut, unit_cell_width=3)
+    with pytest.raises(ValueError, match="spinful"):
+        slater.H_to_iMPS(ssh(L), ssh(L + 2), {"chi_max": chi}, 2, cut, spinful="both")
