@@ -142,7 +142,7 @@ def _fermions_from_slater(mps):
     """Adapter for ``MPSData`` (Slater path, conserve = 'N'): the row-major (merged (p, bra) rows x ket) blocks
     of ``SiteData`` read as column-major matrices without copying."""
     f = _Fermions()
-    f.L, f.oc, f.conserve = mps.L, mps.ortho_center, "N"
+    f.L, f.oc, f.conserve, f.perm = mps.L, mps.ortho_center, "N", None
     f.charges = [np.asarray(b.q_left, np.int64) for b in mps.bonds]
     f.lam_c = np.asarray(mps.bonds[mps.ortho_center].lam)
     recs, arrs = [], []
@@ -221,6 +221,7 @@ def _fermions_from_dense(T, q, lam_c, oc, conserve):
     for r, a in zip(recs, arrs):
         flat[r[4]: r[4] + a.size] = a.reshape(-1, order="F")
     f.flat, f.blocks = flat, (np.array(recs, _blk_dt) if recs else np.zeros(0, _blk_dt))
+    f.perm = perm            # index order of every bond after the sort by charge
     return f
 
 

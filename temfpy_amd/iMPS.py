@@ -2,7 +2,8 @@
 
 ``MPS_to_iMPS`` (iMPS.py:232-441), ``overlap_schmidt`` (:20-62), ``basis_rotation`` (:65-192) and ``iMPSError``
 (:195-229) with the reference's names, arguments, defaults, warnings and exceptions, on the finite MPS objects
-of this package (``MPSData`` from ``slater.C_to_MPS``; U(1) charge blocks).
+of this package (``MPSData`` from ``slater.C_to_MPS``: U(1) charge blocks; ``PfMPSData`` from
+``pfaffian.C_to_MPS``: parity blocks, indices of every bond reordered by parity).
 
 Device work (C ABI, ``include/temfpy_hip.h``; no CPU path for it):
 
@@ -27,7 +28,7 @@ from typing import Iterable, Literal, NamedTuple
 import numpy as np
 
 from . import _native as nat
-from .gutzwiller import _fermions_from_slater, _gemm_recs, _gemm_tiles, _sector_table, _cdiv
+from .gutzwiller import _as_fermions, _gemm_recs, _gemm_tiles, _sector_table, _cdiv
 from .testing import assert_array_less
 
 logger = logging.getLogger(__name__)
@@ -161,10 +162,11 @@ class _Chain:
     """Charge blocks of one finite MPS on the device, every block an (n_l x n_r) column-major matrix."""
 
     def __init__(self, dev, mps):
-        f = _fermions_from_slater(mps)
+        f = _as_fermions(mps)            # MPSData: U(1) blocks; PfMPSData: parities read off the tensors
         self.f, self.dev, self.L = f, dev, f.L
+        self.mod = 2 if f.conserve == "parity" else None
         self.form = list(mps.form)
-        self.lam = [np.asarray(x) for x in mps.lam]
+        self.lam = [np.asarray(x) if f.perm is None else np.asarray(x)[f.perm[b]] for b, x in enumerate(mps.lam)]
         self.tabs = [_sector_table(q) for q in f.charges]
         flat = f.flat.numpy() if not isinstance(f.flat, np.ndarray) else f.flat
         if flat.dtype != dev.np_dt:
@@ -207,7 +209,7 @@ class _Chain:
         return out
 
 
-def _transfer(dev, bra_sites, ket_sites, mode, dq):
+def _transfer(dev, bra_sites, ket_sites, mode, dq, mod=None):
     """Overlap of the Schmidt vectors spanned by two tensor chains (lists of per-site block dicts); charges of
     the ket chain are those of the bra chain + dq.  Returns {bra charge: (tensor, rows, cols)} at the far end."""
     left = mode == "left"
@@ -223,7 +225,7 @@ def _transfer(dev, bra_sites, ket_sites, mode, dq):
             E = {next(iter(ends)): (one, 1, 1)}
         terms = {}
         for (p, cl), (bptr, bl, br, bcr) in B.items():
-            kk = K.get((p, cl + dq))
+            kk = K.get((p, (cl + dq) % mod if mod else cl + dq))
             if kk is None:
                 continue
             kptr, kl, kr, kcr = kk
@@ -283,7 +285,7 @@ def overlap_schmidt(bra, ket, mode: str, *, segment_bra=None, segment_ket=None, 
     b0, b1 = segment_bra if segment_bra is not None else (0, bra.L)
     k0, k1 = segment_ket if segment_ket is not None else (0, ket.L)
     assert b1 - b0 == k1 - k0, "The two MPS have different lengths."
-    cplx = any(np.iscomplexobj(x.sites[0].blocks[0][5]) for x in (bra, ket))
+    cplx = any(np.iscomplexobj(x.sites[0].dense()) for x in (bra, ket))
     dev = _Dev(device, cplx)
     cb, ck = _Chain(dev, bra), _Chain(dev, ket)
     return _overlap(dev, cb, b0, b1, ck, k0, k1, mode)
@@ -295,14 +297,18 @@ def _overlap(dev, cb, b0, b1, ck, k0, k1, mode):
     Bs = [cb.to_form(i, want) for i in range(b0, b1)]
     Ks = [ck.to_form(i, want) for i in range(k0, k1)]
     qb, qk = (cb.f.charges[b0], ck.f.charges[k0]) if left else (cb.f.charges[b1], ck.f.charges[k1])
+    mod = cb.mod
+    assert ck.mod == mod, "Incompatible ChargeInfo in the two MPS"
     dq = int(qk[0]) - int(qb[0])        # both ends carry a single state; constant along the segment
-    E = _transfer(dev, _conj_transposed(dev, Bs) if not left else Bs, Ks, mode, dq)
+    dq = dq % mod if mod else dq
+    E = _transfer(dev, _conj_transposed(dev, Bs) if not left else Bs, Ks, mode, dq, mod)
     dev.torch.cuda.synchronize(dev.device)
     end_b, end_k = (b1, k1) if left else (b0, k0)
     blocks = {}
     for c, (t, r, cc) in E.items():
         m = t.cpu().numpy()[: r * cc].reshape(cc, r).T
-        blocks[(c, c + dq) if left else (c + dq, c)] = m
+        ck_ = (c + dq) % mod if mod else c + dq
+        blocks[(c, ck_) if left else (ck_, c)] = m
     rows, cols = (cb.f.charges[end_b], ck.f.charges[end_k]) if left else (ck.f.charges[end_k], cb.f.charges[end_b])
     return BlockMatrix(blocks, rows, cols)
 
@@ -410,8 +416,8 @@ def MPS_to_iMPS(mps_short, mps_long, sites_per_cell: int, cut: int, unitary_tol:
     if L_short + sites_per_cell != L_long:
         raise ValueError("The given two MPS must differ by one unit cell, got "
                          f"{L_long} - {L_short} != {sites_per_cell}")
-    if not (hasattr(mps_short.bonds[0], "q_left") and hasattr(mps_long.bonds[0], "q_left")):
-        raise ValueError("Incompatible ChargeInfo in the two MPS")          # iMPS.py:312-313 (U(1) MPSData only)
+    if hasattr(mps_short.bonds[0], "q_left") != hasattr(mps_long.bonds[0], "q_left"):
+        raise ValueError("Incompatible ChargeInfo in the two MPS")          # iMPS.py:312-313
     assert all(x is not None for x in mps_short.form), "mps_short is not canonical"
     assert all(x is not None for x in mps_long.form), "mps_long is not canonical"
     if unit_cell_width is None:
@@ -428,34 +434,36 @@ def MPS_to_iMPS(mps_short, mps_long, sites_per_cell: int, cut: int, unitary_tol:
         assert sites_per_cell % unit_cell_width == 0, f"{unit_cell_width = } does not divide {sites_per_cell = }"
         cyl1 = sites_per_cell // unit_cell_width
         assert cut % cyl1 == 0, f"{cut = } not divisible into requested cylinder circumferences of {cyl1}"
-    S0 = np.asarray(mps_short.lam[cut])
-    q0 = np.asarray(mps_short.bonds[cut].q_left, np.int64)
+    cplx = any(np.iscomplexobj(m.sites[0].dense()) for m in (mps_short, mps_long))
+    dev = _Dev(device, cplx)
+    cs, cl_ = _Chain(dev, mps_short), _Chain(dev, mps_long)
+    mod = cs.mod
+    if cl_.mod != mod:
+        raise ValueError("Incompatible ChargeInfo in the two MPS")
+    S0, q0 = cs.lam[cut], np.asarray(cs.f.charges[cut], np.int64)
     if isinstance(offset, Iterable) and not isinstance(offset, str):
         offset = list(offset)
         assert len(offset) == 1, "Expected 1 offsets"
         offset = offset[0]
     if isinstance(offset, (int, np.integer)):
         offset = int(offset)
-    elif offset == "auto":
-        offset = int(round(float((S0**2) @ q0)))                           # iMPS.py:364-366 (U(1): qmod = 1)
+    elif offset == "auto":                                                     # iMPS.py:360-366
+        offset = 0 if mod else int(round(float((S0**2) @ q0)))
     else:
         raise TypeError(f"Expected integer or 'auto' as offset, got {offset!r}")
     logger.info("Using charge offsets %s", offset)
-
-    cplx = any(np.iscomplexobj(m.sites[0].blocks[0][5]) for m in (mps_short, mps_long))
-    dev = _Dev(device, cplx)
-    cs, cl_ = _Chain(dev, mps_short), _Chain(dev, mps_long)
     # left gauge fixing matrix C, right gauge fixing matrix D (iMPS.py:381-413)
     C0 = _overlap(dev, cs, 0, cut, cl_, 0, cut, "left")
-    C, left_unitary, left_schmidt = basis_rotation(C0, S0, mps_long.lam[cut], mode="left", unitary_tol=unitary_tol,
+    C, left_unitary, left_schmidt = basis_rotation(C0, S0, cl_.lam[cut], mode="left", unitary_tol=unitary_tol,
                                                    schmidt_tol=schmidt_tol, device=device)
     D0 = _overlap(dev, cs, cut, L_short, cl_, cut + sites_per_cell, L_long, "right")
-    D, right_unitary, right_schmidt = basis_rotation(D0, S0, mps_long.lam[cut + sites_per_cell], mode="right",
+    D, right_unitary, right_schmidt = basis_rotation(D0, S0, cl_.lam[cut + sites_per_cell], mode="right",
                                                      unitary_tol=unitary_tol, schmidt_tol=schmidt_tol, device=device)
     # unit cell in right canonical form, gauge unitaries on the first and last tensor (iMPS.py:415-421)
     cell = [cl_.to_form(cut + i, "B") for i in range(sites_per_cell)]
-    tabs_s = _sector_table(q0)
-    dq = int(np.asarray(mps_long.bonds[-1].q_left)[0]) - int(np.asarray(mps_short.bonds[-1].q_left)[0])
+    dq = int(cl_.f.charges[L_long][0]) - int(cs.f.charges[L_short][0])
+    dq = dq % mod if mod else dq
+    shift = (lambda c: (c - dq) % mod) if mod else (lambda c: c - dq)
     upC = {k: dev.up(np.asfortranarray(v).astype(dev.np_dt).reshape(-1, order="F")) for k, v in C.blocks.items()}
     upD = {k: dev.up(np.asfortranarray(v).astype(dev.np_dt).reshape(-1, order="F")) for k, v in D.blocks.items()}
     g, first = [], {}
@@ -471,19 +479,19 @@ def MPS_to_iMPS(mps_short, mps_long, sites_per_cell: int, cut: int, unitary_tol:
     cell[0] = first
     g, last = [], {}
     for (p, cl), (ptr, n_l, n_r, cr) in cell[-1].items():
-        key = (cr, cr - dq)                                        # D: rows long (charge cr), columns short (cr - dq)
+        key = (cr, shift(cr))                                      # D: rows long (charge cr), columns short (cr - dq)
         if key not in upD:
             continue
         ns = D.blocks[key].shape[1]
         t = dev.zeros(n_l * ns)
         g.append((ptr, upD[key].data_ptr(), t.data_ptr(), n_l, ns, n_r, n_l, n_r, n_l))
-        last[(p, cl)] = [t.data_ptr(), n_l, ns, cr - dq]
+        last[(p, cl)] = [t.data_ptr(), n_l, ns, shift(cr)]
     dev.gemm(g)
     cell[-1] = last
     dev.torch.cuda.synchronize(dev.device)
     # ---- results -----------------------------------------------------------------------------------------------
-    lam = [S0] + [np.asarray(mps_long.lam[cut + i]) for i in range(1, sites_per_cell)] + [S0]
-    q_b = [q0] + [np.asarray(mps_long.bonds[cut + i].q_left, np.int64) for i in range(1, sites_per_cell)] + [q0]
+    lam = [S0] + [cl_.lam[cut + i] for i in range(1, sites_per_cell)] + [S0]
+    q_b = [q0] + [np.asarray(cl_.f.charges[cut + i], np.int64) for i in range(1, sites_per_cell)] + [q0]
     tabs = [_sector_table(q) for q in q_b]
     blocks = []
     for i, S in enumerate(cell):
@@ -494,9 +502,10 @@ def MPS_to_iMPS(mps_short, mps_long, sites_per_cell: int, cut: int, unitary_tol:
             buf = _read(dev, ptr, n_l * n_r).reshape(n_r, n_l).T
             (l0, nl), (r0, nr) = tabs[i][cl], tabs[i + 1][cr]
             assert (nl, nr) == (n_l, n_r)
-            bl.append((p, cl - offset, cr - offset, l0, l0 + nl, r0, r0 + nr, buf))
+            lab = (lambda c: (c - offset) % mod) if mod else (lambda c: c - offset)
+            bl.append((p, lab(cl), lab(cr), l0, l0 + nl, r0, r0 + nr, buf))
         blocks.append(bl)
-    res = iMPSData(blocks, lam, [q - offset for q in q_b], dq, unit_cell_width)
+    res = iMPSData(blocks, lam, [(q - offset) % mod if mod else q - offset for q in q_b], dq, unit_cell_width)
     return res, iMPSError(left_unitary, left_schmidt, right_unitary, right_schmidt)
 
 

@@ -150,3 +150,41 @@ def H_to_MPS(H: np.ndarray, trunc_par: dict | StoppingCondition, *, basis: str, 
     C = correlation_matrix(H, f"{basis}->M")
     return C_to_MPS(C, trunc_par, basis="M", diag_tol=diag_tol, ortho_center=ortho_center,
                     unit_cell_width=unit_cell_width, device=device)
+
+
+def C_to_iMPS(C_short: np.ndarray, C_long: np.ndarray, trunc_par: dict | StoppingCondition, sites_per_cell: int,
+              cut: int, *, basis: str, diag_tol: float = _DIAG_TOL, unitary_tol: float = 1e-6,
+              schmidt_tol: float = 1e-6, unit_cell_width: int | None = None, device: str = "cuda:0"):
+    """iMPS representation of a Nambu mean-field state from the correlation matrices of two chains that differ by
+    one unit cell (pfaffian.py:1924-2091): same arguments, defaults and exceptions.  As in
+    ``temfpy_amd.slater.C_to_iMPS`` the method differs from the reference's, stated rather than hidden: both
+    chains are converted in full with their orthogonality centre at ``cut`` and the unit cell is gauge fixed by
+    :func:`temfpy_amd.iMPS.MPS_to_iMPS` (transfer-matrix overlaps, Procrustes rotations on both sides), whereas
+    the reference uses its Pfaffian overlap formulas without environment tensors and reports zero right-hand
+    errors."""
+    from . import iMPS
+
+    trunc_par = to_stopping_condition(trunc_par)
+    if unit_cell_width is None:
+        unit_cell_width = sites_per_cell
+    elif sites_per_cell % unit_cell_width != 0:
+        raise ValueError(f"{unit_cell_width = } does not divide {sites_per_cell = }")
+    L_short, L_long = len(C_short) // 2, len(C_long) // 2
+    assert L_short + sites_per_cell == L_long, (
+        "The given two MPS must differ by one unit cell, got " f"{L_long} - {L_short} != {sites_per_cell}")
+    mps_s = C_to_MPS(C_short, trunc_par, basis=basis, diag_tol=diag_tol, ortho_center=cut, device=device)
+    mps_l = C_to_MPS(C_long, trunc_par, basis=basis, diag_tol=diag_tol, ortho_center=cut, device=device)
+    res, err = iMPS.MPS_to_iMPS(mps_s, mps_l, sites_per_cell, cut, unitary_tol=unitary_tol, schmidt_tol=schmidt_tol,
+                                offset=0, unit_cell_width=sites_per_cell, device=device)
+    res.unit_cell_width = unit_cell_width
+    return res, err
+
+
+def H_to_iMPS(H_short: np.ndarray, H_long: np.ndarray, trunc_par: dict | StoppingCondition, sites_per_cell: int,
+              cut: int, *, basis: str, diag_tol: float = _DIAG_TOL, unitary_tol: float = 1e-6,
+              schmidt_tol: float = 1e-6, unit_cell_width: int | None = None, device: str = "cuda:0"):
+    """pfaffian.py:2151-2242."""
+    C_short = correlation_matrix(H_short, basis=f"{basis}->{basis}")
+    C_long = correlation_matrix(H_long, basis=f"{basis}->{basis}")
+    return C_to_iMPS(C_short, C_long, trunc_par, sites_per_cell, cut, basis=basis, diag_tol=diag_tol,
+                     unitary_tol=unitary_tol, schmidt_tol=schmidt_tol, unit_cell_width=unit_cell_width, device=device)

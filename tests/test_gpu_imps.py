@@ -127,3 +127,45 @@ def test_H_to_iMPS(spinful):
         slater.H_to_iMPS(ssh(L), ssh(L + 2), {"chi_max": chi}, 2, cut, unit_cell_width=3)
     with pytest.raises(ValueError, match="spinful"):
         slater.H_to_iMPS(ssh(L), ssh(L + 2), {"chi_max": chi}, 2, cut, spinful="both")
+
+
+def kitaev(L, t1=1.5j, t2=1j):
+    """Majorana Hamiltonian of a gapped Kitaev chain, src/examples/iMPS_pfaffian.py:6-11."""
+    M = t1 * np.ones(2 * L - 1, complex)
+    M[1::2] = t2
+    M = np.diag(M, 1)
+    return M + M.T.conj()
+
+
+def test_pfaffian_H_to_iMPS():
+    """pfaffian.H_to_iMPS on the example of src/examples/iMPS_pfaffian.py (parity-conserving input, one site per
+    unit cell): oracle parity on the same finite MPS and the example's reconstruction check."""
+    from temfpy_amd import gutzwiller, iMPS, pfaffian
+
+    L, cut, chi, n_cell = 20, 10, 32, 3
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res, err = pfaffian.H_to_iMPS(kitaev(L), kitaev(L + 1), {"chi_max": chi}, 1, cut, basis="M")
+        ms = pfaffian.H_to_MPS(kitaev(L), {"chi_max": chi}, basis="M", ortho_center=cut)
+        ml = pfaffian.H_to_MPS(kitaev(L + 1), {"chi_max": chi}, basis="M", ortho_center=cut)
+        mv = pfaffian.H_to_MPS(kitaev(L + n_cell), {"chi_max": chi}, basis="M", ortho_center=cut)
+    assert res.L == 1 and err.total_error < 1e-4 and set(np.unique(res.charges[0])) <= {0, 1}
+
+    def sorted_dense(m):      # the package orders the indices of every bond by parity (stable)
+        T = m.dense_tensors()
+        q = gutzwiller.infer_parities(T)
+        pm = [np.argsort(x, kind="stable") for x in q]
+        return ([t[:, pm[i]][:, :, pm[i + 1]] for i, t in enumerate(T)], [np.asarray(x)[pm[b]] for b, x in enumerate(m.lam)],
+                list(m.form))
+
+    Ts, ls, fs = sorted_dense(ms)
+    Tl, ll, fl = sorted_dense(ml)
+    B, S, eo = io.mps_to_imps(Ts, ls, fs, Tl, ll, fl, 1, cut)
+    np.testing.assert_allclose(list(err), eo, rtol=0, atol=1e-9)
+    for t, r, sl in zip(res.dense_tensors(), B, S[:-1]):
+        assert (sl[None, :, None] * np.abs(t - r)).max() < 1e-9
+    Tr, lr, fr = io.insert_cells(Ts, ls, fs, res.dense_tensors(), res.lam, cut, n_cell)
+    Tv, lv, fv = sorted_dense(mv)
+    ov = io.overlap(Tv, lv, fv, Tr, lr, fr)
+    nr, nv = io.overlap(Tr, lr, fr, Tr, lr, fr).real, io.overlap(Tv, lv, fv, Tv, lv, fv).real
+    assert abs(abs(ov) / np.sqrt(nr * nv) - 1) < 1e-8
