@@ -135,6 +135,8 @@ int tmf_jacobi_block_batched(int dtype, int with_v, const tmf_jacobi_desc* d_des
  * columns of X and of the accumulated rotations are held p x nact in LDS when they fit, else in global memory
  * (desc.X in place, desc.V = p x p workspace).  desc.U receives the right singular vectors sorted by
  * descending singular value, zero columns for everything below the threshold; desc.s, desc.count as above.
+ * desc.V == 0: no accumulator, desc.U receives the sorted, normalised LEFT singular vectors instead (for the
+ * conjugate transpose of a QR-preconditioned factor these are the wanted right vectors, at half the work).
  * The `npc.svd` of the leftward sweep of TeNPy's MPS.canonical_form_finite (gutzwiller.py:266 / :471). */
 int tmf_jacobi_compact_batched(int dtype, const tmf_jacobi_desc* d_desc, int nprob, int max_p, int32_t* d_sweeps,
                                void* stream);

@@ -232,6 +232,9 @@ extern "C" int tmf_svd_left_batched(int dtype, const tmf_jacobi_desc* d_desc, in
 // columns of X and of the rotation accumulator V are held, p x nact each, in LDS when they fit (otherwise V,
 // or both, stay in global memory: d.X in place, d.V as p x nact workspace).  Output: d.U = right singular
 // vectors sorted by descending singular value (zero columns for everything below the threshold), d.s, d.count.
+// With d.V == 0 no rotations are accumulated and d.U receives the LEFT singular vectors (normalised rotated
+// columns) instead: fed with the conjugate transpose of a (twice) QR-preconditioned factor, whose columns are
+// graded, these are the wanted right vectors at half the work and half the LDS.
 // After a Gutzwiller projection about half of the columns are inactive: 4x fewer rotations per sweep and
 // p = 130 (real) fits the LDS that the plain kernel exhausts at p = 100.
 // ---------------------------------------------------------------------------------------------
@@ -283,8 +286,9 @@ __global__ __launch_bounds__(512) void jacobi_compact_kernel(const tmf_jacobi_de
   __syncthreads();
   if (my_col >= 0) act[my_rank] = my_col;
   __syncthreads();
+  const bool with_v = Vg != nullptr;    // desc.V == 0: left vectors only (no accumulator), see the entry point
   const bool x_lds = (size_t)p * nact <= (size_t)lds_elems;
-  const bool v_lds = 2 * (size_t)p * nact <= (size_t)lds_elems;
+  const bool v_lds = with_v && 2 * (size_t)p * nact <= (size_t)lds_elems;
   T* Xs = reinterpret_cast<T*>(smem);
   T* Vs = Xs + (size_t)p * nact;
   auto xcol = [&](int a) -> T* { return x_lds ? Xs + (size_t)a * p : Xg + (size_t)act[a] * d.ldx; };
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(512) void jacobi_compact_kernel(const tmf_jacobi_de
     const int c = act[a];
     for (int r = lane; r < p; r += 64) {
       if (x_lds) x[r] = Xg[(size_t)r + (size_t)c * d.ldx];
-      v[r] = (r == c) ? sc<T>::one() : sc<T>::zero();
+      if (with_v) v[r] = (r == c) ? sc<T>::one() : sc<T>::zero();
     }
   }
   __syncthreads();
@@ -354,12 +358,14 @@ __global__ __launch_bounds__(512) void jacobi_compact_kernel(const tmf_jacobi_de
               xi[r] = sc<T>::sub(sc<T>::scale(a, c), sc<T>::mul(sph, b));
               xj[r] = sc<T>::add(sc<T>::scale(a, s), sc<T>::mul(cph, b));
             }
-            T* vi = vcol(i);
-            T* vj = vcol(j);
-            for (int r = pl; r < p; r += tpp) {
-              const T a = vi[r], b = vj[r];
-              vi[r] = sc<T>::sub(sc<T>::scale(a, c), sc<T>::mul(sph, b));
-              vj[r] = sc<T>::add(sc<T>::scale(a, s), sc<T>::mul(cph, b));
+            if (with_v) {
+              T* vi = vcol(i);
+              T* vj = vcol(j);
+              for (int r = pl; r < p; r += tpp) {
+                const T a = vi[r], b = vj[r];
+                vi[r] = sc<T>::sub(sc<T>::scale(a, c), sc<T>::mul(sph, b));
+                vj[r] = sc<T>::add(sc<T>::scale(a, s), sc<T>::mul(cph, b));
+              }
             }
             if (pl == 0) atomicAdd(&flag, 1);
           }
@@ -390,8 +396,14 @@ __global__ __launch_bounds__(512) void jacobi_compact_kernel(const tmf_jacobi_de
       int rank = 0;
       for (int b = 0; b < nact; ++b) rank += (nrm[b] > sa) || (nrm[b] == sa && b < a);
       const bool keep = sa * sa >= d.thresh2;
-      const T* v = vcol(a);
-      for (int r = lane; r < p; r += 64) Ug[(size_t)r + (size_t)rank * d.ldu] = keep ? v[r] : sc<T>::zero();
+      if (with_v) {
+        const T* v = vcol(a);
+        for (int r = lane; r < p; r += 64) Ug[(size_t)r + (size_t)rank * d.ldu] = keep ? v[r] : sc<T>::zero();
+      } else {      // left singular vectors: the rotated columns, normalised
+        const T* x = xcol(a);
+        const double f = (keep && sa > 0.0) ? 1.0 / sa : 0.0;
+        for (int r = lane; r < p; r += 64) Ug[(size_t)r + (size_t)rank * d.ldu] = sc<T>::scale(x[r], f);
+      }
       if (lane == 0) sg[rank] = sa;
     } else {
       for (int r = lane; r < p; r += 64) Ug[(size_t)r + (size_t)a * d.ldu] = sc<T>::zero();

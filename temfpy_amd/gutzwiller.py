@@ -15,8 +15,9 @@ Everything numerical runs on the GPU through the C ABI (``include/temfpy_hip.h``
   ``method="sequential"`` (default) is TeNPy's algorithm: a sweep to the right with one QR per charge block
   (``tmf_house_qr_batched``, Householder: the projected tensors are exactly rank deficient, where Gram-Schmidt
   needs a rank decision and Householder does not), then a sweep back with one SVD per site, N = A X of shape
-  chi_l x (2 chi_r) per charge block: QR of N^H, one-sided Jacobi with accumulated rotations on the small factor
-  R^H (``tmf_jacobi_compact_batched``), B = (Q V)^H, U S = N (Q V) pushed to the left.  The result is exactly
+  chi_l x (2 chi_r) per charge block: QR of N^H, a second QR of the small factor R^H as preconditioner, one-sided
+  Jacobi WITHOUT accumulator on R3^H (``tmf_jacobi_compact_batched``: its normalised columns are the right
+  singular vectors V3 of R3), B = (Q V3)^H, U S = N (Q V3) pushed to the left.  The result is exactly
   right-canonical after truncation, like TeNPy's.
   ``method="parallel"`` removes the SVDs from the sequential part: two QR-only sweeps that do not depend on each
   other run concurrently on two HIP streams (rightwards ``R_j T_j = A_j R_{j+1}``, leftwards
@@ -534,11 +535,13 @@ class _Projector:
         for j in range(Ls + 1):
             for c, n in self.sect[j].items():
                 i = cnt_index[(j, c)]
-                jd[i] = (P(Cb[j][c]), P(Jwb[j][c]), P(Vzb[j][c]), sv_ptr + 8 * So[j][c], cnt_ptr + 4 * i, self.cutoff ** 2,
-                         n, n, n, n)
+                # Jacobi without accumulator on the conjugate transpose of the QR-preconditioned factor (graded
+                # columns): its sorted, normalised left singular vectors are the wanted right ones
+                jd[i] = (P(Jwb[j][c]), 0, P(Vzb[j][c]), sv_ptr + 8 * So[j][c], cnt_ptr + 4 * i, self.cutoff ** 2, n, n, n, n)
         if self.method == "sequential":
             # leftward sweep, one SVD per site as TeNPy does it (X = U S of bond j+1 lives in the L buffers):
-            # N = A_j X_{j+1}, Y = N^H = Q R, Z = R^H = N Q, Jacobi Z Vz = U S, B^H = Q Vz, X_j = N B^H
+            # N = A_j X_{j+1}, Y = N^H = Q R, second QR R^H = Q3 R3 (preconditioner: R3 is nearly diagonal), Jacobi on
+            # R3^H gives the right singular vectors V3 of R3, so N = (Q3 U3) S (Q V3)^H: B^H = Q V3, X_j = N B^H
             for j in range(Ls - 1, -1, -1):
                 g, cpy, gb, gx, wl, o = [], [], [], [], {}, 0
                 for c, v in Winfo[j].items():
@@ -551,15 +554,16 @@ class _Projector:
                     cols = Winfo[j][c][2]
                     g.append((P(voff + rows[(sg, c)]), P(Lb[j + 1][cp_]), P(Wo + wl[c] + n * cols[(sg, cp_)]),
                               n, npr, npr, m, npr, n))
-                qd = np.zeros(len(Winfo[j]), nat.qr_desc)
+                qd, qd2 = np.zeros(len(Winfo[j]), nat.qr_desc), np.zeros(len(Winfo[j]), nat.qr_desc)
                 for i, (c, v) in enumerate(Winfo[j].items()):
                     n, w = self.sect[j][c], v[1]
                     cpy.append((P(Wo + wl[c]), P(Yq[j][c]), n, w, n, w, 3 if self.cplx else 1, 0))
                     qd[i] = (P(Yq[j][c]), P(Cb[j][c]), w, n, w, n, 1, 0)
+                    qd2[i] = (P(Cb[j][c]), P(Jwb[j][c]), n, n, n, n, 1, 0)
                     gb.append((P(Yq[j][c]), P(Vzb[j][c]), P(Bho[j][c]), w, n, n, w, n, w))
                     gx.append((P(Wo + wl[c]), P(Bho[j][c]), P(Lb[j][c]), n, n, w, n, w, n))
                 i0 = cnt_index[(j, next(iter(self.sect[j])))]
-                steps2.append((G.add(_gemm_recs(g)), CP.add(np.array(cpy, nat.copy_desc)), QR.add(qd),
+                steps2.append((G.add(_gemm_recs(g)), CP.add(np.array(cpy, nat.copy_desc)), QR.add(qd), QR.add(qd2),
                                (i0, len(self.sect[j]), max(self.sect[j].values())), G.add(_gemm_recs(gb)),
                                G.add(_gemm_recs(gx))))
         else:
@@ -592,7 +596,12 @@ class _Projector:
                     for (sg, cp_), c0 in v[2].items():
                         npr = self.sect[j + 1][cp_]
                         g2.append((P(Vzb[j + 1][cp_]), P(G1o[j][c] + c0), P(Bho[j][c] + c0), npr, n, npr, npr, w, w))
-            tail = (G.add(_gemm_recs(gc)), G.add(_gemm_recs(g1)), G.add(_gemm_recs(g2)))
+            qc = np.zeros(n_sec_tot, nat.qr_desc)
+            for j in range(Ls + 1):
+                for c, n in self.sect[j].items():
+                    qc[cnt_index[(j, c)]] = (P(Cb[j][c]), P(Jwb[j][c]), n, n, n, n, 1, 0)      # C = Q R, R^H -> Jacobi
+            qc = qc[np.argsort(-qc["n"], kind="stable")]
+            tail = (G.add(_gemm_recs(gc)), G.add(_gemm_recs(g1)), G.add(_gemm_recs(g2)), QR.add(qc))
             jd = jd[np.argsort(-jd["p"], kind="stable")]          # one launch over all bonds: large problems first
         # upload all tables
         gt = G.table()
@@ -649,10 +658,11 @@ class _Projector:
             d_sw = None
             if os.environ.get("TMF_JACOBI_SWEEPS"):     # development aid: sweep counts of every Jacobi problem
                 d_sw = torch.zeros(n_sec_tot, dtype=torch.int32, device=self.device)
-            for gw_, cw_, qw_, (i0, nj, pmax), gb_, gx_ in steps2:
+            for gw_, cw_, qw_, qw2_, (i0, nj, pmax), gb_, gx_ in steps2:
                 gemm(gw_, s1)
                 copy(cw_, s1)
                 qr(qw_, s1)
+                qr(qw2_, s1)
                 nat.check(lib.tmf_jacobi_compact_batched(self.dt, tabs_d["jc"].data_ptr() + 64 * i0, nj, pmax,
                                                          None if d_sw is None else d_sw.data_ptr() + 4 * i0, s1),
                           "tmf_jacobi_compact_batched")
@@ -684,6 +694,7 @@ class _Projector:
             # ================= every bond at once =================
             t3 = time.perf_counter()
             gemm(tail[0], s1, alpha=1.0 / norm)
+            qr(tail[3], s1)
             nat.check(lib.tmf_jacobi_compact_batched(self.dt, tabs_d["jc"].data_ptr(), n_sec_tot, int(jd["p"].max()), None,
                                                      s1), "tmf_jacobi_compact_batched")
             gemm(tail[1], s1)

@@ -770,3 +770,44 @@ def test_jacobi_compact_rank_deficient(eng, cplx):
         np.testing.assert_allclose(np.linalg.norm(XV, axis=0), s[:k], rtol=1e-10, atol=1e-16)
         G = XV.conj().T @ XV                                    # columns of X V are orthogonal (= U S)
         np.testing.assert_allclose(G - np.diag(np.diag(G)), 0, atol=1e-14 * max(1.0, sref[0] ** 2))
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_jacobi_compact_left_vectors_of_preconditioned_factor(eng, cplx):
+    """desc.V == 0: left singular vectors without accumulator.  Input as in the canonicalisation sweep: the
+    conjugate transpose of the twice-QR'd factor of a graded, rank-deficient matrix; the normalised columns must
+    be orthonormal to 1e-13 even for singular values of 1e-11 and diagonalise the factor."""
+    from temfpy_amd import _native as nat
+
+    setup(eng, cplx)
+    rng = np.random.default_rng(41)
+    Ws, Rs = [], []
+    for p, r in [(141, 110), (64, 64), (20, 7)]:
+        sv = np.logspace(0, -11, r)
+        N = (np.linalg.qr(rnd(rng, (p, r), cplx))[0] * sv) @ np.linalg.qr(rnd(rng, (2 * p, r), cplx))[0].conj().T   # p x 2p
+        R = np.linalg.qr(N.conj().T)[1]                    # N^H = Q R
+        R3 = np.linalg.qr(R.conj().T)[1]                   # R^H = Q3 R3
+        Rs.append(R3)
+        Ws.append(R3.conj().T)
+    ps = [len(w) for w in Ws]
+    dX = [dev(eng, w) for w in Ws]
+    dU = [dev(eng, np.zeros_like(w)) for w in Ws]
+    ds = [torch.zeros(p, dtype=torch.float64, device="cuda:0") for p in ps]
+    dc = torch.zeros(len(ps), dtype=torch.int32, device="cuda:0")
+    d = np.zeros(len(ps), nat.jacobi_desc)
+    for i, p in enumerate(ps):
+        d[i] = (dX[i][1], 0, dU[i][1], ds[i].data_ptr(), dc.data_ptr() + 4 * i, 1e-24, p, p, p, p)
+    t = torch.from_numpy(d.view(np.uint8).reshape(-1).copy()).to("cuda:0")
+    sw = torch.zeros(len(ps), dtype=torch.int32, device="cuda:0")
+    nat.check(eng.lib.tmf_jacobi_compact_batched(eng.dtype, t.data_ptr(), len(ps), max(ps), sw.data_ptr(), eng.stream), "jc")
+    torch.cuda.synchronize()
+    for p, R3, du, s_, c in zip(ps, Rs, dU, ds, dc.cpu().numpy()):
+        V, s = back(du[0], (p, p)), s_.cpu().numpy()
+        sref = np.linalg.svd(R3, compute_uv=False)
+        k = int(np.sum(sref**2 >= 1e-24))
+        assert c == k
+        np.testing.assert_allclose(s[:k], sref[:k], rtol=1e-9, atol=1e-17)
+        np.testing.assert_allclose(V[:, :k].conj().T @ V[:, :k], np.eye(k), rtol=0, atol=1e-13)
+        G = (R3 @ V[:, :k]).conj().T @ (R3 @ V[:, :k])       # V = right singular vectors of R3
+        np.testing.assert_allclose(G - np.diag(np.diag(G)), 0, atol=1e-14)
+    assert sw.cpu().numpy().max() <= 8                      # preconditioned: few sweeps
