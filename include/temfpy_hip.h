@@ -273,7 +273,7 @@ int tmf_copy_blocks_batched(int dtype, const tmf_copy_desc* d_desc, int nprob, i
 
 /* Householder QR of many matrices, one workgroup each: A (m x n, column-major) is replaced by the thin
  * orthonormal factor Q and R (n x n upper triangular; flags & 1: its conjugate transpose R^H instead) is
- * written to `R` (may be 0).  For m < n, Q is m x m followed by zero columns and R has zero rows beyond m,
+ * written to `R` (may be 0).  flags & 2: only R is wanted, Q is not formed (A is left holding the reflectors).  For m < n, Q is m x m followed by zero columns and R has zero rows beyond m,
  * so shapes stay fixed.  Orthogonal to machine precision for any rank (no rank decision): the `npc.qr` /
  * first half of `npc.svd` of TeNPy's MPS.canonical_form_finite behind gutzwiller.py:266 / :471. */
 typedef struct {

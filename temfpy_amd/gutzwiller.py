@@ -559,7 +559,7 @@ class _Projector:
                     n, w = self.sect[j][c], v[1]
                     cpy.append((P(Wo + wl[c]), P(Yq[j][c]), n, w, n, w, 3 if self.cplx else 1, 0))
                     qd[i] = (P(Yq[j][c]), P(Cb[j][c]), w, n, w, n, 1, 0)
-                    qd2[i] = (P(Cb[j][c]), P(Jwb[j][c]), n, n, n, n, 1, 0)
+                    qd2[i] = (P(Cb[j][c]), P(Jwb[j][c]), n, n, n, n, 3, 0)       # R3^H only, Q3 is not needed
                     gb.append((P(Yq[j][c]), P(Vzb[j][c]), P(Bho[j][c]), w, n, n, w, n, w))
                     gx.append((P(Wo + wl[c]), P(Bho[j][c]), P(Lb[j][c]), n, n, w, n, w, n))
                 i0 = cnt_index[(j, next(iter(self.sect[j])))]
@@ -599,7 +599,7 @@ class _Projector:
             qc = np.zeros(n_sec_tot, nat.qr_desc)
             for j in range(Ls + 1):
                 for c, n in self.sect[j].items():
-                    qc[cnt_index[(j, c)]] = (P(Cb[j][c]), P(Jwb[j][c]), n, n, n, n, 1, 0)      # C = Q R, R^H -> Jacobi
+                    qc[cnt_index[(j, c)]] = (P(Cb[j][c]), P(Jwb[j][c]), n, n, n, n, 3, 0)      # C = Q R, R^H -> Jacobi
             qc = qc[np.argsort(-qc["n"], kind="stable")]
             tail = (G.add(_gemm_recs(gc)), G.add(_gemm_recs(g1)), G.add(_gemm_recs(g2)), QR.add(qc))
             jd = jd[np.argsort(-jd["p"], kind="stable")]          # one launch over all bonds: large problems first

@@ -721,6 +721,19 @@ def test_house_qr_any_rank(eng, cplx):
             assert np.all(Q[:, K:] == 0) and np.all(R[K:] == 0) and np.all(np.tril(R, -1) == 0)
             scale = max(np.abs(A).max(), 1e-300)
             np.testing.assert_allclose(Q @ R, A, rtol=0, atol=2e-14 * scale * max(m, n) ** 0.5)
+    # flags & 2: R only (|R| is fixed by A^H A = R^H R up to the signs of its rows)
+    dA = [dev(eng, a) for a in mats]
+    dR = [dev(eng, np.zeros((n, n), mats[0].dtype)) for (m, n) in shapes]
+    d = np.zeros(len(shapes), nat.qr_desc)
+    for i, (m, n) in enumerate(shapes):
+        d[i] = (dA[i][1], dR[i][1], m, n, m, n, 2, 0)
+    t = torch.from_numpy(d.view(np.uint8).reshape(-1).copy()).to("cuda:0")
+    nat.check(eng.lib.tmf_house_qr_batched(eng.dtype, t.data_ptr(), len(shapes), 300, 130, eng.stream), "qr")
+    torch.cuda.synchronize()
+    for (m, n), A, dr in zip(shapes, mats, dR):
+        R = back(dr[0], (n, n))
+        scale = max(np.abs(A).max(), 1e-300) ** 2
+        np.testing.assert_allclose(R.conj().T @ R, A.conj().T @ A, rtol=0, atol=1e-13 * scale * max(m, n))
 
 
 @pytest.mark.parametrize("cplx", [True, False])
