@@ -23,7 +23,7 @@ Everything numerical runs on the GPU through the C ABI (``include/temfpy_hip.h``
   other run concurrently on two HIP streams (rightwards ``R_j T_j = A_j R_{j+1}``, leftwards
   ``T_j L_{j+1} = L_j B_j``), the centre matrix of every bond is ``C_j = R_j L_j / norm``, the SVDs of ALL bonds
   and charge sectors are ONE Jacobi launch (~2500 workgroups instead of <= 5 at a time) and the Schmidt gauge
-  ``B_j <- V_j^H B_j V_{j+1}`` two batched MFMA launches (5x faster at L = 512, chi = 512).  Same state and
+  ``B_j <- V_j^H B_j V_{j+1}`` two batched MFMA launches (3x faster at L = 512, chi = 512).  Same state and
   Schmidt values; but rows of B that belong to Schmidt values within a few decades of ``cutoff`` are then
   isometric only up to (cutoff / s)^2, because every bond is truncated independently (exact for cutoff -> 0).
   In both methods Schmidt values below ``cutoff`` are zeroed on the device (shapes stay fixed: all descriptors
