@@ -116,6 +116,34 @@ def correlation_matrix(H: np.ndarray, basis: str | None = None, *, rtol: float =
     return assert_nambu(C, None if basis is None else basis[3], offset=1, name="correlation matrix", **tol)
 
 
+def parity(V: np.ndarray, *, tol: float = 1e-12, device: str = "cuda:0") -> int:
+    """Fermion parity of a Bogoliubov vacuum from the singular values of ``V`` (pfaffian.py:396-456): the
+    values strictly between 0 and 1 come in pairs, so the parity of the number of singular values above the
+    largest gap is that of the completely filled modes.  The singular values come from the GPU
+    (``utils._device_svd``)."""
+    from .utils import _device_svd
+
+    V = np.asarray(V)
+    if len(V) == 0:
+        return 0
+    if len(V) == 1:
+        v = V.item()
+        if np.isclose(v, 0.0, rtol=0, atol=tol):
+            return 0
+        if np.isclose(abs(v), 1.0, rtol=0, atol=tol):
+            return 1
+        raise RuntimeError("Invalid 1x1 V")
+    (s,) = _device_svd([V], device, False)
+    if len(V) > 2:
+        n = np.argmax(-np.diff(s))
+        return int((n + 1) % 2)
+    if np.allclose(s, [1.0, 0.0], rtol=0, atol=tol):
+        return 1
+    if np.isclose(s[0], s[1], rtol=0, atol=tol):
+        return 0
+    raise ValueError("Invalid 2x2 V")
+
+
 def C_to_MPS(C: np.ndarray, trunc_par: dict | StoppingCondition, *, basis: str, diag_tol: float = _DIAG_TOL,
              ortho_center: int = None, unit_cell_width: int | None = None, device: str = "cuda:0"):
     """MPS of a BCS / Pfaffian state from its Nambu correlation matrix (pfaffian.py:1785-1921)."""

@@ -824,3 +824,42 @@ def test_jacobi_compact_left_vectors_of_preconditioned_factor(eng, cplx):
         G = (R3 @ V[:, :k]).conj().T @ (R3 @ V[:, :k])       # V = right singular vectors of R3
         np.testing.assert_allclose(G - np.diag(np.diag(G)), 0, atol=1e-14)
     assert sw.cpu().numpy().max() <= 8                      # preconditioned: few sweeps
+
+
+def test_utils_block_svd_and_pfaffian_parity():
+    """utils.block_svd (utils.py:19-96) and pfaffian.parity (pfaffian.py:396-456) with their small SVDs on the GPU,
+    against the reference semantics evaluated with NumPy."""
+    from temfpy_amd import pfaffian, utils
+
+    rng = np.random.default_rng(5)
+    n, m, k = 12, 9, 6
+    U0 = np.linalg.qr(rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n)))[0]
+    V0 = np.linalg.qr(rng.normal(size=(m, m)) + 1j * rng.normal(size=(m, m)))[0]
+    sv = np.array([0.9, 0.5, 0.5, 0.5, 0.2, 0.2])
+    e = np.array([0.7, 0.4, 0.4, 0.4, 0.1, 0.1])          # degenerate groups 1 + 3 + 2
+    CLR = (U0[:, :k] * sv) @ V0[:, :k].conj().T
+    mix3 = np.linalg.qr(rng.normal(size=(3, 3)) + 1j * rng.normal(size=(3, 3)))[0]
+    mix2 = np.linalg.qr(rng.normal(size=(2, 2)) + 1j * rng.normal(size=(2, 2)))[0]
+    vL, vR = U0[:, :k].copy(), V0[:, :k].copy()
+    vL[:, 1:4], vR[:, 1:4] = vL[:, 1:4] @ mix3, vR[:, 1:4] @ np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    vL[:, 4:6] = vL[:, 4:6] @ mix2
+    a, b = utils.block_svd(CLR, vL, vR, e, overwrite=False)
+    S = a.conj().T @ CLR @ b
+    np.testing.assert_allclose(S, np.diag(np.diag(S)), atol=1e-13)
+    np.testing.assert_allclose(np.sort(np.abs(np.diag(S)))[::-1], np.sort(sv)[::-1], atol=1e-13)
+    assert np.all(np.diag(S).real > 0) and np.abs(np.diag(S).imag).max() < 1e-13
+    np.testing.assert_allclose(a.conj().T @ a, np.eye(k), atol=1e-13)
+    assert vL is not a and np.abs(vL - U0[:, :k]).max() > 1e-3          # overwrite=False left the input alone
+    a2, b2 = utils.block_svd(CLR, vL, vR, e)
+    assert a2 is vL and b2 is vR                                         # in place by default (utils.py:65-67)
+    # parity: singular values 1 (filled), pairs in (0, 1), zeros
+    for n_one, pairs, zeros in [(1, [0.6], 2), (2, [0.8, 0.3], 1), (0, [0.7], 3), (3, [], 2)]:
+        s = np.array([1.0] * n_one + [x for x in pairs for _ in range(2)] + [0.0] * zeros)
+        p = len(s)
+        A = np.linalg.qr(rng.normal(size=(p, p)) + 1j * rng.normal(size=(p, p)))[0]
+        B = np.linalg.qr(rng.normal(size=(p, p)) + 1j * rng.normal(size=(p, p)))[0]
+        assert pfaffian.parity((A * s) @ B) == n_one % 2
+    assert pfaffian.parity(np.zeros((0, 0))) == 0 and pfaffian.parity(np.array([[1j]])) == 1
+    assert pfaffian.parity(np.diag([1.0, 0.0])) == 1 and pfaffian.parity(0.5 * np.eye(2)) == 0
+    with pytest.raises(RuntimeError):
+        pfaffian.parity(np.array([[0.5]]))
