@@ -18,6 +18,7 @@ N > 1  : conversions are independent objects: every rank converts its own chain 
 Prints ONE JSON line on rank 0 (see the driver contract in the task description).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -174,6 +175,12 @@ def main():
         """W untimed + exactly K timed steps between barrier + synchronize; max over ranks."""
         for _ in range(a.warmup):
             step()
+        # Python's cyclic garbage collector is kept out of the timed region: a generation-2 collection over the
+        # interpreter's ~10^6 live objects takes ~30 ms, and whether one falls inside the K steps depends on the
+        # allocation count before them (measured with rocprofv3: a 30 ms host stall between two conversions in
+        # `python bench.py`, none in `python bench.py --steps 5`, 44 vs 38 ms per step; kernels identical).
+        gc.collect()
+        gc.disable()
         barrier()
         for e_ in engines + pipe_engines:
             e_.time_gemm = collect
@@ -190,6 +197,7 @@ def main():
                 gemm_fl.append(sum(fl for _, _, fl in eng.gemm_events))
         barrier()
         dt_ = time.perf_counter() - t0
+        gc.enable()
         if world > 1:
             t = torch.tensor([dt_], dtype=torch.float64, device="cpu" if same_dev else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
