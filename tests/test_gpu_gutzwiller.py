@@ -233,3 +233,37 @@ def test_pfaffian_input_parity_conserving(seed, kind):
         X = np.einsum("pab,pcb->ac", t, t.conj())
         assert np.abs(X - np.eye(len(X))).max() < 1e-10
     assert abs(spin_overlap(B, Bh) - 1) < 1e-10
+
+
+def test_config5_full_size_properties():
+    """BASELINE config 5 at full size (L = 512 uniform chain, spinful "PH", chi_max = 512 -> 512 spins), checked
+    through size-independent properties: right-canonical isometry on sampled sites, <psi|psi> = 1 by transfer
+    matrices, 2 S^z bookkeeping, and agreement of the two canonicalisation methods (norm, Schmidt values)."""
+    from temfpy_amd import gutzwiller, slater
+
+    C, _ = slater.correlation_matrix(uniform_chain(512))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mps = slater.C_to_MPS(C, {"chi_max": 512}, spinful="PH", as_tenpy=False)
+    seq = gutzwiller.abrikosov_ph(mps)
+    par = gutzwiller.abrikosov_ph(mps, method="parallel")
+    assert seq.L == 512 and seq.conserve == "Sz" and 1e-60 < seq.norm < 1e-50
+    assert abs(par.norm / seq.norm - 1) < 1e-10
+    T = seq.dense_tensors()
+    for j in (0, 1, 100, 255, 256, 400, 510, 511):
+        X = np.einsum("pab,pcb->ac", T[j], T[j].conj())
+        assert np.abs(X - np.eye(len(X))).max() < 1e-10
+    E = np.ones((1, 1))
+    for t in T:
+        E = np.tensordot(np.tensordot(E, t.conj(), axes=(0, 1)), t, axes=([0, 1], [1, 0]))
+    assert abs(E[0, 0] - 1) < 1e-9
+    assert seq.charges[0].tolist() == [0] and seq.charges[-1].tolist() == [0]
+    for bl in (seq.blocks[7], seq.blocks[300]):
+        for p, ql, qr, *_ in bl:
+            assert qr - ql == (1 if p == 1 else -1)
+    for b in range(0, 513, 16):
+        a, r = np.sort(seq.lam[b])[::-1], np.sort(par.lam[b])[::-1]
+        n = min(len(a), len(r))
+        assert np.abs(a[:n] - r[:n]).max() < 1e-11 and abs(len(a) - len(r)) <= (a < 1e-11).sum() + (r < 1e-11).sum()
+    S = seq.entanglement_entropy()
+    assert abs(S[255] - S[255 - 2]) < 0.5 and 0.5 < S[255] < 2.0          # log-law plateau of the projected chain
