@@ -282,6 +282,17 @@ typedef struct {
 } tmf_qr_desc;               /* 40 bytes */
 int tmf_house_qr_batched(int dtype, const tmf_qr_desc* d_desc, int nprob, int max_m, int max_n, void* stream);
 
+/* Householder QR of tall slabs with the working panel in LDS (n x c, c <= 64, n <= 4096): A is replaced by the
+ * thin orthonormal factor Q (flags & 2: left untouched... holding the reflectors), R or R^H (flags & 1) goes to `R`
+ * (may be 0); `Q` is a caller-provided scratch of n x c elements (leading dimension ldq).  One workgroup per
+ * slab.  The two range-finder QRs of every cut (orthonormal bases inside the replacement of
+ * numpy.linalg.eigh, slater.py:347): orthogonal for any numerical rank, one launch instead of ~60. */
+typedef struct {
+  uint64_t A, Q, R;
+  int32_t n, c, lda, ldq, ldr, flags;
+} tmf_slab_desc;             /* 48 bytes */
+int tmf_house_slab_batched(int dtype, const tmf_slab_desc* d_desc, int nprob, int max_n, int max_c, void* stream);
+
 /* Products of nested blocks of one D x D matrix C (column-major) with a shared block Omega whose
  * rows are indexed by the GLOBAL orbital index: for every cut position x with dest[x] != 0
  *

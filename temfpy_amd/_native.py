@@ -68,6 +68,9 @@ assert copy_desc.itemsize == 40
 qr_desc = np.dtype([("A", "<u8"), ("R", "<u8"), ("m", "<i4"), ("n", "<i4"), ("lda", "<i4"), ("ldr", "<i4"),
                     ("flags", "<i4"), ("pad", "<i4")])
 assert qr_desc.itemsize == 40
+slab_desc = np.dtype([("A", "<u8"), ("Q", "<u8"), ("R", "<u8"), ("n", "<i4"), ("c", "<i4"), ("lda", "<i4"), ("ldq", "<i4"),
+                      ("ldr", "<i4"), ("flags", "<i4")])
+assert slab_desc.itemsize == 48
 site_job = np.dtype([("mode", "<i4"), ("cut_b", "<i4"), ("cut_k", "<i4"), ("k_b", "<i4"), ("nf_b", "<i4"),
                      ("k_k", "<i4"), ("nf_k", "<i4"), ("sec_cap", "<i4"), ("row_off", "<i8"), ("col_off", "<i8"),
                      ("bra_off", "<i8"), ("sec_off", "<i8"), ("idx_off", "<i8"), ("idx_cap", "<i8")])
@@ -83,7 +86,7 @@ SYMBOLS = [
     "tmf_det_gather_batched", "tmf_det_reduced_batched", "tmf_det_ppt_batched", "tmf_transpose", "tmf_fill_normal",
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_column_norms_batched", "tmf_cut_vectors",
     "tmf_site_prepare", "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_det_tiles_build", "tmf_pf_gather_batched",
-    "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched", "tmf_copy_blocks_batched", "tmf_house_qr_batched", "tmf_jacobi_compact_batched",
+    "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched", "tmf_copy_blocks_batched", "tmf_house_qr_batched", "tmf_jacobi_compact_batched", "tmf_house_slab_batched",
 ]
 
 
@@ -129,6 +132,7 @@ def load():
         fn.argtypes = [vp, i32, vp]
     lib.tmf_copy_blocks_batched.argtypes = [i32, vp, i32, i32, vp]
     lib.tmf_house_qr_batched.argtypes = [i32, vp, i32, i32, i32, vp]
+    lib.tmf_house_slab_batched.argtypes = [i32, vp, i32, i32, i32, vp]
     lib.tmf_transpose.argtypes = [i32, vp, vp, i32, vp]
     lib.tmf_fill_normal.argtypes = [i32, vp, i64, u64, vp]
     lib.tmf_gather_signed_batched.argtypes = [i32, vp, i32, vp]

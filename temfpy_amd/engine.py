@@ -251,6 +251,34 @@ class Engine:
         nat.check(self.lib.tmf_bcgs_batched(self.dtype, t_bd.data_ptr(), nat._p(bd), base.size, passes,
                                             1 if cholqr else 0, d_work.data_ptr(), wb, self.stream), "tmf_bcgs_batched")
 
+    def house_slab(self, base, rows, ld, cols, inplace=True):
+        """Householder QR of tall slabs (tmf_house_slab_batched: columns in registers, reflector blocks in LDS, one
+        workgroup per slab): the thin orthonormal factor of every matrix base[i] (rows[i] x cols[i], leading
+        dimension ld[i]).  Orthogonal for any numerical rank - no projection passes, no per-column rank decision.
+        inplace: Q overwrites the slab.  Otherwise Q stays in the scratch the kernel builds it in (saves one pass
+        over every slab) and the array of its addresses is returned (leading dimension = rows); slabs without
+        rows or columns keep their address."""
+        base, rows, ld, cols = (np.asarray(x, np.int64) for x in (base, rows, ld, cols))
+        out = base.copy()
+        keep = np.nonzero((rows > 0) & (cols > 0))[0]
+        if keep.size == 0:
+            return out
+        keep = keep[np.argsort(-rows[keep], kind="stable")]      # long slabs first
+        b_, r_, l_, c_ = (x[keep] for x in (base, rows, ld, cols))
+        sizes = r_ * c_
+        off = np.concatenate(([0], np.cumsum((sizes + 1) & ~1)))
+        d_q = self._alloc(int(off[-1]) + 2)
+        self._keep.append(d_q)
+        d = np.zeros(b_.size, nat.slab_desc)
+        d["A"], d["Q"], d["R"] = b_, d_q.data_ptr() + off[:-1] * self.elem, 0
+        d["n"], d["c"], d["lda"], d["ldq"], d["ldr"], d["flags"] = r_, c_, l_, r_, 1, 0 if inplace else 2
+        t_d = self._up(d)
+        nat.check(self.lib.tmf_house_slab_batched(self.dtype, t_d.data_ptr(), b_.size, int(r_.max()), int(c_.max()),
+                                                  self.stream), "tmf_house_slab_batched")
+        if not inplace:
+            out[keep] = d["Q"].astype(np.int64)
+        return out
+
     def jacobi(self, X, V, s, count, thresh2, p, ldx, ldv, left_only=False):
         """One-sided Jacobi per problem.  ``left_only``: ``V`` receives the normalised LEFT singular
         vectors (tmf_svd_left_batched, no rotation accumulator) instead of the right ones.
@@ -409,7 +437,18 @@ class Engine:
         else:
             self.gemm(0, 1.0, 0.0, off, omp, Yp, n, p, m, L, L, ld1)
         # E2: Q = qr(Y)
-        self.bcgs2(Yp[doE], n[doE], n[doE], zero[doE], p[doE], scrp[doE], passes=3)
+        house = self.range_qr == "house" and int(np.max(p[doE], initial=0)) <= 64
+
+        def _rqr(ptr, rows_):
+            """Orthonormal factor of every slab; returns the addresses it lives at afterwards."""
+            if house:      # Q stays in the buffer the kernel builds it in (no copy back over the slab)
+                ptr = np.array(ptr, np.int64)
+                ptr[doE] = self.house_slab(ptr[doE], rows_[doE], rows_[doE], p[doE], inplace=False)
+            else:
+                self.bcgs2(ptr[doE], rows_[doE], rows_[doE], zero[doE], p[doE], scrp[doE], passes=3)
+            return ptr
+
+        Yp = _rqr(Yp, n)
         # E3: B^H = F^H Q  (m x p), R = Q2^H B^H.  One round of orthogonal (subspace) iteration first:
         # the range-finder error of a direction is ~ sigma_(p+1) / sigma_i, which is only 5e-6 for the
         # weakest kept mode when the spectrum decays slowly (measured: random BdG chain, L = 512);
@@ -417,10 +456,10 @@ class Engine:
         for it in range(iterations + 1):
             self.gemm(1, 1.0, 0.0, off, Yp, Btp, m, p, n, L, ld1, np.maximum(m, 1))
             d_Q2.copy_(d_Bt)
-            self.bcgs2(Q2p[doE], m[doE], m[doE], zero[doE], p[doE], scrp[doE], passes=3)
+            Q2p = _rqr(d_Q2.data_ptr() + oB * el, m)
             if it < iterations:
                 self.gemm(0, 1.0, 0.0, off, Q2p, Yp, n, p, m, L, np.maximum(m, 1), ld1)
-                self.bcgs2(Yp[doE], n[doE], n[doE], zero[doE], p[doE], scrp[doE], passes=3)
+                Yp = _rqr(Yp, n)
         # R^H = (F^H Q)^H Q2 (lower triangular; its columns are graded by the singular values, which is
         # the form one-sided Jacobi diagonalises in few sweeps: 11.2 ms -> measured below for R itself)
         self.gemm(1, 1.0, 0.0, Btp, Q2p, Rp, p, p, m, np.maximum(m, 1), np.maximum(m, 1), np.maximum(p, 1))
@@ -441,6 +480,7 @@ class Engine:
                     keep=(d_Y, d_U0, d_W1, d_Bt, d_Q2, d_R, d_Z, d_T, d_X, d_sig, d_scr))
 
     range_floor_tol = 1e-11
+    range_qr = os.environ.get("TMF_RANGE_QR", "house")      # "house": LDS-panel Householder; "bcgs": blocked Gram-Schmidt
     filled_cholqr = os.environ.get("TMF_FILLED_CHOLQR", "1") == "1"   # panel method of the filled-basis QR
     det_method = os.environ.get("TMF_DET_METHOD", "ppt")              # "ppt" | "reduced" (A/B switch)
     filled_passes = int(os.environ.get("TMF_FILLED_PASSES", "1"))     # projection passes of the filled-basis QR

@@ -863,3 +863,32 @@ def test_utils_block_svd_and_pfaffian_parity():
     assert pfaffian.parity(np.diag([1.0, 0.0])) == 1 and pfaffian.parity(0.5 * np.eye(2)) == 0
     with pytest.raises(RuntimeError):
         pfaffian.parity(np.array([[0.5]]))
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_house_slab_qr(eng, cplx):
+    """tmf_house_slab_batched (panel in LDS): in-place thin Q orthonormal to 1e-13 with the column space of A, for
+    tall slabs of the range-finder sizes, graded / exactly rank-deficient / zero slabs and n < c."""
+    setup(eng, cplx)
+    rng = np.random.default_rng(51)
+    shapes = [(512, 64), (1023, 64), (300, 64), (64, 64), (40, 64), (1, 64), (777, 33), (130, 1), (257, 17), (96, 64)]
+    mats = []
+    for i, (n, c) in enumerate(shapes):
+        A = rnd(rng, (n, c), cplx)
+        if i == 0:      # numerically rank 35, singular values down to 1e-17 (a range-finder slab)
+            A = (rnd(rng, (n, 35), cplx) * np.logspace(0, -17, 35)) @ rnd(rng, (35, c), cplx)
+        if i == 2:
+            A[:, 40:] = 0.0
+        if i == 9:
+            A[:] = 0.0
+        mats.append(A)
+    dA = [dev(eng, a) for a in mats]
+    eng.house_slab([d[1] for d in dA], [s[0] for s in shapes], [s[0] for s in shapes], [s[1] for s in shapes])
+    torch.cuda.synchronize()
+    for (n, c), A, da in zip(shapes, mats, dA):
+        Q = back(da[0], (n, c))
+        K = min(n, c)
+        np.testing.assert_allclose(Q[:, :K].conj().T @ Q[:, :K], np.eye(K), rtol=0, atol=1e-13)
+        assert np.all(Q[:, K:] == 0)
+        scale = max(np.abs(A).max(), 1e-300)
+        np.testing.assert_allclose(Q @ (Q.conj().T @ A), A, rtol=0, atol=1e-13 * scale * n ** 0.5)   # span(Q) contains A
