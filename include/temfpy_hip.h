@@ -283,8 +283,9 @@ typedef struct {
 int tmf_house_qr_batched(int dtype, const tmf_qr_desc* d_desc, int nprob, int max_m, int max_n, void* stream);
 
 /* Householder QR of tall slabs with the working panel in LDS (n x c, c <= 64, n <= 4096): A is replaced by the
- * thin orthonormal factor Q (flags & 2: left untouched... holding the reflectors), R or R^H (flags & 1) goes to `R`
- * (may be 0); `Q` is a caller-provided scratch of n x c elements (leading dimension ldq).  One workgroup per
+ * thin orthonormal factor Q (flags & 2: Q stays in the scratch, A is left holding the reflectors; flags & 4: no Q at
+ * all, only R), R or R^H (flags & 1) goes to `R` (may be 0); `Q` is a caller-provided scratch of n x c elements
+ * (leading dimension ldq; unused with flags & 4).  One workgroup per
  * slab.  The two range-finder QRs of every cut (orthonormal bases inside the replacement of
  * numpy.linalg.eigh, slater.py:347): orthogonal for any numerical rank, one launch instead of ~60. */
 typedef struct {

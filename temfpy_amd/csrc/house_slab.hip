@@ -146,6 +146,7 @@ void house_slab_kernel(const tmf_slab_desc* __restrict__ desc, int w) {
       if (d.flags & 1) R[cc + (size_t)r * d.ldr] = sc<T>::conj(v);
       else R[r + (size_t)cc * d.ldr] = v;
     }
+  if (d.flags & 4) return;      // only R wanted: no Q at all (A is left holding the reflectors)
   // ---------------- phase 2: thin Q, panel by panel, into the scratch ----------------
   for (int p0 = 0; p0 < c; p0 += w) {
     const int wp = (c - p0 < w) ? c - p0 : w;

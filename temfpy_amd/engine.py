@@ -251,7 +251,7 @@ class Engine:
         nat.check(self.lib.tmf_bcgs_batched(self.dtype, t_bd.data_ptr(), nat._p(bd), base.size, passes,
                                             1 if cholqr else 0, d_work.data_ptr(), wb, self.stream), "tmf_bcgs_batched")
 
-    def house_slab(self, base, rows, ld, cols, inplace=True):
+    def house_slab(self, base, rows, ld, cols, inplace=True, r_only=None, r_ld=None):
         """Householder QR of tall slabs (tmf_house_slab_batched: columns in registers, reflector blocks in LDS, one
         workgroup per slab): the thin orthonormal factor of every matrix base[i] (rows[i] x cols[i], leading
         dimension ld[i]).  Orthogonal for any numerical rank - no projection passes, no per-column rank decision.
@@ -265,11 +265,19 @@ class Engine:
             return out
         keep = keep[np.argsort(-rows[keep], kind="stable")]      # long slabs first
         b_, r_, l_, c_ = (x[keep] for x in (base, rows, ld, cols))
+        d = np.zeros(b_.size, nat.slab_desc)
+        if r_only is not None:      # only the conjugate transpose of the triangular factor is wanted (slab destroyed)
+            d["A"], d["Q"], d["R"] = b_, 0, np.asarray(r_only, np.int64)[keep]
+            d["n"], d["c"], d["lda"], d["ldq"], d["flags"] = r_, c_, l_, 1, 1 | 4
+            d["ldr"] = np.asarray(r_ld, np.int64)[keep]
+            t_d = self._up(d)
+            nat.check(self.lib.tmf_house_slab_batched(self.dtype, t_d.data_ptr(), b_.size, int(r_.max()), int(c_.max()),
+                                                      self.stream), "tmf_house_slab_batched")
+            return out
         sizes = r_ * c_
         off = np.concatenate(([0], np.cumsum((sizes + 1) & ~1)))
         d_q = self._alloc(int(off[-1]) + 2)
         self._keep.append(d_q)
-        d = np.zeros(b_.size, nat.slab_desc)
         d["A"], d["Q"], d["R"] = b_, d_q.data_ptr() + off[:-1] * self.elem, 0
         d["n"], d["c"], d["lda"], d["ldq"], d["ldr"], d["flags"] = r_, c_, l_, r_, 1, 0 if inplace else 2
         t_d = self._up(d)
@@ -455,6 +463,12 @@ class Engine:
         # Y <- F orth(F^H Q) cubes that ratio.
         for it in range(iterations + 1):
             self.gemm(1, 1.0, 0.0, off, Yp, Btp, m, p, n, L, ld1, np.maximum(m, 1))
+            if house and iterations == 0:
+                # only R^H = (F^H Q)^H Q2 is needed below: factor B^H in place and take R^H from the kernel - no Q2,
+                # no copy, no product (R is unique up to the phases of its rows, which the Jacobi does not see)
+                d_R.zero_()
+                self.house_slab(Btp[doE], m[doE], np.maximum(m, 1)[doE], p[doE], r_only=Rp[doE], r_ld=np.maximum(p, 1)[doE])
+                break
             d_Q2.copy_(d_Bt)
             Q2p = _rqr(d_Q2.data_ptr() + oB * el, m)
             if it < iterations:
@@ -462,7 +476,8 @@ class Engine:
                 Yp = _rqr(Yp, n)
         # R^H = (F^H Q)^H Q2 (lower triangular; its columns are graded by the singular values, which is
         # the form one-sided Jacobi diagonalises in few sweeps: 11.2 ms -> measured below for R itself)
-        self.gemm(1, 1.0, 0.0, Btp, Q2p, Rp, p, p, m, np.maximum(m, 1), np.maximum(m, 1), np.maximum(p, 1))
+        if not (house and iterations == 0):
+            self.gemm(1, 1.0, 0.0, Btp, Q2p, Rp, p, p, m, np.maximum(m, 1), np.maximum(m, 1), np.maximum(p, 1))
         # E4: Jacobi SVD of R^H: left singular vectors Z (= right ones of R), sigma; columns below the
         # threshold zeroed
         self.jacobi(Rp, Zp, sigp, cntp, thr2, p, np.maximum(p, 1), np.maximum(p, 1), left_only=True)
