@@ -92,41 +92,49 @@ void house_slab_kernel(const tmf_slab_desc* __restrict__ desc, int w) {
         for (int j = 0; j < nb; ++j) apply(kb + j, sc<T>::conj(taus[kb + j]), VBLK + (size_t)j * n);
     }
     __syncthreads();
+    // The wavefront of column jj builds reflector k = p0 + jj from its registers into an LDS slot; the others
+    // apply it.  Look-ahead: the wavefront of column jj + 1 builds the next reflector right after its own update,
+    // into the other slot, while the rest is still applying the current one - one barrier per reflector.
+    auto build = [&](int k, T* __restrict__ slot) {
+      double s_ = 0.0;
+      T al = sc<T>::zero();
+#pragma unroll
+      for (int i = 0; i < RMAX; ++i) {
+        const int r = lane + 64 * i;
+        if (r > k && r < n) s_ += sc<T>::abs2(col[i]);
+        if (r == k) al = col[i];
+      }
+      for (int o = 32; o > 0; o >>= 1) s_ += __shfl_xor(s_, o);
+      const T alpha = wsum<T>(al);
+      T tau = sc<T>::zero(), scal = sc<T>::zero(), beta = alpha;
+      if (s_ > 0.0 || sc<T>::imag(alpha) != 0.0) {
+        double b_ = sqrt(sc<T>::abs2(alpha) + s_);
+        if (sc<T>::real(alpha) > 0.0) b_ = -b_;
+        beta = sc<T>::from_real(b_);
+        tau = sc<T>::scale(sc<T>::sub(beta, alpha), 1.0 / b_);
+        scal = sc<T>::inv(sc<T>::sub(alpha, beta));
+      }
+#pragma unroll
+      for (int i = 0; i < RMAX; ++i) {
+        const int r = lane + 64 * i;
+        if (r >= k && r < n) {
+          const T v = (r == k) ? sc<T>::one() : sc<T>::mul(col[i], scal);
+          slot[r] = v;
+          col[i] = (r == k) ? beta : v;
+        }
+      }
+      if (lane == 0) taus[k] = tau;
+    };
+    if (wave == 0 && p0 < K) build(p0, VBLK);
+    __syncthreads();
     for (int jj = 0; jj < wp; ++jj) {
       const int k = p0 + jj;
       if (k >= K) break;
-      if (wave == jj) {            // this column's wavefront builds the reflector (slot 0 of the block)
-        double s = 0.0;
-        T al = sc<T>::zero();
-#pragma unroll
-        for (int i = 0; i < RMAX; ++i) {
-          const int r = lane + 64 * i;
-          if (r > k && r < n) s += sc<T>::abs2(col[i]);
-          if (r == k) al = col[i];
-        }
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        const T alpha = wsum<T>(al);
-        T tau = sc<T>::zero(), scal = sc<T>::zero(), beta = alpha;
-        if (s > 0.0 || sc<T>::imag(alpha) != 0.0) {
-          double b = sqrt(sc<T>::abs2(alpha) + s);
-          if (sc<T>::real(alpha) > 0.0) b = -b;
-          beta = sc<T>::from_real(b);
-          tau = sc<T>::scale(sc<T>::sub(beta, alpha), 1.0 / b);
-          scal = sc<T>::inv(sc<T>::sub(alpha, beta));
-        }
-#pragma unroll
-        for (int i = 0; i < RMAX; ++i) {
-          const int r = lane + 64 * i;
-          if (r >= k && r < n) {
-            const T v = (r == k) ? sc<T>::one() : sc<T>::mul(col[i], scal);
-            VBLK[r] = v;
-            col[i] = (r == k) ? beta : v;
-          }
-        }
-        if (lane == 0) taus[k] = tau;
+      T* cur = VBLK + (size_t)(jj & 1) * n;
+      if (mine && wave > jj) {
+        apply(k, sc<T>::conj(taus[k]), cur);
+        if (wave == jj + 1 && k + 1 < K) build(k + 1, VBLK + (size_t)((jj + 1) & 1) * n);
       }
-      __syncthreads();
-      if (mine && wave > jj) apply(k, sc<T>::conj(taus[k]), VBLK);
       __syncthreads();
     }
     if (mine) {
@@ -198,7 +206,7 @@ extern "C" int tmf_house_slab_batched(int dtype, const tmf_slab_desc* d_desc, in
     set_error("tmf_house_slab_batched: %d rows not in 1..%d", max_n, (dtype == TMF_C128) ? 1024 : 2048);
     return TMF_E_LIMIT;
   }
-  const size_t lds = ((size_t)max_n * VB + (size_t)max_c + 4) * elem + 64;
+  const size_t lds = ((size_t)max_n * VB + (size_t)max_c + 4) * elem + 64;   // VB >= 2 slots for the look-ahead
   if (lds > 150 * 1024) {
     set_error("tmf_house_slab_batched: %d rows need %zu B of LDS", max_n, lds);
     return TMF_E_LIMIT;
