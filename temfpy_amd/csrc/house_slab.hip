@@ -16,7 +16,8 @@
 //            finally Q is copied over A.
 // A reflector application is a lane-strided dot product with the LDS vector + 6 shuffles + update in registers.
 // (First version with the panel in LDS: 5 LDS accesses per element and reflector, LDS-bandwidth bound at 5.4 ms
-// per launch - no faster than the Gram-Schmidt it replaces.)  Traffic per slab: ~4 x its size.
+// per launch - no faster than the Gram-Schmidt it replaces.)  HBM traffic: 7 x the slab (PMC: 1.9 GB per launch for
+// 0.27 GB of slabs with Q, the earlier reflectors are re-read by every later panel), 0.8 TB/s: not the bound.
 #include "common.hpp"
 
 namespace tmf {
