@@ -445,11 +445,14 @@ class Engine:
         else:
             self.gemm(0, 1.0, 0.0, off, omp, Yp, n, p, m, L, L, ld1)
         # E2: Q = qr(Y)
-        house = self.range_qr == "house" and int(np.max(p[doE], initial=0)) <= 64
+        slab_rows = 1024 if self.dtype == nat.TMF_C128 else 2048        # row limit of the slab kernel (registers)
+        house_ok = self.range_qr == "house" and int(np.max(p[doE], initial=0)) <= 64
+        house = house_ok and int(np.max(m[doE], initial=0)) <= slab_rows    # the longer slabs: F^H Q is m x p
 
         def _rqr(ptr, rows_):
             """Orthonormal factor of every slab; returns the addresses it lives at afterwards."""
-            if house:      # Q stays in the buffer the kernel builds it in (no copy back over the slab)
+            if house_ok and int(np.max(rows_[doE], initial=0)) <= slab_rows:
+                # Q stays in the buffer the kernel builds it in (no copy back over the slab)
                 ptr = np.array(ptr, np.int64)
                 ptr[doE] = self.house_slab(ptr[doE], rows_[doE], rows_[doE], p[doE], inplace=False)
             else:

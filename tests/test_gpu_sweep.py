@@ -542,3 +542,22 @@ def test_singular_always_block_raises_like_the_reference():
         for blk in s.blocks:
             assert np.all(np.isfinite(blk[5]))
     assert all(abs((b.lam**2).sum() - 1) < 1e-12 for b in mps.bonds)
+
+
+def test_chain_longer_than_the_slab_kernel_limit():
+    """L = 1100 complex: the m x 64 slabs of the second range-finder QR exceed the 1024 rows the Householder slab
+    kernel keeps in registers, so that QR falls back to the Gram-Schmidt path while the first one (n <= 550) stays
+    on the slab kernel; entropies against the oracle on sampled cuts."""
+    from tests_inputs import random_hopping
+    from temfpy_amd import slater
+
+    L, chi = 1100, 64
+    C, _ = slater.correlation_matrix(random_hopping(L, 4))
+    mps = slater.C_to_MPS(C, {"chi_max": chi}, as_tenpy=False)
+    S = mps.entanglement_entropy(all_bonds=True)
+    trunc = orc.as_trunc({"chi_max": chi})
+    for x in (3, 400, 550, 1097):
+        cut = orc.cut_vectors(C, x, trunc, "LR" if x == L // 2 else ("L" if x < L // 2 else "R"))
+        p = cut.lam**2
+        assert abs(S[x] + (p[p > 0] * np.log(p[p > 0])).sum()) < 1e-10
+        assert mps.bonds[x].chi == len(cut.lam)
