@@ -619,6 +619,30 @@ class _Projector:
                   for k, v in tabs_h.items()}
         keep_alive.append(tabs_d)
         qr_max = [(int(tabs_h["qr"][o: o + n]["m"].max()), int(tabs_h["qr"][o: o + n]["n"].max())) for o, n in QR.spans]
+        # The same factorisations through the on-chip slab kernel (panel columns in registers, reflector blocks in
+        # LDS: 2x faster than the L2-resident kernel at 280 x 140) whenever the rows fit its registers; Q is built
+        # in a scratch (one per sweep direction) and copied over the block.
+        slab_rows = 1024 if self.cplx else 2048
+        use_slab = os.environ.get("TMF_GW_QR", "slab") == "slab" and max(q[0] for q in qr_max) <= slab_rows
+        if use_slab:
+            qt = tabs_h["qr"]
+            sl = np.zeros(len(qt), nat.slab_desc)
+            sl["A"], sl["R"], sl["n"], sl["c"], sl["lda"], sl["ldr"] = qt["A"], qt["R"], qt["m"], qt["n"], qt["lda"], qt["ldr"]
+            sl["flags"] = (qt["flags"] & 1) | np.where(qt["flags"] & 2, 4, 0)
+            sl["ldq"] = qt["m"]
+            sizes = (qt["m"].astype(np.int64) * qt["n"] + 1) & ~1
+            need, rel = 0, np.zeros(len(qt), np.int64)
+            for o, n in QR.spans:
+                c_ = np.concatenate(([0], np.cumsum(sizes[o: o + n])))
+                rel[o: o + n] = c_[:-1]
+                need = max(need, int(c_[-1]))
+            scratch = [torch.empty(need + 2, dtype=d_ar.dtype, device=self.device) for _ in range(2)]
+            keep_alive.append(scratch)
+            first2 = min([x[2] for x in steps2] + ([tail[3]] if tail is not None else []), default=len(QR.spans))
+            for i, (o, n) in enumerate(QR.spans):      # launches of the rightward sweep come first in the table
+                sl["Q"][o: o + n] = scratch[0 if i < first2 else 1].data_ptr() + el * rel[o: o + n]
+            t_sl = torch.from_numpy(sl.view(np.uint8).reshape(-1).copy()).to(self.device)
+            keep_alive.append(t_sl)
         cp_max = [int((_cdiv(tabs_h["cp"][o: o + n]["rows"].astype(np.int64), 32)
                        * _cdiv(tabs_h["cp"][o: o + n]["cols"].astype(np.int64), 32)).max()) for o, n in CP.spans]
         self.timings["descriptors"] = time.perf_counter() - t1
@@ -635,6 +659,10 @@ class _Projector:
 
         def qr(i, st_):
             o, n = QR.spans[i]
+            if use_slab:
+                nat.check(lib.tmf_house_slab_batched(self.dt, t_sl.data_ptr() + 48 * o, n, qr_max[i][0], qr_max[i][1], st_),
+                          "tmf_house_slab_batched")
+                return
             nat.check(lib.tmf_house_qr_batched(self.dt, tabs_d["qr"].data_ptr() + 40 * o, n, qr_max[i][0], qr_max[i][1],
                                                st_), "tmf_house_qr_batched")
 
