@@ -267,3 +267,27 @@ def test_config5_full_size_properties():
         assert np.abs(a[:n] - r[:n]).max() < 1e-11 and abs(len(a) - len(r)) <= (a < 1e-11).sum() + (r < 1e-11).sum()
     S = seq.entanglement_entropy()
     assert abs(S[255] - S[255 - 2]) < 0.5 and 0.5 < S[255] < 2.0          # log-law plateau of the projected chain
+
+
+def test_chi512_sample_against_oracle():
+    """Config-5 bond dimension (chi_max = 512, 140-state charge sectors, the slab QR + preconditioned Jacobi
+    path at full block size) on a 64-spin chain against the charge-block oracle: Schmidt values 1e-12."""
+    from temfpy_amd import gutzwiller, slater
+
+    C, _ = slater.correlation_matrix(uniform_chain(64))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mps = slater.C_to_MPS(C, {"chi_max": 512}, spinful="PH", as_tenpy=False)
+    res = gutzwiller.abrikosov_ph(mps)
+    T, q, lam, oc = oracle_inputs(mps)
+    M, keep = gw.group_and_project(T, q, lam, oc, "ph")
+    B, S, Q, nrm = gw.canonical_form_finite_blocks(M, gw.spin_charges(q, keep))
+    assert abs(res.norm / nrm - 1) < 1e-10
+    for b, (a, r) in enumerate(zip(res.lam, S)):
+        a, r = np.sort(a)[::-1], np.sort(r)[::-1]
+        n = min(len(a), len(r))
+        assert np.abs(a[:n] - r[:n]).max() < TOL_S, b
+        assert abs(len(a) - len(r)) <= (a < 1e-11).sum() + (r < 1e-11).sum()
+    for b in (1, 16, 32, 63):      # 2 S^z labels of the kept Schmidt indices: same multiset per charge
+        for c in np.unique(Q[b]):
+            assert abs((res.charges[b] == c).sum() - (Q[b] == c).sum()) <= 2
