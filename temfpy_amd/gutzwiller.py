@@ -142,6 +142,9 @@ def _sector_table(q):
 def _fermions_from_slater(mps):
     """Adapter for ``MPSData`` (Slater path, conserve = 'N'): the row-major (merged (p, bra) rows x ket) blocks
     of ``SiteData`` read as column-major matrices without copying."""
+    if len(mps.sites) != mps.L or any(s_ is None for s_ in mps.sites):
+        raise ValueError("the MPS carries no (or only a shard of the) site tensors: convert the whole chain with "
+                         "download=True (the default of slater.C_to_MPS)")
     f = _Fermions()
     f.L, f.oc, f.conserve, f.perm = mps.L, mps.ortho_center, "N", None
     f.charges = [np.asarray(b.q_left, np.int64) for b in mps.bonds]
