@@ -242,6 +242,17 @@ typedef struct {
 } tmf_pf_matrix_desc;        /* 32 bytes */
 int tmf_pf_matrix_batched(const tmf_pf_matrix_desc* d_desc, int nprob, void* stream);
 
+/* ---- result path: page-locked host memory ----------------------------------------- */
+/* The reference's tensors are NumPy arrays in host memory (slater.py:1137-1141 fills them in
+ * place); here they leave the GPU by asynchronous copies into page-locked memory.
+ * tmf_host_register page-locks a caller-owned range (e.g. a POSIX shared-memory segment that
+ * the rank assembling the MPS maps too: every GPU of a node then writes its site shard through
+ * its own PCIe link, no collective - slater.py:1301-1346, independent sites).
+ * tmf_memcpy_async: to_host = 1 device -> host, 0 host -> device; only enqueues.          */
+int tmf_host_register(void* ptr, int64_t bytes);
+int tmf_host_unregister(void* ptr);
+int tmf_memcpy_async(void* dst, const void* src, int64_t bytes, int to_host, void* stream);
+
 /* ---- small device utilities ------------------------------------------------------ */
 /* out (n x n col-major) = transpose of the row-major host layout already on device   */
 int tmf_transpose(int dtype, const void* d_in, void* d_out, int n, void* stream);

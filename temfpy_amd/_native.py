@@ -87,6 +87,7 @@ SYMBOLS = [
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_column_norms_batched", "tmf_cut_vectors",
     "tmf_site_prepare", "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_det_tiles_build", "tmf_pf_gather_batched",
     "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched", "tmf_copy_blocks_batched", "tmf_house_qr_batched", "tmf_jacobi_compact_batched", "tmf_house_slab_batched",
+    "tmf_host_register", "tmf_host_unregister", "tmf_memcpy_async",
 ]
 
 
@@ -143,6 +144,9 @@ def load():
     lib.tmf_site_prepare.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i64, vp]
     lib.tmf_cut_vectors_batch.argtypes = [i32, vp, vp, vp, vp, i64, f64, f64, vp, i32, i64, vp, vp, vp, vp, vp, i32]
     lib.tmf_site_prepare_batch.argtypes = [i32, vp, vp, vp, vp, i64] + [vp] * 9 + [i32]
+    lib.tmf_host_register.argtypes = [vp, i64]
+    lib.tmf_host_unregister.argtypes = [vp]
+    lib.tmf_memcpy_async.argtypes = [vp, vp, i64, i32, vp]
     _LIB = lib
     return lib
 

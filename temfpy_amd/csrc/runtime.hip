@@ -268,3 +268,25 @@ extern "C" int tmf_copy_blocks_batched(int dtype, const tmf_copy_desc* d_desc, i
   }
   return check_hip(hipGetLastError(), "tmf_copy_blocks_batched");
 }
+
+// ---- host <-> device plumbing of the result path ---------------------------------------
+// The tensors of a conversion leave the GPU through page-locked host memory: either memory
+// the caller registered (a POSIX shared-memory segment that rank 0 maps as well, so that
+// every GPU of a node writes its shard through its own PCIe link into one host-visible
+// result) or ordinary pinned allocations.
+extern "C" int tmf_host_register(void* ptr, int64_t bytes) {
+  if (ptr == nullptr || bytes <= 0) {
+    set_error("tmf_host_register: empty range");
+    return TMF_E_ARG;
+  }
+  return check_hip(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterPortable), "hipHostRegister");
+}
+
+extern "C" int tmf_host_unregister(void* ptr) { return check_hip(hipHostUnregister(ptr), "hipHostUnregister"); }
+
+extern "C" int tmf_memcpy_async(void* dst, const void* src, int64_t bytes, int to_host, void* stream) {
+  if (bytes <= 0) return TMF_OK;
+  return check_hip(hipMemcpyAsync(dst, src, (size_t)bytes, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice,
+                                  static_cast<hipStream_t>(stream)),
+                   "hipMemcpyAsync");
+}

@@ -41,7 +41,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from . import _native as nat
-from .mps_data import BondData, LazyList, MPSData, SiteData
+from .mps_data import MPSData, ShardArrays
 
 logger = logging.getLogger("temfpy_amd.slater")
 
@@ -65,6 +65,29 @@ class _GpuWait:
 
     def block(self):
         self.ev.synchronize()
+
+
+class _EventWait:
+    def __init__(self, ev):
+        self.ev = ev
+
+    def ready(self):
+        return self.ev.query()
+
+    def block(self):
+        self.ev.synchronize()
+
+
+class PinnedSink:
+    """Host memory of a result: page-locked blocks from torch's caching host allocator (the block of a
+    released result is reused by the next conversion; a pageable destination ran at ~6 GB/s)."""
+
+    def __init__(self, torch):
+        self.torch = torch
+
+    def alloc(self, nbytes):
+        t = self.torch.empty(int(nbytes), dtype=self.torch.uint8, pin_memory=True)
+        return t.numpy(), t
 
 
 class _ThreadWait:
@@ -143,6 +166,11 @@ class Engine:
         self.force_direct_det = bool(int(os.environ.get("TMF_DIRECT_DET", "0")))  # A/B switch
         self.time_gemm = False   # bench.py: HIP events around every MFMA GEMM launch
         self.gemm_events = []
+        self._inflight = []      # (event, references) of downloads still running on the copy stream
+        self._copy_stream = torch.cuda.Stream(device=self.device)   # device -> host: the tensors of a result
+        self._up_stream = torch.cuda.Stream(device=self.device)     # host -> device: index lists
+        self._sink = None
+        self.coord = None        # multi-rank runs: object with .max(np.ndarray) -> elementwise max over the ranks
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -545,6 +573,18 @@ class Engine:
             out.fill(0)
         return out
 
+    def default_sink(self):
+        if self._sink is None:
+            self._sink = PinnedSink(self.torch)
+        return self._sink
+
+    def _gmax(self, values):
+        """Elementwise maximum over all ranks of a sharded conversion (identity on one rank): decisions that
+        change the orbitals of a cut - range-finder width, subspace iteration - must be the same on both
+        ranks that hold a shard-boundary cut, or their copies of it differ by a gauge."""
+        v = np.asarray(values, np.float64)
+        return v if self.coord is None else self.coord.max(v)
+
     def _finish(self, mps):
         mps.info = {"range_finder_iterations": self.range_iterations_used, "range_finder_columns": self.range_width,
                     "range_finder_smallest_sigma": self.range_floor,
@@ -587,6 +627,9 @@ class Engine:
             yield w_
             h_sig, h_cnt, h_e, oS = h_sig.copy(), h_cnt.copy(), h_e.copy(), st["oS"]
             worst = max((h_sig[oS[i] + P - 1] for i in np.nonzero(full)[0]), default=0.0)
+            sat = np.nonzero(full & (h_cnt >= p))[0]
+            # the decisions below are taken on the maximum over ALL ranks of a sharded conversion (_gmax)
+            worst, any_sat = self._gmax([worst, float(sat.size > 0)])
             self.range_floor = float(worst)
             its = 0
             if worst > self.range_floor_tol:
@@ -596,13 +639,17 @@ class Engine:
                 yield w_
                 h_sig, h_cnt, h_e, oS = h_sig.copy(), h_cnt.copy(), h_e.copy(), st["oS"]
                 bad = [i for i in np.nonzero(full)[0] if h_sig[oS[i] + P - 1] > 4.6e-4 * thr2**0.5]
+                sat = np.nonzero(full & (h_cnt >= p))[0]
                 if bad:   # (s_P / sqrt(thr2))^3 > 1e-10 even after the iteration
                     reason = (f"cut {cs_b[bad[0]]}: smallest captured singular value "
                               f"{h_sig[oS[bad[0]] + P - 1]:.1e} vs threshold {thr2 ** 0.5:.1e} with {P} columns")
+                any_bad, any_sat = self._gmax([float(len(bad) > 0), float(sat.size > 0)])
+                if any_bad:
+                    reason = reason or "another rank's cut needs a wider range finder"
                     continue
-            sat = np.nonzero(full & (h_cnt >= p))[0]
-            if sat.size:
-                reason = f"cut {cs_b[sat[0]]}: {P} or more orbitals above the range-finder threshold"
+            if any_sat:
+                reason = (f"cut {cs_b[sat[0]]}: {P} or more orbitals above the range-finder threshold" if sat.size
+                          else "another rank's cut has more orbitals above the threshold than the range finder is wide")
                 continue
             st.update(P=P, p=p, d_Om=d_Om, range_iterations=its, h_e=h_e, h_cnt=h_cnt)
             self.range_iterations_used, self.range_width = its, P
@@ -659,18 +706,24 @@ class Engine:
         return (C + C.conj().T) / 2, steps
 
     # ------------------------------------------------------------------ the sweep
-    def run(self, C, trunc, ortho_center, unit_cell_width, threads=None, download=True, site_range=None):
+    def run(self, C, trunc, ortho_center, unit_cell_width, threads=None, download=True, site_range=None, sink=None):
         """One C -> MPS conversion (blocking form of :meth:`run_gen`)."""
-        return _drive(self.run_gen(C, trunc, ortho_center, unit_cell_width, threads, download, site_range))
+        return _drive(self.run_gen(C, trunc, ortho_center, unit_cell_width, threads, download, site_range, sink=sink))
 
     def run_gen(self, C, trunc, ortho_center, unit_cell_width, threads=None, download=True, site_range=None,
-                diag=None, presynced=False):
+                diag=None, presynced=False, sink=None):
         """One C -> MPS conversion as a generator: yields a wait handle (``ready()`` / ``block()``) at the
         three places where the host has to wait - eigenvalues coming down, the enumeration thread, the
         final results - so that several site ranges can be interleaved (:func:`run_pipelined`).
 
         C            (L, L) NumPy array, or a row-major torch tensor already resident in HBM
-        download     False keeps the tensors in HBM (``self.d_out``) and returns no site blocks
+        download     True: tensors in host memory on return.  "async": the call returns once everything is
+                     enqueued; the tensors land in page-locked host memory while the caller goes on (the next
+                     conversion's kernels overlap the 1.5 GB transfer); ``result.wait()`` - called by the site
+                     objects on first access - blocks until they are there.  False keeps the tensors in HBM
+                     (``self.d_out``) and returns no site blocks
+        sink         where the host copy of the result lives (default: page-locked memory; the multi-GPU path
+                     passes shared-memory segments, multi_gpu.ShmSink)
         site_range   (a, b): only sites a <= i < b and the cuts next to them (one rank's shard)
         """
         torch = self.torch
@@ -681,6 +734,7 @@ class Engine:
         if not presynced:
             torch.cuda.current_stream(self.device).synchronize()  # staging arena of the previous call is free
         self._pin_off = 0
+        self._inflight = [f for f in self._inflight if not f[0].query()]
         if isinstance(C, torch.Tensor):
             d_Crm = C.reshape(-1)
             cplx = d_Crm.is_complex()
@@ -822,29 +876,15 @@ class Engine:
             self.timings["host_enum_native"] = time.perf_counter() - t0 - self.timings["host_enum_setup"]
             if np.any(c_chi == 0):
                 raise ValueError("No Schmidt vectors left after filtering by `trunc_par.sectors`!")  # slater.py:668
-            def make_bonds(L=L):  # bind the chain length now: run() re-uses the name for the shard
-                # private copies of the enumeration outputs (the scratch above is reused by the next sweep);
-                # plain memcpys - a boolean-mask compaction of the kept prefixes cost 5 ms here
-                o_sets, o_lam, o_q, o_chi = c_sets.copy(), c_lam.copy(), c_q.copy(), c_chi.copy()
-                info = logger.isEnabledFor(logging.INFO)
-                def bond(b):
-                    j = int(cpos[b])
-                    if j < 0:
-                        return None          # a cut outside this rank's site range
-                    ch = int(o_chi[j])
-                    lam_raw = o_lam[j, :ch]
-                    return BondData(x=b, e=e_pool[int(e_off[j]): int(e_off[j]) + int(kk_cut[j])], n_filled_left=int(nfl[j]), n_filled_right=int(nfr[j]),
-                                    masks=o_sets[j, :ch], lam_raw=lam_raw,
-                                    lam=lam_raw / np.sqrt(np.dot(lam_raw, lam_raw)), q_left=o_q[j, :ch],
-                                    n_checked=int(c_chk[j]))
-
-                if info:
-                    for j, b in enumerate(my_cuts):
-                        logger.info("bond %d: %d Schmidt modes, checked %d subsets, kept %d, norm %.12g", b,
-                                    kk_cut[j], c_chk[j], int(o_chi[j]),
-                                    float(np.sqrt(np.dot(o_lam[j, :int(o_chi[j])], o_lam[j, :int(o_chi[j])]))))
-                bonds = LazyList(L + 1, bond)
-                return bonds
+            if logger.isEnabledFor(logging.INFO):
+                for j, b in enumerate(my_cuts):
+                    logger.info("bond %d: %d Schmidt modes, checked %d subsets, kept %d, norm %.12g", b,
+                                kk_cut[j], c_chk[j], int(c_chi[j]),
+                                float(np.sqrt(np.dot(c_lam[j, :int(c_chi[j])], c_lam[j, :int(c_chi[j])]))))
+            # enumeration outputs of this rank's cuts (scratch, reused by the next sweep: the result object
+            # gets copies, see the end of run_gen)
+            bond_arrays = dict(my_cuts=my_cuts.astype(np.int64), c_sets=c_sets, c_lam=c_lam, c_q=c_q, c_chi=c_chi, c_chk=c_chk,
+                               e_pool=e_pool, e_off=e_off, kk_cut=kk_cut, nfl=nfl, nfr=nfr)
 
             self.timings["host_enumerate"] = time.perf_counter() - t0
 
@@ -889,7 +929,7 @@ class Engine:
             self.timings["host_site_native"] = time.perf_counter() - t1
             self.timings["host_site_prepare"] = time.perf_counter() - t0
 
-            return dict(make_bonds=make_bonds, jobs=jobs, souts=souts, row_sel=row_sel, row_sign=row_sign, col_sel=col_sel,
+            return dict(bond_arrays=bond_arrays, jobs=jobs, souts=souts, row_sel=row_sel, row_sign=row_sign, col_sel=col_sel,
                         col_sign=col_sign, bra_p=bra_p, bra_alpha=bra_alpha, sec_buf=sec_buf, pool=pool, mode=mode,
                         ib=ib, ik=ik, chi_b=chi_b, chi_k=chi_k, my_sites=my_sites, ns=ns)
 
@@ -1017,16 +1057,14 @@ class Engine:
         # the index pool (19 MB) was written into pinned memory by the site preparation; it goes up on a side
         # stream while the overlap GEMM and the LU run (on the launch stream the copy sat between the LU and
         # the determinant kernel: 1.5 ms of idle SIMDs)
-        if getattr(self, "_copy_stream", None) is None:
-            self._copy_stream = torch.cuda.Stream(device=self.device)
         t_pin = self._hpool["idx_pool/tensor"][: pool.nbytes]
         t_pool = torch.empty(pool.nbytes, dtype=torch.uint8, device=self.device)
         self._keep.append(t_pool)
-        self._copy_stream.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self._copy_stream):
+        self._up_stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._up_stream):
             t_pool.copy_(t_pin, non_blocking=True)
             pool_ready = torch.cuda.Event()
-            pool_ready.record(self._copy_stream)
+            pool_ready.record(self._up_stream)
         pool_upload = (t_pool, pool_ready)
 
         # ---- S1/S2: overlaps and W assembly ---------------------------------------------------
@@ -1163,55 +1201,85 @@ class Engine:
         self.n_det = n_det
         self._tick("S_determinants", t0)
         self.d_out = d_out  # device-resident result
+        self.d_det = d_det
+
+        # ---- result object: ONE host buffer (page-locked; a shared-memory segment on the multi-GPU path) holds the
+        # bookkeeping arrays of the host phase and receives the tensors straight from the GPU ------------------
         t0 = time.perf_counter()
-        bonds = ho["make_bonds"]()
+        cdt = np.complex128 if cplx else np.float64
+        src = dict(ho["bond_arrays"])
+        src.update(mode=mode.astype(np.int32), sec_off=jobs["sec_off"].astype(np.int64), nsec=nsec,
+                   sectors=sec_buf, out_off=out_off.astype(np.int64), bra_off=jobs["bra_off"].astype(np.int64),
+                   chi_b=chi_b.astype(np.int64), chi_k=chi_k.astype(np.int64), bra_p=bra_p, bra_alpha=bra_alpha)
+        spec = {k_: (v_.dtype, v_.shape) for k_, v_ in src.items()}
+        want_out = download is not False
+        spec["det"] = (cdt, (L,))
+        spec["out"] = (cdt, (int(out_tot) if want_out else 0,))
+        entries, total = ShardArrays.plan(spec)
+        buf, keep = (sink or self.default_sink()).alloc(total)
+        shard = ShardArrays.create(buf, entries, dict(L=int(L_all), s_lo=int(s_lo), s_hi=int(s_hi), ortho_center=int(oc),
+                                                      complex=bool(cplx)), keepalive=keep)
+        for k_, v_ in src.items():
+            shard.arrays[k_][...] = v_
         self._tick("host_bonds", t0)
-        yield _GpuWait(torch, self.device)
-        self.check_results = {}
-        if d_chk is not None:
-            self.check_results = dict(zip(chk_names, (float(v) for v in d_chk.cpu().numpy())))
 
-        # ---- host round trip 2: tensors back -----------------------------------------------------
-        if not download:
-            self.timings["total"] = time.perf_counter() - t_all
-            self._keep.clear()
-            return self._finish(MPSData(bonds, [], oc, unit_cell_width, dict(self.timings)))
+        # ---- host round trip 2: tensors back, on the copy stream (the launch stream is free for the next
+        # conversion; the page-locked buffer and the device tensors stay referenced until the copies are done) ----
         t0 = time.perf_counter()
-        # tensors come down through pinned host memory (torch's caching host allocator: the page-locked
-        # block of a released result is reused by the next conversion); a pageable .cpu() ran at ~6 GB/s
-        t_out = torch.empty(d_out.numel(), dtype=d_out.dtype, pin_memory=True)
-        t_out.copy_(d_out, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
-        h_out = t_out.numpy()          # the blocks below are views; they keep the pinned tensor alive
-        h_det = d_det.cpu().numpy()
-        if not np.all(np.isfinite(h_det)) or np.any(h_det == 0):
-            # the overlap of the always-occupied orbitals of two neighbouring cuts is singular: the
-            # reference fails in numpy.linalg.inv at slater.py:1079 / :1086 with the same exception
-            raise np.linalg.LinAlgError("Singular matrix")
-        n_local = L
+        cs = self._copy_stream
+        cs.wait_stream(torch.cuda.current_stream(self.device))
+        d_det.record_stream(cs)
+        nat.check(self.lib.tmf_memcpy_async(shard.arrays["det"].ctypes.data, d_det.data_ptr(), L * el, 1, cs.cuda_stream), "D2H")
+        if want_out:
+            d_out.record_stream(cs)
+            dst, chunk = shard.arrays["out"].ctypes.data, 64 << 20
+            for o_ in range(0, int(out_tot) * el, chunk):   # in pieces: small copies of other streams get a turn
+                nat.check(self.lib.tmf_memcpy_async(dst + o_, d_out.data_ptr() + o_, min(chunk, int(out_tot) * el - o_), 1,
+                                                    cs.cuda_stream), "D2H")
+        check_names, h_chk = chk_names, None
+        if d_chk is not None:
+            d_chk.record_stream(cs)
+            h_chk = torch.empty(len(check_names), dtype=torch.float64, pin_memory=True)
+            with torch.cuda.stream(cs):
+                h_chk.copy_(d_chk[: len(check_names)], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(cs)
+        self._inflight.append((done, keep, d_out, d_det, d_chk, h_chk))
+        state = {"checked": False}
 
-        def site(i):   # built on first access (LazyList): views into the pinned result buffer
-            j = i - s_lo
-            if not 0 <= j < n_local:
-                return None          # a site outside this rank's range
-            m_ = "left" if mode[j] == 0 else "right"
-            blocks = []
-            so_ = int(jobs["sec_off"][j])
-            for sec in sec_buf[so_: so_ + int(nsec[j])]:
-                r0, r1, c0, c1 = (int(sec[f]) for f in ("r0", "r1", "c0", "c1"))
-                o = out_off[j] + int(sec["out_off"])
-                blocks.append((int(sec["q"]), r0, r1, c0, c1, h_out[o: o + (r1 - r0) * (c1 - c0)].reshape(r1 - r0, c1 - c0)))
-            bo = int(jobs["bra_off"][j])
-            return SiteData(mode=m_, det_always=h_det[j], qtotal=0, bra_p=bra_p[bo: bo + 2 * int(chi_b[j])],
-                            bra_alpha=bra_alpha[bo: bo + 2 * int(chi_b[j])], blocks=blocks,
-                            chi_bra=int(chi_b[j]), chi_ket=int(chi_k[j]))
+        def wait():
+            if state["checked"]:
+                return
+            done.synchronize()
+            state["checked"] = True
+            shard.wait = None
+            shard.check_det()
 
-        sites = LazyList(L_all, site)
-        self._tick("download", t0)
+        shard.wait = wait
         self.timings["total"] = time.perf_counter() - t_all
         self._keep.clear()
-        res = MPSData(bonds, sites, oc, unit_cell_width, dict(self.timings))
-        res._flat_t = t_out     # the pinned buffer all blocks are views of (gutzwiller: re-upload in one copy)
+        res = MPSData.from_shards([shard], oc, unit_cell_width, dict(self.timings), with_sites=want_out)
+        if want_out and isinstance(keep, torch.Tensor):
+            # the page-locked array all blocks are views of, as a tensor (gutzwiller: re-upload in one copy)
+            o_ = entries["out"][2]
+            res._flat_t = keep[o_: o_ + int(out_tot) * el].view(torch.complex128 if cplx else torch.float64)
+        if download == "async":
+            # the caller overlaps the download with its next conversion and calls res.wait() (the site objects do);
+            # the reconstruction deviations of the centre cut are read then as well
+            self.check_results = {}
+            if d_chk is not None:
+                def lazy_checks():
+                    done.synchronize()
+                    return dict(zip(check_names, (float(v) for v in h_chk.numpy())))
+                res._lazy_checks = lazy_checks
+            return self._finish(res)
+        yield _EventWait(done)
+        self.check_results = {}
+        if d_chk is not None:
+            self.check_results = dict(zip(check_names, (float(v) for v in h_chk.numpy())))
+        wait()
+        self._tick("download", t0)
+        res.timings = dict(self.timings, total=time.perf_counter() - t_all)
         return self._finish(res)
 
 

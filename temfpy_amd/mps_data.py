@@ -95,6 +95,123 @@ class LazyList:
         return (self[i] for i in range(self._n))
 
 
+_ALIGN = 4096
+
+
+class ShardArrays:
+    """Flat result of one conversion, or of one rank's site range of it: what the sweep leaves in host
+    memory.  ``arrays`` maps names to NumPy arrays, ``meta`` holds scalars.  The tensors are ONE flat
+    array (``out``: the charge blocks of all sites back to back, row-major per block), which is what the
+    GPU writes through page-locked memory; everything else is integer bookkeeping of the host phase.
+
+    bonds   my_cuts (ncut), c_sets (ncut, cap, 2) u64, c_lam / c_q (ncut, cap), c_chi, c_chk,
+            e_pool + e_off + kk_cut (entangled eigenvalues), nfl / nfr (filled orbitals left / right)
+    sites   mode, sec_off, nsec, sectors (tmf_sector records), out_off, bra_off, chi_b, chi_k, bra_p,
+            bra_alpha, det (det_always per site), out
+    meta    L, s_lo, s_hi, ortho_center
+
+    ``pack`` / ``unpack`` move the whole object through one byte buffer (a shared-memory segment of the
+    multi-GPU path): [u64 header length][JSON header][arrays at 4096-byte aligned offsets]."""
+
+    def __init__(self, arrays, meta, keepalive=None):
+        self.arrays, self.meta, self.keepalive = arrays, meta, keepalive
+        self._cpos = None
+        self.wait = None      # callable that blocks until ``out`` / ``det`` have landed (asynchronous download)
+
+    # ---- serialisation ---------------------------------------------------------------------------
+    HEADER_ROOM = 16384
+
+    @staticmethod
+    def plan(spec):
+        """spec: {name: (dtype, shape)} -> ({name: [dtype descr, shape, byte offset]}, total bytes)."""
+        entries, off = {}, ShardArrays.HEADER_ROOM
+        for name, (dt, shape) in spec.items():
+            dt = np.dtype(dt)
+            off = (off + _ALIGN - 1) & ~(_ALIGN - 1)
+            entries[name] = [dt.descr if dt.fields else dt.str, [int(x) for x in shape], off]
+            off += int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+        return entries, (off + _ALIGN - 1) & ~(_ALIGN - 1)
+
+    @staticmethod
+    def _views(buf, entries):
+        arrays = {}
+        for name, (dt, shape, off) in entries.items():
+            dt = np.dtype([tuple(f) for f in dt]) if isinstance(dt, list) else np.dtype(dt)
+            arrays[name] = np.frombuffer(buf, dt, int(np.prod(shape, dtype=np.int64)), off).reshape(shape)
+        return arrays
+
+    @classmethod
+    def create(cls, buf, entries, meta, keepalive=None):
+        """Header into ``buf`` (uint8 array of at least ``plan``'s size); the arrays are uninitialised views."""
+        import json
+        hdr = json.dumps({"meta": meta, "arrays": entries}).encode()
+        assert len(hdr) + 8 <= cls.HEADER_ROOM - 16, "header of the packed shard result too long"
+        buf[:8] = np.frombuffer(np.uint64(len(hdr)).tobytes(), np.uint8)
+        buf[8: 8 + len(hdr)] = np.frombuffer(hdr, np.uint8)
+        return cls(cls._views(buf, entries), dict(meta), keepalive)
+
+    @classmethod
+    def unpack(cls, buf, keepalive=None):
+        """Zero-copy views into a buffer written by ``create`` (kept alive through ``keepalive``)."""
+        import json
+        n = int(np.frombuffer(bytes(buf[:8]), np.uint64)[0])
+        hdr = json.loads(bytes(buf[8: 8 + n]).decode())
+        return cls(cls._views(buf, hdr["arrays"]), hdr["meta"], keepalive)
+
+    # ---- object construction ---------------------------------------------------------------------
+    @property
+    def cpos(self):
+        if self._cpos is None:
+            c = np.full(int(self.meta["L"]) + 1, -1, np.int64)
+            c[self.arrays["my_cuts"]] = np.arange(len(self.arrays["my_cuts"]))
+            self._cpos = c
+        return self._cpos
+
+    def has_bond(self, b):
+        return self.cpos[b] >= 0
+
+    def has_site(self, i):
+        return self.meta["s_lo"] <= i < self.meta["s_hi"]
+
+    def bond(self, b):
+        A = self.arrays
+        j = int(self.cpos[b])
+        if j < 0:
+            return None
+        ch = int(A["c_chi"][j])
+        lam_raw = A["c_lam"][j, :ch]
+        o, kk = int(A["e_off"][j]), int(A["kk_cut"][j])
+        return BondData(x=b, e=A["e_pool"][o: o + kk], n_filled_left=int(A["nfl"][j]), n_filled_right=int(A["nfr"][j]),
+                        masks=A["c_sets"][j, :ch], lam_raw=lam_raw, lam=lam_raw / np.sqrt(np.dot(lam_raw, lam_raw)),
+                        q_left=A["c_q"][j, :ch], n_checked=int(A["c_chk"][j]))
+
+    def site(self, i):
+        if not self.has_site(i):
+            return None
+        if self.wait is not None:
+            self.wait()
+        A = self.arrays
+        j = i - int(self.meta["s_lo"])
+        h_out = A["out"]
+        so_, oo = int(A["sec_off"][j]), int(A["out_off"][j])
+        blocks = []
+        for sec in A["sectors"][so_: so_ + int(A["nsec"][j])]:
+            r0, r1, c0, c1 = (int(sec[f]) for f in ("r0", "r1", "c0", "c1"))
+            o = oo + int(sec["out_off"])
+            blocks.append((int(sec["q"]), r0, r1, c0, c1, h_out[o: o + (r1 - r0) * (c1 - c0)].reshape(r1 - r0, c1 - c0)))
+        bo, cb = int(A["bra_off"][j]), int(A["chi_b"][j])
+        return SiteData(mode="left" if A["mode"][j] == 0 else "right", det_always=A["det"][j], qtotal=0,
+                        bra_p=A["bra_p"][bo: bo + 2 * cb], bra_alpha=A["bra_alpha"][bo: bo + 2 * cb], blocks=blocks,
+                        chi_bra=cb, chi_ket=int(A["chi_k"][j]))
+
+    def check_det(self):
+        """The overlap of the always-occupied orbitals of two neighbouring cuts is singular: the reference
+        fails in numpy.linalg.inv at slater.py:1079 / :1086 with the same exception."""
+        d = self.arrays["det"]
+        if not np.all(np.isfinite(d)) or np.any(d == 0):
+            raise np.linalg.LinAlgError("Singular matrix")
+
+
 class MPSData:
     """Finite MPS in mixed canonical form A..A [lam] B..B with U(1) charge blocks."""
 
@@ -106,6 +223,37 @@ class MPSData:
         self.unit_cell_width = unit_cell_width
         self.form = ["A"] * ortho_center + ["B"] * (self.L - ortho_center)  # slater.py:1348
         self.timings = timings or {}
+        self.shards = []
+
+    @classmethod
+    def from_shards(cls, shards, ortho_center, unit_cell_width, timings=None, with_sites=True):
+        """One MPS from the flat results of one or several site ranges (ranks): a bond / site object is
+        built on first access from the arrays of the shard that owns it (a cut on a shard boundary is
+        held, bit-identically, by both neighbours; the lower rank's copy is used)."""
+        L = int(shards[0].meta["L"])
+
+        def bond(b):
+            for s in shards:
+                if s.has_bond(b):
+                    return s.bond(b)
+            return None
+
+        def site(i):
+            for s in shards:
+                if s.has_site(i):
+                    return s.site(i)
+            return None
+
+        res = cls(LazyList(L + 1, bond), LazyList(L, site) if with_sites else [], ortho_center, unit_cell_width, timings)
+        res.shards = list(shards)
+        return res
+
+    def wait(self):
+        """Blocks until the tensors of an asynchronous download have landed in host memory."""
+        for s in self.shards:
+            if s.wait is not None:
+                s.wait()
+        return self
 
     @property
     def lam(self):
@@ -127,17 +275,23 @@ class MPSData:
     def dense_tensors(self):
         return [s.dense() for s in self.sites]
 
-    def to_tenpy(self):
+    def to_tenpy(self, verify=True):
         """Assemble ``tenpy.networks.mps.MPS`` exactly like slater.py:1106-1143,1348-1351.
 
-        Needs physics-tenpy; it is not installed in the build environment, so this
-        assembly is untested there ('parity unpinned: LegPipe order')."""
+        Needs physics-tenpy, which is not installed in the build environment: the row order of TeNPy's
+        ``LegPipe`` (slater.py:1118) could not be pinned there.  The assembly therefore CHECKS ITSELF at run time
+        (``verify``): every assembled tensor (a sample of 16 sites on long chains) is read back through
+        ``to_ndarray()`` and compared element by element with this object's own dense tensor; a mismatch raises
+        instead of handing a permuted tensor to TeNPy.  ``slater.C_to_MPS(..., as_tenpy=False)`` skips TeNPy."""
         import tenpy.linalg.np_conserved as npc  # noqa: F401  (ImportError is the caller's signal)
         from tenpy import networks
 
+        self.wait()
         site = networks.site.FermionSite()
         leg_p = site.leg
         chinfo = leg_p.chinfo
+        dtype = next((s.blocks[0][5].dtype for s in self.sites if s.blocks), np.dtype(float))
+        check = set(range(self.L)) if self.L <= 64 else set(np.linspace(0, self.L - 1, 16).astype(int).tolist())
         tensors = []
         for i, s in enumerate(self.sites):
             left = s.mode == "left"
@@ -147,11 +301,19 @@ class MPSData:
             leg_bra = npc.LegCharge.from_qdict(chinfo, bra.idx_L, qconj=qconj[0])
             leg_ket = npc.LegCharge.from_qdict(chinfo, ket.idx_L, qconj=qconj[1])
             pipe = npc.LegPipe([leg_p, leg_bra], qconj=leg_bra.qconj)
-            B = npc.zeros([pipe, leg_ket], labels=[f"(p.{names[0]})", names[1]], dtype=s.blocks[0][5].dtype,
-                          qtotal=(s.qtotal,))
+            B = npc.zeros([pipe, leg_ket], labels=[f"(p.{names[0]})", names[1]], dtype=dtype, qtotal=(s.qtotal,))
             qd = pipe.to_qdict()
             for q, r0, r1, c0, c1, blk in s.blocks:
                 B[qd[(q + s.qtotal * qconj[0],)], slice(c0, c1)] = blk
-            tensors.append(B.split_legs())
+            B = B.split_legs()
+            if verify and i in check:
+                got = B.to_ndarray()                                   # (p, bra, ket)
+                want = s.dense() if left else s.dense().transpose(0, 2, 1)
+                if got.shape != want.shape or not np.array_equal(got, want):
+                    raise RuntimeError(
+                        f"TeNPy assembly self-check failed at site {i}: the tensor read back from np_conserved differs "
+                        "from the converter's own (LegPipe row order other than slater.py:943-952 documents?). "
+                        "Use slater.C_to_MPS(..., as_tenpy=False) for the backend-neutral MPSData.")
+            tensors.append(B)
         return networks.mps.MPS([site] * self.L, tensors, self.lam, form=self.form,
                                 unit_cell_width=self.unit_cell_width)

@@ -1,0 +1,537 @@
+"""One conversion over the GPUs of one node: contiguous site ranges, one process per GPU.
+
+Sites are independent given C (the loops of slater.py:1301-1321 and :1326-1346 touch site i through the
+cuts i and i+1 only), so rank r converts sites [a_r, b_r) and recomputes the cut on each of its range
+boundaries; the kernels are deterministic and the few data-dependent decisions of the entangled stage are
+taken on the maximum over all ranks (``Engine._gmax``), so both neighbours hold bit-identical copies of a
+boundary cut.  Data path:
+
+  C        rank 0 uploads it and RCCL-broadcasts the 16 MiB over xGMI (the only collective on the data path)
+  tensors  every rank copies its shard through its own PCIe link into a page-locked POSIX shared-memory
+           segment (``ShmSink``); the assembling process maps the segments of all ranks and builds ONE
+           ``MPSData`` whose bond / site objects are views into them - no gather collective, no copy
+  control  a gloo group next to the RCCL one carries the elementwise-max decisions and the (generation,
+           size, busy time) triple of each rank's segment
+
+Two ways in:
+
+  * ranks started by a launcher (``torch.distributed.run`` or ``bench.py --gpus N``): ``ShardGroup`` on every
+    rank, ``group.convert(C, ...)`` returns the assembled ``MPSData`` on rank 0;
+  * ``slater.C_to_MPS(..., devices=[...])``: a ``DevicePool`` of worker processes, one per device, started
+    before the calling process touches a GPU; the caller hands C over in shared memory and assembles the
+    result itself.
+
+``TMF_DRY_ENGINE=1`` replaces the GPU engine by a deterministic stand-in (``DryEngine``) so that the process
+plumbing - spawn, rendezvous, segments, leases, assembly - is testable on a machine without a GPU.
+"""
+from __future__ import annotations
+
+import atexit
+import mmap
+import os
+import pickle
+import socket
+import subprocess
+import sys
+import time
+import weakref
+
+import numpy as np
+
+from .mps_data import MPSData, ShardArrays
+
+_LEASE_OFF = ShardArrays.HEADER_ROOM - 16      # uint64 inside the header room: 1 while a reader holds views
+
+
+def shard_sites(L, oc, world):
+    """Contiguous site ranges with balanced cost  w(i) = 1 + 3 (n_i / (L/2))^3
+    (determinant stage ~ constant in the chi-saturated bulk, eigen / overlap stages ~ n^3)."""
+    i = np.arange(L)
+    n = np.where(i < oc, i + 1, L - i)
+    w = 1.0 + 3.0 * (n / max(L / 2, 1)) ** 3
+    c = np.concatenate(([0.0], np.cumsum(w)))
+    bounds = [int(np.searchsorted(c, c[-1] * r / world)) for r in range(world + 1)]
+    if world > L:
+        raise ValueError(f"{world} ranks for {L} sites: every rank needs at least one site")
+    bounds[0], bounds[-1] = 0, L
+    for r in range(1, world):          # strictly increasing: no empty range
+        bounds[r] = min(max(bounds[r], bounds[r - 1] + 1), L - (world - r))
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+# ------------------------------------------------------------------------------------------------ shared memory
+class Segment:
+    """A POSIX shared-memory file mapped into this process (plain ``/dev/shm`` + ``mmap``: Python's
+    ``multiprocessing.shared_memory`` hands attached segments to a resource tracker that unlinks them when the
+    attaching process exits)."""
+
+    def __init__(self, name, size=None, create=False):
+        self.name, self.path, self.owner = name, "/dev/shm/" + name, create
+        fd = os.open(self.path, os.O_RDWR | (os.O_CREAT | os.O_EXCL if create else 0), 0o600)
+        try:
+            if create:
+                os.ftruncate(fd, size)
+            self.size = os.fstat(fd).st_size
+            self.map = mmap.mmap(fd, self.size)
+        finally:
+            os.close(fd)
+        self.buf = np.frombuffer(self.map, np.uint8)
+        self.registered = False
+
+    @property
+    def lease(self):
+        return int(self.buf[_LEASE_OFF: _LEASE_OFF + 8].view(np.uint64)[0])
+
+    @lease.setter
+    def lease(self, v):
+        self.buf[_LEASE_OFF: _LEASE_OFF + 8].view(np.uint64)[0] = v
+
+    def unlink(self):
+        if self.owner:
+            try:
+                os.unlink(self.path)
+            except FileNotFoundError:
+                pass
+            self.owner = False
+
+
+class ShmSink:
+    """Host memory of a rank's results: shared-memory segments ``<tag>_r<rank>_g<generation>``, page-locked for
+    the GPU (``tmf_host_register``) so that the tensors arrive by asynchronous DMA.  A segment is reused as soon
+    as the reader has dropped the result built on it (lease word back to 0); otherwise a new generation is
+    created, so results handed out earlier stay valid."""
+
+    def __init__(self, tag, rank, lib=None):
+        self.tag, self.rank, self.lib = tag, rank, lib
+        self.segments = []           # generation -> Segment
+        self.last = None
+        atexit.register(self.close)
+
+    def alloc(self, nbytes):
+        seg = None
+        for s in self.segments:
+            if s.size >= nbytes and s.lease == 0:
+                seg = s
+                break
+        if seg is None:
+            size = (int(nbytes * 1.25) + (1 << 21)) & ~((1 << 21) - 1)
+            seg = Segment(f"{self.tag}_r{self.rank}_g{len(self.segments)}", size, create=True)
+            seg.gen = len(self.segments)
+            seg.buf[: ShardArrays.HEADER_ROOM] = 0
+            if self.lib is not None:
+                from . import _native as nat
+                nat.check(self.lib.tmf_host_register(seg.buf.ctypes.data, seg.size), "tmf_host_register")
+                seg.registered = True
+            self.segments.append(seg)
+        self.last = seg
+        return seg.buf, seg
+
+    def close(self):
+        for s in self.segments:
+            if s.registered and self.lib is not None:
+                self.lib.tmf_host_unregister(s.buf.ctypes.data)
+                s.registered = False
+            s.unlink()
+
+
+class _Reader:
+    """Maps the segments of all ranks in the assembling process (attachments are cached by name)."""
+
+    def __init__(self, tag):
+        self.tag, self.cache = tag, {}
+
+    def shard(self, rank, gen):
+        name = f"{self.tag}_r{rank}_g{gen}"
+        seg = self.cache.get(name)
+        if seg is None:
+            seg = self.cache[name] = Segment(name)
+        return ShardArrays.unpack(seg.buf, keepalive=seg), seg
+
+
+def assemble(reader, infos, ortho_center, unit_cell_width, timings=None):
+    """``MPSData`` over the segments announced by the ranks: infos[r] = (generation, ...).  The segments stay
+    leased until the returned object is garbage-collected."""
+    shards, segs = [], []
+    for r, info in enumerate(infos):
+        sh, seg = reader.shard(r, int(info[0]))
+        shards.append(sh), segs.append(seg)
+    shards = [s for s in shards if s.meta["s_hi"] > s.meta["s_lo"] or len(s.arrays["my_cuts"])]
+    mps = MPSData.from_shards(shards, ortho_center, unit_cell_width, timings)
+    weakref.finalize(mps, _release, segs)
+    return mps
+
+
+def _release(segs):
+    for s in segs:
+        try:
+            s.lease = 0
+        except (ValueError, BufferError):    # interpreter shutdown: mapping already gone
+            pass
+
+
+# ------------------------------------------------------------------------------------------------ rank side
+class GlooMax:
+    def __init__(self, dist, torch, group):
+        self.dist, self.torch, self.group = dist, torch, group
+
+    def max(self, v):
+        t = self.torch.from_numpy(np.array(v, np.float64))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return t.numpy()
+
+
+class DryEngine:
+    """Stand-in for ``engine.Engine`` without a GPU (``TMF_DRY_ENGINE=1``): fabricates the flat result of a site
+    range deterministically from (L, site, bond) so that tests can follow every value through shared memory and
+    the assembly, and exercises the cross-rank decision hook.  Never used by the product path."""
+
+    def __init__(self, device=None):
+        self.coord, self.timings, self.check_results = None, {}, {}
+        self.range_iterations_used, self.range_width, self.range_floor = 0, 64, 0.0
+
+    def run(self, C, trunc, ortho_center, unit_cell_width, threads=None, download=True, site_range=None, sink=None):
+        from . import _native as nat
+        C = np.asarray(C)
+        L = len(C)
+        lo, hi = site_range if site_range is not None else (0, L)
+        # a decision that differs between the ranks unless it is reduced: each rank proposes its own range
+        v = np.array([float(lo), float(hi)])
+        self.decision = v if self.coord is None else self.coord.max(v)
+        cuts = np.arange(lo, hi + 1) if hi > lo else np.zeros(0, np.int64)
+        ncut, cap, ns = len(cuts), 3, hi - lo
+        src = dict(my_cuts=cuts.astype(np.int64), c_sets=np.zeros((ncut, cap, 2), np.uint64), c_lam=np.zeros((ncut, cap)),
+                   c_q=np.zeros((ncut, cap), np.int32), c_chi=np.full(ncut, 2, np.int64), c_chk=np.zeros(ncut, np.int64),
+                   e_pool=np.zeros(ncut + 1), e_off=np.arange(ncut, dtype=np.int64), kk_cut=np.ones(ncut, np.int32),
+                   nfl=cuts.astype(np.int32), nfr=(L - cuts).astype(np.int32))
+        src["c_lam"][:, 0], src["c_lam"][:, 1] = 3.0 + cuts, 4.0
+        src["c_sets"][:, 1, 0] = 1
+        src["e_pool"][:ncut] = 0.25 + 0.5 * cuts / (L + 1)
+        sec = np.zeros(ns, nat.sector)
+        sec["q"], sec["r0"], sec["r1"], sec["c0"], sec["c1"] = np.arange(lo, hi), 0, 4, 0, 2
+        cdt = C.dtype if C.dtype.kind == "c" else np.float64
+        src.update(mode=(np.arange(lo, hi) >= ortho_center).astype(np.int32), sec_off=np.arange(ns, dtype=np.int64),
+                   nsec=np.ones(ns, np.int64), sectors=sec, out_off=8 * np.arange(ns, dtype=np.int64),
+                   bra_off=4 * np.arange(ns, dtype=np.int64), chi_b=np.full(ns, 2, np.int64), chi_k=np.full(ns, 2, np.int64),
+                   bra_p=np.tile(np.array([0, 0, 1, 1], np.int32), ns), bra_alpha=np.tile(np.array([0, 1, 0, 1], np.int32), ns),
+                   det=np.ones(ns, cdt), out=(np.arange(8 * ns) + 8.0 * lo + C[0, 0]).astype(cdt))
+        entries, total = ShardArrays.plan({k: (v_.dtype, v_.shape) for k, v_ in src.items()})
+        buf, keep = sink.alloc(total)
+        sh = ShardArrays.create(buf, entries, dict(L=int(L), s_lo=int(lo), s_hi=int(hi), ortho_center=int(ortho_center),
+                                                   complex=bool(np.iscomplexobj(C)), decision=self.decision.tolist()),
+                                keepalive=keep)
+        for k, v_ in src.items():
+            sh.arrays[k][...] = v_
+        mps = MPSData.from_shards([sh], ortho_center, unit_cell_width, {"total": 1e-3})
+        mps.info = {"checks": {}, "decision": self.decision.tolist()}
+        return mps
+
+
+class ShardGroup:
+    """Rank-side driver of the sharded conversion.  ``torch.distributed`` must be initialised (backend "nccl" =
+    RCCL, one rank per GPU; "gloo" for the one-GPU rehearsal / dry mode, where C travels as a host tensor)."""
+
+    def __init__(self, engine, tag, device=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.eng, self.tag = torch, dist, engine, tag
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = device
+        self.data_nccl = dist.get_backend() == "nccl"
+        self.ctl = dist.new_group(backend="gloo") if self.data_nccl else dist.group.WORLD
+        if self.world > 1:
+            engine.coord = GlooMax(dist, torch, self.ctl)
+        self.sink = ShmSink(tag, self.rank, getattr(engine, "lib", None))
+        self.reader = _Reader(tag) if self.rank == 0 else None
+        self.host_threads = max(2, min(16, len(os.sched_getaffinity(0)) // max(self.world, 1)))
+        self.last_busy_ms = None
+
+    def convert_local(self, C, trunc, ortho_center=None, unit_cell_width=None):
+        """Steps every rank takes: shape + C from rank 0, this rank's site range into its segment.  Returns
+        (generation, bytes, busy ms, checks)."""
+        torch, dist = self.torch, self.dist
+        t0 = time.perf_counter()
+        hdr = torch.zeros(4, dtype=torch.int64)
+        if self.rank == 0:
+            C = np.asarray(C)
+            cplx = np.iscomplexobj(C)
+            C = np.ascontiguousarray(C, np.complex128 if cplx else np.float64)
+            hdr[:] = torch.tensor([len(C), int(cplx), ortho_center or len(C) // 2, unit_cell_width or len(C)])
+        if self.world > 1:
+            dist.broadcast(hdr, 0, group=self.ctl)
+        L, cplx, oc, ucw = (int(x) for x in hdr)
+        tdt = torch.complex128 if cplx else torch.float64
+        if self.data_nccl:
+            d_C = (torch.from_numpy(C.reshape(-1)).to(self.device) if self.rank == 0
+                   else torch.empty(L * L, dtype=tdt, device=self.device))
+            if self.world > 1:
+                dist.broadcast(d_C, 0)                      # RCCL over xGMI
+            mat = d_C
+        else:
+            h_C = torch.from_numpy(C.reshape(-1)) if self.rank == 0 else torch.empty(L * L, dtype=tdt)
+            if self.world > 1:
+                dist.broadcast(h_C, 0)
+            mat = h_C.numpy().reshape(L, L)
+        rng = shard_sites(L, oc, self.world)[self.rank]
+        mps = self.eng.run(mat, trunc, oc, ucw, threads=self.host_threads, download=True, site_range=rng, sink=self.sink)
+        seg = self.sink.last
+        seg.lease = 1
+        self.last_local = mps
+        busy = (time.perf_counter() - t0) * 1e3
+        return seg.gen, seg.size, busy, dict(getattr(mps, "info", {}).get("checks", {}))
+
+    def convert(self, C, trunc, ortho_center=None, unit_cell_width=None):
+        """Launcher mode: the assembled ``MPSData`` on rank 0, ``None`` elsewhere."""
+        torch, dist = self.torch, self.dist
+        gen, size, busy, checks = self.convert_local(C, trunc, ortho_center, unit_cell_width)
+        mine = torch.tensor([float(gen), float(size), busy], dtype=torch.float64)
+        infos = [torch.zeros(3, dtype=torch.float64) for _ in range(self.world)]
+        if self.world > 1:
+            dist.all_gather(infos, mine, group=self.ctl)     # also orders "segment written" before "segment read"
+        else:
+            infos = [mine]
+        self.last_busy_ms = [float(t[2]) for t in infos]
+        if self.rank != 0:
+            return None                    # the segment stays leased until rank 0 drops the assembled object
+        L = int(self.last_local.L)
+        mps = assemble(self.reader, [t.tolist() for t in infos], ortho_center or L // 2, unit_cell_width or L,
+                       {"busy_ms_per_rank": self.last_busy_ms})
+        mps.info = dict(getattr(self.last_local, "info", {}))
+        return mps
+
+
+def init_rank(local=None, gloo=False, dry=False):
+    """Process-group set-up of one rank from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (launcher contract).
+    local: device index (default LOCAL_RANK).  gloo: all ranks may share one device (RCCL refuses that): the
+    one-GPU rehearsal, where C travels as a host tensor; the dry mode always runs on gloo.
+    Returns (rank, world, device string or None)."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if local is None:
+        local = int(os.environ.get("LOCAL_RANK", rank))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dev = None
+    if not dry:
+        torch.cuda.set_device(local)
+        dev = f"cuda:{local}"
+    if not dist.is_initialized():
+        dist.init_process_group("gloo" if (gloo or dry) else "nccl", rank=rank, world_size=world)
+    return rank, world, dev
+
+
+def make_engine(dev, dry=False):
+    if dry:
+        return DryEngine()
+    from .engine import Engine
+    return Engine(dev, profile=False)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(argv, world, extra_env=None, **popen_kw):
+    """Starts ``world`` fresh Python processes with the launcher's environment (RANK, LOCAL_RANK, WORLD_SIZE,
+    MASTER_ADDR, MASTER_PORT) - what ``torch.distributed.run`` does, without its agent.  Must be called BEFORE
+    the calling process initialises a GPU (a process that holds the device must not start others on this pool)."""
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TMF_SHM_TAG=f"tmf{os.getpid()}p{port}")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env, **popen_kw))
+    return procs
+
+
+# ------------------------------------------------------------------------------------------------ library pool
+class DevicePool:
+    """Worker processes behind ``slater.C_to_MPS(..., devices=[...])``: one per device, started on first use -
+    which has to come before this process initialises a GPU itself.  C goes to the workers through a shared-
+    memory segment, their shards come back the same way; this process only maps and assembles."""
+
+    def __init__(self, devices, timeout=600.0):
+        import torch
+
+        self.devices = [str(d) for d in devices]
+        self.world = len(self.devices)
+        self.dry = os.environ.get("TMF_DRY_ENGINE") == "1"
+        if not self.dry and torch.cuda.is_initialized():
+            raise RuntimeError("the device pool must be created before this process uses a GPU itself: call "
+                               "slater.C_to_MPS(..., devices=[...]) (or multi_gpu.DevicePool) first")
+        self.timeout = timeout
+        self.sockpath = f"/tmp/tmf_pool_{os.getpid()}_{free_port()}.sock"
+        srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        srv.bind(self.sockpath)
+        srv.listen(self.world)
+        srv.settimeout(timeout)
+        ids = [d.split(":")[1] if ":" in d else "0" for d in self.devices]
+        same = len(set(ids)) < len(ids)
+        self.procs = spawn_ranks(["-m", "temfpy_amd.multi_gpu", "--serve", self.sockpath], self.world,
+                                 extra_env={"TMF_POOL_DEVICES": ",".join(ids), "TMF_SAME_DEVICE": "1" if same else "0"})
+        self.tag = None
+        self.conns = [None] * self.world
+        try:
+            for _ in range(self.world):
+                c, _a = srv.accept()
+                c.settimeout(timeout)
+                hello = _recv(c)
+                self.conns[hello["rank"]] = c
+                self.tag = hello["tag"]
+        except Exception:
+            self.close()
+            raise
+        finally:
+            srv.close()
+            try:
+                os.unlink(self.sockpath)
+            except OSError:
+                pass
+        self.reader = _Reader(self.tag)
+        self.c_seg = None
+        atexit.register(self.close)
+
+    def convert(self, C, trunc, ortho_center=None, unit_cell_width=None):
+        C = np.asarray(C)
+        cplx = np.iscomplexobj(C)
+        C = np.ascontiguousarray(C, np.complex128 if cplx else np.float64)
+        L = len(C)
+        if self.c_seg is None or self.c_seg.size < C.nbytes:
+            if self.c_seg is not None:
+                self.c_seg.unlink()
+            self.c_gen = getattr(self, "c_gen", -1) + 1
+            self.c_seg = Segment(f"{self.tag}_C{self.c_gen}", max(C.nbytes, 4096), create=True)
+        self.c_seg.buf[: C.nbytes] = C.reshape(-1).view(np.uint8)
+        try:
+            blob = pickle.dumps(trunc)
+        except Exception as exc:
+            raise TypeError("the truncation parameters must be picklable to reach the worker processes "
+                            f"(a lambda as `sectors`?): {exc}") from exc
+        msg = dict(cmd="convert", c_name=self.c_seg.name, L=L, cplx=cplx, trunc=blob, oc=ortho_center, ucw=unit_cell_width)
+        for c in self.conns:
+            _send(c, msg)
+        infos, checks, err = [], {}, None
+        for r, c in enumerate(self.conns):
+            rep = self._recv_alive(r, c)
+            if rep.get("error"):
+                err = err or rep
+            else:
+                infos.append((rep["gen"], rep["size"], rep["busy_ms"]))
+                checks.update(rep["checks"])
+        if err is not None:
+            raise _rebuild_exception(err)
+        mps = assemble(self.reader, infos, ortho_center or L // 2, unit_cell_width or L,
+                       {"busy_ms_per_rank": [i[2] for i in infos]})
+        mps.info = {"checks": checks}
+        return mps
+
+    def _recv_alive(self, r, c):
+        t_end = time.time() + self.timeout
+        c.settimeout(1.0)
+        while True:
+            try:
+                return _recv(c)
+            except socket.timeout:
+                if self.procs[r].poll() is not None:
+                    raise RuntimeError(f"worker of {self.devices[r]} exited with code {self.procs[r].returncode}")
+                if time.time() > t_end:
+                    raise TimeoutError(f"worker of {self.devices[r]} did not answer within {self.timeout} s")
+
+    def close(self):
+        for c in getattr(self, "conns", []):
+            if c is not None:
+                try:
+                    _send(c, dict(cmd="exit"))
+                    c.close()
+                except OSError:
+                    pass
+        self.conns = []
+        for p in getattr(self, "procs", []):
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        self.procs = []
+        if getattr(self, "c_seg", None) is not None:
+            self.c_seg.unlink()
+            self.c_seg = None
+
+
+def _send(conn, obj):
+    b = pickle.dumps(obj)
+    conn.sendall(len(b).to_bytes(8, "little") + b)
+
+
+def _recv(conn):
+    def exactly(n):
+        out = b""
+        while len(out) < n:
+            chunk = conn.recv(n - len(out))
+            if not chunk:
+                raise ConnectionError("peer closed the pool connection")
+            out += chunk
+        return out
+    n = int.from_bytes(exactly(8), "little")
+    return pickle.loads(exactly(n))
+
+
+def _rebuild_exception(rep):
+    import builtins
+    cls = getattr(builtins, rep.get("type", ""), None) or getattr(np.linalg, rep.get("type", ""), None)
+    if not (isinstance(cls, type) and issubclass(cls, Exception)):
+        cls = RuntimeError
+    return cls(f"{rep['error']} (rank {rep.get('rank')})")
+
+
+def _serve(sockpath):
+    """Worker main loop (``python -m temfpy_amd.multi_gpu --serve <socket>``)."""
+    dry = os.environ.get("TMF_DRY_ENGINE") == "1"
+    same = os.environ.get("TMF_SAME_DEVICE") == "1"
+    ids = os.environ.get("TMF_POOL_DEVICES", "").split(",")
+    rank, world, dev = init_rank(local=int(ids[int(os.environ["RANK"])] or 0), gloo=same, dry=dry)
+    tag = os.environ["TMF_SHM_TAG"]
+    group = ShardGroup(make_engine(dev, dry), tag, device=dev)
+    conn = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    conn.connect(sockpath)
+    _send(conn, dict(rank=rank, tag=tag))
+    c_segs = {}
+    while True:
+        msg = _recv(conn)
+        if msg["cmd"] == "exit":
+            break
+        try:
+            C = None
+            if rank == 0:
+                seg = c_segs.get(msg["c_name"]) or c_segs.setdefault(msg["c_name"], Segment(msg["c_name"]))
+                dt = np.complex128 if msg["cplx"] else np.float64
+                C = np.frombuffer(seg.buf, dt, msg["L"] ** 2).reshape(msg["L"], msg["L"])
+            gen, size, busy, checks = group.convert_local(C, pickle.loads(msg["trunc"]), msg["oc"], msg["ucw"])
+            _send(conn, dict(gen=gen, size=size, busy_ms=busy, checks=checks))
+        except Exception as exc:   # reported to the caller, which re-raises
+            _send(conn, dict(error=str(exc), type=type(exc).__name__, rank=rank))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+_POOLS = {}
+
+
+def pool(devices):
+    key = tuple(str(d) for d in devices)
+    if key not in _POOLS:
+        _POOLS[key] = DevicePool(key)
+    return _POOLS[key]
+
+
+if __name__ == "__main__":
+    if len(sys.argv) == 3 and sys.argv[1] == "--serve":
+        _serve(sys.argv[2])
+    else:
+        raise SystemExit("usage: python -m temfpy_amd.multi_gpu --serve <socket>   (started by DevicePool)")

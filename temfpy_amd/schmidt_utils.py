@@ -50,6 +50,10 @@ class StoppingCondition:
         assert self.degeneracy_tol > 0, f"`degeneracy_tol` must be positive, got {self.degeneracy_tol!r}"
         object.__setattr__(self, "max_logval", -np.log(self.svd_min) + self.degeneracy_tol)
 
+    def __reduce__(self):
+        # picklable (worker processes of the multi-GPU path) as long as `sectors` itself is
+        return (StoppingCondition, (self.sectors, self.chi_max, self.svd_min, self.degeneracy_tol))
+
     def __call__(self, logvals) -> bool:
         """schmidt_utils.py:99-138."""
         logvals = np.asarray(logvals)

@@ -74,9 +74,16 @@ def C_to_MPS(
     spinful: Literal["simple", "PH", None] = None,
     unit_cell_width: int | None = None,
     device: str = "cuda:0",
+    devices: list | None = None,
     as_tenpy: bool | None = None,
 ):
-    """MPS representation of a Slater determinant from its correlation matrix (slater.py:1216-1353)."""
+    """MPS representation of a Slater determinant from its correlation matrix (slater.py:1216-1353).
+
+    Extra keywords (not in the reference): ``device`` - the GPU that converts; ``devices`` - a list of GPUs
+    (e.g. ``["cuda:0", ..., "cuda:7"]``) that share the sites of this one chain, one worker process per
+    device (:mod:`temfpy_amd.multi_gpu`; the first such call must come before this process uses a GPU
+    itself); ``as_tenpy`` - True: return ``tenpy.networks.mps.MPS`` (ImportError without TeNPy), False:
+    return :class:`MPSData`, None: TeNPy object if TeNPy is importable."""
     trunc_par = to_stopping_condition(trunc_par)
     if unit_cell_width is None:
         unit_cell_width = len(C)
@@ -93,9 +100,14 @@ def C_to_MPS(
     assert C.shape == (L, L), f"Got non-square {C.shape} correlation matrix"
     ortho_center = ortho_center or L // 2  # slater.py:1291
     logger.info("Central bond %d", ortho_center)
-    eng = _engine(device)
-    eng.checks = testing.TEST_ACTION != "pass"  # testing.py:146-147
-    mps = eng.run(C, trunc_par, ortho_center, unit_cell_width)
+    if devices is not None and len(devices) > 1:
+        from . import multi_gpu
+
+        mps = multi_gpu.pool(devices).convert(C, trunc_par, ortho_center, unit_cell_width)
+    else:
+        eng = _engine(devices[0] if devices else device)
+        eng.checks = testing.TEST_ACTION != "pass"  # testing.py:146-147
+        mps = eng.run(C, trunc_par, ortho_center, unit_cell_width)
     testing.report_schmidt_checks(mps.info["checks"], diag_tol)  # slater.py:419-420
     if as_tenpy is False:
         return mps
@@ -116,12 +128,13 @@ def H_to_MPS(
     spinful: Literal["simple", "PH", None] = None,
     unit_cell_width: int | None = None,
     device: str = "cuda:0",
+    devices: list | None = None,
     as_tenpy: bool | None = None,
 ):
     """MPS representation of a Slater determinant from its Hamiltonian (slater.py:1568-1627)."""
     C, _ = correlation_matrix(H)
     return C_to_MPS(C, trunc_par, diag_tol=diag_tol, ortho_center=ortho_center, spinful=spinful,
-                    unit_cell_width=unit_cell_width, device=device, as_tenpy=as_tenpy)
+                    unit_cell_width=unit_cell_width, device=device, devices=devices, as_tenpy=as_tenpy)
 
 
 def C_to_iMPS(

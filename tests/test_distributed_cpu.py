@@ -1,73 +1,128 @@
-"""world_size-2 gloo test (CPU) of the multi-rank plumbing of bench.py: identical, contiguous,
-exhaustive site shards on every rank and the max-over-ranks step time.  The compute itself
-needs a GPU and is covered by tests/test_gpu_sweep.py::test_site_sharding_*."""
+"""CPU tests (gloo, world_size 2) of the multi-GPU plumbing: `bench.py --gpus N` starting its own ranks, the
+worker pool behind `slater.C_to_MPS(devices=[...])`, shared-memory segments, leases and the assembly of ONE
+MPS from the ranks' shards.  The GPU engine is replaced by multi_gpu.DryEngine (TMF_DRY_ENGINE=1), which
+fabricates a shard deterministically from (L, site, bond); the compute itself is covered on the GPU by
+tests/test_gpu_sweep.py::test_site_sharding_*."""
+import json
 import os
-import socket
 import subprocess
 import sys
 import textwrap
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(TMF_DRY_ENGINE="1", **kw)
+    return env
 
 
-def test_two_rank_sharding_and_timing_reduce():
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with a clean environment reports n_gpus = 2 (what the process group saw), the
+    sharded chain as headline (scaling strong) and the per-rank busy times."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--L", "24", "--chi", "8",
+                        "--steps", "3", "--warmup", "1", "--cpu-sample", "0"], env=_env(), capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 3
+    assert out["value"] > 0 and len(out["config"]["busy_ms_per_rank"]) == 2
+    assert out["config"]["backend"] == "gloo"
+
+
+def test_bench_rank_failure_is_reported():
+    """A rank that dies makes the launcher exit non-zero instead of printing a number."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--L", "1", "--chi", "8",
+                        "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--timeout", "120"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0            # 2 ranks for 1 site: shard_sites raises on every rank
+
+
+def test_device_pool_assembles_one_mps_and_leases_segments():
     code = textwrap.dedent("""
-        import os, sys, json
+        import os, sys, gc
         sys.path.insert(0, %r)
-        import torch, torch.distributed as dist
-        import bench
-        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        L, oc = 1024, 512
-        ranges = bench.shard_sites(L, oc, world)
-        mine = ranges[rank]
-        # every rank derives the same partition; ranges are contiguous and cover all sites
-        gathered = [None] * world
-        dist.all_gather_object(gathered, ranges)
-        assert all(g == ranges for g in gathered)
-        assert ranges[0][0] == 0 and ranges[-1][1] == L
-        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
-        t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        assert abs(t.item() - 0.1 * world) < 1e-12
-        n = torch.tensor([mine[1] - mine[0]])
-        dist.all_reduce(n)
-        assert n.item() == L
-        dist.barrier()
-        dist.destroy_process_group()
-        print("ok", rank, mine)
+        import numpy as np
+        from temfpy_amd import multi_gpu
+        from temfpy_amd.schmidt_utils import to_stopping_condition
+        L = 20
+        C = np.eye(L) * 0.5
+        pool = multi_gpu.DevicePool(["cuda:0", "cuda:1", "cuda:2"])
+        tr = to_stopping_condition({"chi_max": 8})
+        ranges = multi_gpu.shard_sites(L, L // 2, 3)
+        m1 = pool.convert(C, tr)
+        assert m1.L == L and len(m1.shards) == 3
+        # every site comes from the rank that owns it, values as DryEngine fabricates them (out = index + C[0,0])
+        for r, (lo, hi) in enumerate(ranges):
+            for i in range(lo, hi):
+                s = m1.sites[i]
+                assert s is not None and s.blocks[0][0] == i
+                j = i - lo
+                want = (np.arange(8 * j, 8 * j + 8) + 8.0 * lo + 0.5).reshape(4, 2)
+                assert np.array_equal(s.blocks[0][5], want), (i, s.blocks[0][5], want)
+        # every bond exists exactly as fabricated; boundary cuts are held by two shards
+        for b in range(L + 1):
+            assert m1.bonds[b] is not None and m1.bonds[b].lam_raw[0] == 3.0 + b
+        for (lo, hi) in ranges[1:]:
+            assert sum(sh.has_bond(lo) for sh in m1.shards) == 2
+        # cross-rank decision hook: every rank saw the maximum over all ranks
+        assert all(sh.meta["decision"] == [float(ranges[-1][0]), float(L)] for sh in m1.shards)
+        g1 = [sh.keepalive.name for sh in m1.shards]
+        # a second conversion while the first result is alive must not overwrite it: new generation
+        m2 = pool.convert(C * 2, tr)
+        g2 = [sh.keepalive.name for sh in m2.shards]
+        assert set(g1).isdisjoint(g2)
+        assert m1.sites[0].blocks[0][5][0, 0] == 0.5 and m2.sites[0].blocks[0][5][0, 0] == 1.0
+        # dropping the first result frees its segments for the third conversion
+        del m1, s
+        gc.collect()
+        m3 = pool.convert(C * 4, tr)
+        assert [sh.keepalive.name for sh in m3.shards] == g1
+        assert m3.sites[L - 1].blocks[0][5][0, 0] == 8.0 * (ranges[-1][1] - 1 - ranges[-1][0]) + 8.0 * ranges[-1][0] + 2.0
+        pool.close()
+        assert not [f for f in os.listdir("/dev/shm") if f.startswith(pool.tag)]
+        print("ok")
     """ % ROOT)
-    port = _free_port()
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=240)[0] for p in procs]
-    for p, o in zip(procs, outs):
-        assert p.returncode == 0, o
-        assert "ok" in o
+    r = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_shard_cost_balance():
-    import sys
     sys.path.insert(0, ROOT)
-    import numpy as np
-    import bench
+    from temfpy_amd.multi_gpu import shard_sites
 
     for world in (1, 2, 4, 8):
-        r = bench.shard_sites(1024, 512, world)
+        r = shard_sites(1024, 512, world)
         assert len(r) == world and sum(b - a for a, b in r) == 1024
+        assert r[0][0] == 0 and r[-1][1] == 1024 and all(a[1] == b[0] for a, b in zip(r, r[1:]))
         i = np.arange(1024)
         n = np.where(i < 512, i + 1, 1024 - i)
         w = 1.0 + 3.0 * (n / 512) ** 3
         loads = [w[a:b].sum() for a, b in r]
         assert max(loads) / (sum(loads) / world) < 1.15
+    assert all(b > a for a, b in shard_sites(9, 4, 8))      # no empty range
+
+
+def test_shard_arrays_roundtrip_through_a_byte_buffer():
+    sys.path.insert(0, ROOT)
+    from temfpy_amd.mps_data import ShardArrays
+    from temfpy_amd import _native as nat
+
+    sec = np.zeros(3, nat.sector)
+    sec["q"] = [1, 2, 3]
+    src = dict(a=np.arange(7, dtype=np.int32), b=np.arange(6.0).reshape(2, 3) * (1 + 2j), sectors=sec)
+    entries, total = ShardArrays.plan({k: (v.dtype, v.shape) for k, v in src.items()})
+    buf = np.zeros(total, np.uint8)
+    sh = ShardArrays.create(buf, entries, {"L": 5, "s_lo": 0, "s_hi": 5})
+    for k, v in src.items():
+        sh.arrays[k][...] = v
+    back = ShardArrays.unpack(buf)
+    assert back.meta["L"] == 5
+    for k, v in src.items():
+        assert back.arrays[k].dtype == v.dtype and np.array_equal(back.arrays[k], v)
+        assert back.arrays[k].ctypes.data % 4096 == buf.ctypes.data % 4096   # page-aligned offsets
