@@ -291,7 +291,7 @@ def main():
         raise SystemExit("TMF_DRY_ENGINE needs --gpus > 1 (it rehearses the multi-rank plumbing)")
     group = None
     det_ms, det_flops, det_n = {}, {}, {}
-    gemm_ms, gemm_fl = [], []
+    gemm_ms, gemm_fl, gemm_n, det_all = [], [], [], []
 
     # (1) headline: host C in -> host tensors out, downloads overlapped with the next conversion
     results = []
@@ -320,12 +320,14 @@ def main():
     eng.time_gemm = True
 
     def collect():
-        torch.cuda.synchronize()
-        for cls, e0, e1, fl, nd in eng.det_events:
-            det_ms.setdefault(cls, []).append(e0.elapsed_time(e1))
-            det_flops[cls], det_n[cls] = fl, nd
-        gemm_ms.append(sum(e0.elapsed_time(e1) for e0, e1, _ in eng.gemm_events))
-        gemm_fl.append(sum(fl for _, _, fl in eng.gemm_events))
+        ki = eng.kernel_info         # HIP events on the launch stream, read back by tmf_sweep_info_get
+        kind = ("ppt", "reduced", "direct")[ki.det_kind] + (f"/{ki.det_order}" if ki.det_kind else "")
+        det_ms.setdefault(kind, []).append(ki.det_ms)
+        det_flops[kind], det_n[kind] = ki.det_flops, int(ki.n_det)
+        det_all.append(ki.det_all_ms)
+        gemm_ms.append(ki.gemm_ms)
+        gemm_fl.append(ki.gemm_flops)
+        gemm_n.append(int(ki.n_gemm_launches))
 
     dt_dev, mps_dev = timed(lambda: eng.run(d_C, trunc, oc, L, download=False), finish=sync, collect=collect)
     eng.time_gemm = False
@@ -344,7 +346,7 @@ def main():
         # Dominant kernel by GPU time: the 64-wide-tile MFMA GEMM `gemm_kernel<cd, OPA, 64>` - rotation / overlap
         # products `slater.py:1071` and the GEMM share of the block diagonalisation.  achieved = 8 M N K summed over
         # the launches of one conversion / their summed duration (HIP events on the launch stream).
-        n_l = len(eng.gemm_events)
+        n_l = int(np.mean(gemm_n))
         g_ms, g_fl = float(np.mean(gemm_ms)), float(np.mean(gemm_fl))
         ach = g_fl / (g_ms * 1e-3) / 1e12
         kk = [pmc_k.get("tmf::gemm_kernel<tmf::cd, %d, 64>" % o) for o in (0, 1)]
@@ -364,9 +366,9 @@ def main():
     if dom is not None and roof is not None:
         avg_ms = float(np.mean(det_ms[dom]))
         kname = ("tmf::ppt_det_kernel<tmf::cd>" if dom == "ppt"
-                 else f"tmf::reduced_det_kernel<tmf::cd, {str(dom)[:-1]}>" if str(dom).endswith("r")
-                 else f"tmf::det_kernel<tmf::cd, {dom}, G>")
-        all_ms = sum(float(np.mean(v)) for v in det_ms.values())
+                 else f"tmf::reduced_det_kernel<tmf::cd, {dom.split('/')[1]}>" if dom.startswith("reduced")
+                 else f"tmf::det_kernel<tmf::cd, {dom.split('/')[1]}, G>")
+        all_ms = float(np.mean(det_all))
         # The determinant stage (90 % of the reference's time, `slater.py:828-869`).  `reference_work` counts the
         # REFERENCE's algorithm (one (8/3) n^3 LU per minor); the pivoted-exchange kernel evaluates
         # order-d minors of one shared exchange instead and executes almost none of those flops.  The hardware-true

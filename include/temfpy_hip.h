@@ -450,6 +450,130 @@ int64_t tmf_det_tiles_build(int nsites, const tmf_site_job* jobs, const tmf_site
                             int64_t tile_cap, int64_t* rest, int64_t rest_cap, int64_t* n_rest, int32_t* lds_max,
                             double* flops_n3, int64_t* n_pairs);
 
+/* ------------------------------------------------------------------------------------
+ * Sweep level: one conversion per call.  Replaces the driver loop of slater.C_to_MPS
+ * (slater.py:1293-1346: centre cut, right sweep, left sweep) together with
+ * SchmidtVectors.from_correlation_matrix (:702-755) and MPSTensorData.from_schmidt_vectors
+ * (:975-1104) for all cuts / sites at once: every stage is one batched launch over all of them, the
+ * descriptors are built here in C++, two host round trips (eigenvalues down, index lists up).
+ *
+ * A context owns one device: its streams (launch, download, upload), a device arena for the
+ * temporaries of a sweep, page-locked staging memory and the double-buffered output blocks.
+ * Calls on one context are not re-entrant (one conversion at a time; the DOWNLOAD of a finished
+ * conversion may still be running while the next one computes).
+ *
+ * Staged form (what the Python host code drives; the stages are separate calls because a
+ * multi-GPU run reduces the range-finder decisions over the ranks between them):
+ *   tmf_sweep_begin      C up (row-major, as NumPy holds it), cut-side problems of the site range
+ *   tmf_sweep_entangled  entangled orbitals + eigenvalues of every cut with a P-column range finder;
+ *                        blocks until the eigenvalues are in host memory; reports the quantities the
+ *                        adaptive rule needs.  Repeat with iterations = 1 or a larger P as needed.
+ *   tmf_sweep_sites      classification, enumeration (schmidt_utils.py:211-324) and site preparation
+ *                        (host threads) overlapped with the filled-orbital bases; overlaps (slater.py:1071),
+ *                        Schur complements (:1077-1090), all determinants (:828-869) enqueued; reports
+ *                        the sizes of the result arrays
+ *   tmf_sweep_download   bookkeeping arrays into caller memory, tensors by asynchronous DMA into caller
+ *                        (page-locked) memory on the download stream; returns a ticket
+ *   tmf_sweep_wait       blocks until the ticket's tensors have landed; returns the deviations of
+ *                        testing.check_schmidt_decomposition (testing.py:131-177) for the centre cut
+ * tmf_slater_sweep runs all of them for one rank and owns the result (tmf_result_* accessors).
+ * ---------------------------------------------------------------------------------- */
+typedef struct tmf_ctx tmf_ctx;
+typedef struct tmf_result tmf_result;
+
+int tmf_ctx_create(int device, tmf_ctx** out);
+void tmf_ctx_destroy(tmf_ctx* ctx);
+
+#define TMF_SWEEP_CHECKS 1u        /* evaluate the self-check of the centre cut (TEST_ACTION != "pass")   */
+#define TMF_SWEEP_TIME_KERNELS 2u  /* HIP events around every MFMA GEMM and determinant launch (bench.py)  */
+#define TMF_SWEEP_RANGE_BCGS 4u    /* range-finder QRs by blocked Gram-Schmidt instead of the slab kernel  */
+#define TMF_SWEEP_NO_CHOLQR 8u     /* filled-basis panels by the LDS Gram-Schmidt kernel                  */
+#define TMF_SWEEP_DET_REDUCED 16u  /* all minors through tmf_det_reduced_batched (A/B switch)              */
+#define TMF_SWEEP_DET_DIRECT 32u   /* ... through tmf_det_gather_batched                                  */
+#define TMF_SWEEP_C_ON_DEVICE 64u  /* C is a device pointer (row-major) instead of host memory            */
+#define TMF_SWEEP_TWO_PASSES 128u  /* two projection passes in the filled-basis Gram-Schmidt              */
+
+typedef struct {
+  int64_t L;                 /* C is L x L, row-major, real (double) or complex (re, im doubles)          */
+  int64_t chi_max;           /* <= 0: no limit (StoppingCondition.chi_max = None)                         */
+  double svd_min, degeneracy_tol;
+  const int64_t* sectors;    /* NULL, or n_sectors allowed left charges (StoppingCondition.sectors)       */
+  int64_t ortho_center;      /* already resolved: slater.py:1291                                          */
+  int64_t site_lo, site_hi;  /* sites [site_lo, site_hi) of this rank; 0, L for a whole chain             */
+  int32_t n_sectors, is_complex, host_threads;
+  uint32_t flags;
+} tmf_sweep_params;          /* 80 bytes */
+
+typedef struct {
+  int64_t ncut, cap, ns, sec_tot, bra_tot, e_tot, out_elems, elem_bytes;
+} tmf_sweep_dims;
+
+/* Destination of the result arrays (host memory of the caller).  Shapes from tmf_sweep_dims:
+ * my_cuts[ncut] i64; c_sets[ncut][cap][2] u64; c_lam[ncut][cap] f64; c_q[ncut][cap] i32; c_chi, c_chk[ncut] i64;
+ * e_pool[e_tot + 1] f64; e_off[ncut] i64; kk_cut, nfl, nfr[ncut] i32; mode[ns] i32; sec_off, nsec[ns] i64;
+ * sectors[sec_tot + 1] tmf_sector; out_off, bra_off, chi_b, chi_k[ns] i64; bra_p, bra_alpha[bra_tot + 1] i32;
+ * det[ns] elements; out[out_elems] elements (page-locked memory, else the copy is staged and slow). */
+typedef struct {
+  void *my_cuts, *c_sets, *c_lam, *c_q, *c_chi, *c_chk, *e_pool, *e_off, *kk_cut, *nfl, *nfr;
+  void *mode, *sec_off, *nsec, *sectors, *out_off, *bra_off, *chi_b, *chi_k, *bra_p, *bra_alpha, *det, *out;
+} tmf_sweep_ptrs;
+
+typedef struct {
+  double stage_ms[16];       /* host wall time per stage, see tmf_sweep_stage_name                        */
+  double gemm_ms, gemm_flops;            /* with TMF_SWEEP_TIME_KERNELS: all MFMA GEMM launches of the sweep */
+  double det_ms, det_flops, det_all_ms;  /* dominant determinant launch (by time); all determinant launches  */
+  int64_t n_det, n_gemm_launches;
+  int32_t det_kind;          /* 0 pivoted exchange, 1 reduced, 2 direct */
+  int32_t det_order;
+  int32_t range_width, range_iterations;
+  double range_floor;
+  int64_t n_fermion, device_bytes;
+} tmf_sweep_info;
+
+int tmf_sweep_begin(tmf_ctx* ctx, const void* C, const tmf_sweep_params* par);
+/* smallest_sigma: largest over the truncated cuts of the smallest singular value the P columns captured;
+ * saturated: a truncated cut has P or more directions above the threshold; weak: (iterations > 0) a cut whose
+ * smallest captured value still exceeds 4.6e-4 sqrt(threshold); max_sweeps: largest Jacobi sweep count
+ * (60 = not converged).  bad_cut: a cut the flags refer to (for messages). */
+int tmf_sweep_entangled(tmf_ctx* ctx, int P, int iterations, double* smallest_sigma, int32_t* saturated, int32_t* weak,
+                        int32_t* max_sweeps, int64_t* bad_cut);
+int tmf_sweep_sites(tmf_ctx* ctx, tmf_sweep_dims* dims);
+int tmf_sweep_download(tmf_ctx* ctx, const tmf_sweep_ptrs* dst, int want_tensors, int64_t* ticket);
+int tmf_sweep_query(tmf_ctx* ctx, int64_t ticket);     /* 1: landed, 0: still copying, < 0: error */
+int tmf_sweep_wait(tmf_ctx* ctx, int64_t ticket, double* checks /* 5 doubles */, int32_t* n_checks);
+int tmf_sweep_info_get(tmf_ctx* ctx, tmf_sweep_info* out);
+const char* tmf_sweep_stage_name(int i);
+/* device address / element count of the tensors of the last tmf_sweep_sites (valid until the next one) */
+int tmf_sweep_device_out(tmf_ctx* ctx, uint64_t* d_out, int64_t* elems);
+
+/* One call: the whole conversion of sites [site_lo, site_hi) with the adaptive range finder (64, 128, 256
+ * columns; one subspace iteration when the smallest captured singular value exceeds range_floor_tol <= 0 ->
+ * 1e-11), result in page-locked memory owned by the returned object. */
+int tmf_slater_sweep(tmf_ctx* ctx, const void* C, const tmf_sweep_params* par, double range_floor_tol, tmf_result** out);
+typedef struct {
+  int64_t x, chi, k, n_filled_left, n_filled_right, n_checked;
+  const double* e;           /* k entangled eigenvalues of C_LL, descending (SchmidtModes.e)              */
+  const uint64_t* masks;     /* chi x 2 words: bit i = entangled orbital i occupied on the left           */
+  const double* lam_raw;     /* unnormalised Schmidt values (SchmidtVectors.schmidt_values)               */
+  const int32_t* q_left;     /* particles left of the cut, ascending (idx_L)                              */
+} tmf_bond_view;
+typedef struct {
+  int64_t site, chi_bra, chi_ket, n_blocks;
+  int32_t mode, pad;         /* 0: A tensor (left of the centre), 1: B tensor                              */
+  double det_always[2];
+  const int32_t *bra_p, *bra_alpha;   /* 2 chi_bra entries: physical occupation / bra index of every merged row */
+} tmf_site_view;
+typedef struct {
+  int32_t q, r0, r1, c0, c1, n;
+  const void* data;          /* (r1 - r0) x (c1 - c0), row-major                                          */
+} tmf_block_view;
+int tmf_result_dims(const tmf_result* r, tmf_sweep_dims* dims, int64_t* L, int64_t* site_lo, int64_t* site_hi);
+int tmf_result_bond(const tmf_result* r, int64_t b, tmf_bond_view* out);      /* TMF_E_ARG: not held by this range */
+int tmf_result_site(const tmf_result* r, int64_t i, tmf_site_view* out);
+int tmf_result_block(const tmf_result* r, int64_t i, int64_t j, tmf_block_view* out);
+int tmf_result_checks(const tmf_result* r, double* checks, int32_t* n_checks);
+void tmf_result_free(tmf_result* r);
+
 #ifdef __cplusplus
 }
 #endif

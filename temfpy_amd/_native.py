@@ -88,7 +88,73 @@ SYMBOLS = [
     "tmf_site_prepare", "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_det_tiles_build", "tmf_pf_gather_batched",
     "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched", "tmf_copy_blocks_batched", "tmf_house_qr_batched", "tmf_jacobi_compact_batched", "tmf_house_slab_batched",
     "tmf_host_register", "tmf_host_unregister", "tmf_memcpy_async",
+    "tmf_ctx_create", "tmf_ctx_destroy", "tmf_sweep_begin", "tmf_sweep_entangled", "tmf_sweep_sites", "tmf_sweep_download",
+    "tmf_sweep_query", "tmf_sweep_wait", "tmf_sweep_info_get", "tmf_sweep_stage_name", "tmf_sweep_device_out",
+    "tmf_slater_sweep", "tmf_result_dims", "tmf_result_bond", "tmf_result_site", "tmf_result_block", "tmf_result_checks",
+    "tmf_result_free",
 ]
+
+# ---- sweep-level structs (include/temfpy_hip.h, "Sweep level") ---------------------------------------------
+SWEEP_CHECKS, SWEEP_TIME_KERNELS, SWEEP_RANGE_BCGS, SWEEP_NO_CHOLQR = 1, 2, 4, 8
+SWEEP_DET_REDUCED, SWEEP_DET_DIRECT, SWEEP_C_ON_DEVICE, SWEEP_TWO_PASSES = 16, 32, 64, 128
+
+
+class SweepParams(C.Structure):
+    _fields_ = [("L", C.c_int64), ("chi_max", C.c_int64), ("svd_min", C.c_double), ("degeneracy_tol", C.c_double),
+                ("sectors", C.c_void_p), ("ortho_center", C.c_int64), ("site_lo", C.c_int64), ("site_hi", C.c_int64),
+                ("n_sectors", C.c_int32), ("is_complex", C.c_int32), ("host_threads", C.c_int32), ("flags", C.c_uint32)]
+
+
+class SweepDims(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("ncut", "cap", "ns", "sec_tot", "bra_tot", "e_tot", "out_elems", "elem_bytes")]
+
+
+SWEEP_ARRAYS = ("my_cuts", "c_sets", "c_lam", "c_q", "c_chi", "c_chk", "e_pool", "e_off", "kk_cut", "nfl", "nfr", "mode",
+                "sec_off", "nsec", "sectors", "out_off", "bra_off", "chi_b", "chi_k", "bra_p", "bra_alpha", "det", "out")
+
+
+class SweepPtrs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in SWEEP_ARRAYS]
+
+
+class SweepInfo(C.Structure):
+    _fields_ = [("stage_ms", C.c_double * 16), ("gemm_ms", C.c_double), ("gemm_flops", C.c_double), ("det_ms", C.c_double),
+                ("det_flops", C.c_double), ("det_all_ms", C.c_double), ("n_det", C.c_int64), ("n_gemm_launches", C.c_int64),
+                ("det_kind", C.c_int32), ("det_order", C.c_int32), ("range_width", C.c_int32), ("range_iterations", C.c_int32),
+                ("range_floor", C.c_double), ("n_fermion", C.c_int64), ("device_bytes", C.c_int64)]
+
+
+class BondView(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("x", "chi", "k", "n_filled_left", "n_filled_right", "n_checked")] + \
+               [("e", C.c_void_p), ("masks", C.c_void_p), ("lam_raw", C.c_void_p), ("q_left", C.c_void_p)]
+
+
+class SiteView(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("site", "chi_bra", "chi_ket", "n_blocks")] + \
+               [("mode", C.c_int32), ("pad", C.c_int32), ("det_always", C.c_double * 2), ("bra_p", C.c_void_p),
+                ("bra_alpha", C.c_void_p)]
+
+
+class BlockView(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("q", "r0", "r1", "c0", "c1", "n")] + [("data", C.c_void_p)]
+
+
+assert C.sizeof(SweepParams) == 80 and C.sizeof(SweepDims) == 64 and C.sizeof(SweepPtrs) == 23 * 8
+
+
+def sweep_spec(dims, cplx, want_out=True):
+    """{name: (dtype, shape)} of the result arrays of a sweep (the destinations of tmf_sweep_download)."""
+    cdt = np.complex128 if cplx else np.float64
+    nc, cap, ns = int(dims.ncut), int(dims.cap), int(dims.ns)
+    return {"my_cuts": (np.int64, (nc,)), "c_sets": (np.uint64, (nc, cap, 2)), "c_lam": (np.float64, (nc, cap)),
+            "c_q": (np.int32, (nc, cap)), "c_chi": (np.int64, (nc,)), "c_chk": (np.int64, (nc,)),
+            "e_pool": (np.float64, (int(dims.e_tot) + 1,)), "e_off": (np.int64, (nc,)), "kk_cut": (np.int32, (nc,)),
+            "nfl": (np.int32, (nc,)), "nfr": (np.int32, (nc,)), "mode": (np.int32, (ns,)), "sec_off": (np.int64, (ns,)),
+            "nsec": (np.int64, (ns,)), "sectors": (sector, (int(dims.sec_tot) + 1,)), "out_off": (np.int64, (ns,)),
+            "bra_off": (np.int64, (ns,)), "chi_b": (np.int64, (ns,)), "chi_k": (np.int64, (ns,)),
+            "bra_p": (np.int32, (int(dims.bra_tot) + 1,)), "bra_alpha": (np.int32, (int(dims.bra_tot) + 1,)),
+            "det": (cdt, (ns,)), "out": (cdt, (int(dims.out_elems) if want_out else 0,))}
+
 
 
 class NativeError(RuntimeError):
@@ -100,6 +166,13 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
+    host_only = os.environ.get("TMF_ASAN_LIB")      # tools/run_host_asan.sh: sanitizer build of the host entry points
+    if host_only:
+        lib = C.CDLL(host_only)
+        lib.tmf_last_error.restype = C.c_char_p
+        _set_host_argtypes(lib)
+        _LIB = lib
+        return lib
     if not os.path.exists(_PATH):
         raise NativeError(
             f"{_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -139,16 +212,44 @@ def load():
     lib.tmf_gather_signed_batched.argtypes = [i32, vp, i32, vp]
     lib.tmf_normalise_columns_batched.argtypes = [i32, vp, i32, vp]
     lib.tmf_column_norms_batched.argtypes = [i32, vp, i32, vp]
-    lib.tmf_cut_vectors.argtypes = [vp, i32, i32, i64, f64, f64, vp, i32, i64, vp, vp, vp, vp, vp]
-    lib.tmf_site_prepare.argtypes = [vp] * 13 + [i32, vp, i64, vp]
-    lib.tmf_site_prepare.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i64, vp]
-    lib.tmf_cut_vectors_batch.argtypes = [i32, vp, vp, vp, vp, i64, f64, f64, vp, i32, i64, vp, vp, vp, vp, vp, i32]
-    lib.tmf_site_prepare_batch.argtypes = [i32, vp, vp, vp, vp, i64] + [vp] * 9 + [i32]
+    _set_host_argtypes(lib)
+    lib.tmf_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    lib.tmf_ctx_destroy.argtypes = [vp]
+    lib.tmf_ctx_destroy.restype = None
+    lib.tmf_sweep_begin.argtypes = [vp, vp, C.POINTER(SweepParams)]
+    lib.tmf_sweep_entangled.argtypes = [vp, i32, i32, C.POINTER(f64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32), C.POINTER(i64)]
+    lib.tmf_sweep_sites.argtypes = [vp, C.POINTER(SweepDims)]
+    lib.tmf_sweep_download.argtypes = [vp, C.POINTER(SweepPtrs), i32, C.POINTER(i64)]
+    lib.tmf_sweep_query.argtypes = [vp, i64]
+    lib.tmf_sweep_wait.argtypes = [vp, i64, C.POINTER(f64), C.POINTER(C.c_int32)]
+    lib.tmf_sweep_info_get.argtypes = [vp, C.POINTER(SweepInfo)]
+    lib.tmf_sweep_stage_name.argtypes = [i32]
+    lib.tmf_sweep_stage_name.restype = C.c_char_p
+    lib.tmf_sweep_device_out.argtypes = [vp, C.POINTER(u64), C.POINTER(i64)]
+    lib.tmf_slater_sweep.argtypes = [vp, vp, C.POINTER(SweepParams), f64, C.POINTER(vp)]
+    lib.tmf_result_dims.argtypes = [vp, C.POINTER(SweepDims), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+    lib.tmf_result_bond.argtypes = [vp, i64, C.POINTER(BondView)]
+    lib.tmf_result_site.argtypes = [vp, i64, C.POINTER(SiteView)]
+    lib.tmf_result_block.argtypes = [vp, i64, i64, C.POINTER(BlockView)]
+    lib.tmf_result_checks.argtypes = [vp, C.POINTER(f64), C.POINTER(C.c_int32)]
+    lib.tmf_result_free.argtypes = [vp]
+    lib.tmf_result_free.restype = None
     lib.tmf_host_register.argtypes = [vp, i64]
     lib.tmf_host_unregister.argtypes = [vp]
     lib.tmf_memcpy_async.argtypes = [vp, vp, i64, i32, vp]
     _LIB = lib
     return lib
+
+
+def _set_host_argtypes(lib):
+    vp, i32, i64, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    lib.tmf_cut_vectors.argtypes = [vp, i32, i32, i64, f64, f64, vp, i32, i64, vp, vp, vp, vp, vp]
+    lib.tmf_site_prepare.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i64, vp]
+    lib.tmf_cut_vectors_batch.argtypes = [i32, vp, vp, vp, vp, i64, f64, f64, vp, i32, i64, vp, vp, vp, vp, vp, i32]
+    lib.tmf_site_prepare_batch.argtypes = [i32, vp, vp, vp, vp, i64] + [vp] * 9 + [i32]
+    lib.tmf_det_tiles_build.argtypes = [i32, vp, vp, vp, vp, i32, i64, vp, i64, vp, i64, vp, vp, vp, vp]
+    lib.tmf_det_tiles_build.restype = i64
 
 
 def check(status: int, what: str):
@@ -159,6 +260,17 @@ def check(status: int, what: str):
         if status == -3:
             raise NotImplementedError(f"{what}: {msg}")
         raise NativeError(f"{what}: {msg} (status {status})")
+
+
+JACOBI_SWEEP_CAP = 60   # csrc/jacobi.hip: a problem that reports this many sweeps still had rotations pending
+
+
+def check_jacobi_sweeps(sweeps, what="Jacobi iteration"):
+    """LAPACK's eigh / svd raise LinAlgError when they do not converge (numpy.linalg); so does this."""
+    sweeps = np.asarray(sweeps)
+    if sweeps.size and int(sweeps.max()) >= JACOBI_SWEEP_CAP:
+        bad = int(np.count_nonzero(sweeps >= JACOBI_SWEEP_CAP))
+        raise np.linalg.LinAlgError(f"{what} did not converge in {JACOBI_SWEEP_CAP} sweeps ({bad} of {sweeps.size} problems)")
 
 
 def _p(a: np.ndarray):

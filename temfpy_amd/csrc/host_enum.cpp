@@ -496,6 +496,9 @@ int parallel_for(int n, int nthreads, F&& fn) {
   if (nthreads < 1) nthreads = 1;
   if (nthreads > n) nthreads = n > 0 ? n : 1;
   std::atomic<int> next(0), err(0);
+  // The error text is thread-local (tmf_last_error): the first failing worker's message is copied out under
+  // the same compare-exchange that records its status, and re-set on the CALLING thread before returning.
+  char first_msg[512] = "";
   auto work = [&]() {
     for (;;) {
       const int i = next.fetch_add(1);
@@ -503,7 +506,7 @@ int parallel_for(int n, int nthreads, F&& fn) {
       const int st = fn(i);
       if (st != 0) {
         int z = 0;
-        err.compare_exchange_strong(z, st);
+        if (err.compare_exchange_strong(z, st)) snprintf(first_msg, sizeof(first_msg), "item %d: %s", i, tmf_last_error());
       }
     }
   };
@@ -511,6 +514,7 @@ int parallel_for(int n, int nthreads, F&& fn) {
   for (int t = 1; t < nthreads; ++t) th.emplace_back(work);
   work();
   for (auto& t : th) t.join();
+  if (err.load() != 0) tmf::set_error("%s", first_msg);
   return err.load();
 }
 }  // namespace

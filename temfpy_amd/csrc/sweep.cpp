@@ -1,0 +1,1764 @@
+// Sweep level of the Slater -> MPS conversion: the host driver in C++.
+//
+// The reference walks the chain site by site (slater.py:1300-1346) and calls LAPACK per cut.  All L+1 cuts
+// and all L sites are independent given C, so every stage here is ONE batched launch over all of them
+// (descriptor arrays, variable sizes) with two host round trips: the entangled eigenvalues come down for
+// the best-first enumeration (integer work on host threads, overlapped with the filled-basis launches), the
+// index lists go up for the determinant stage.
+//
+// Per cut side (block A = C_LL or C_RR, off-diagonal block F = C_LR or C_RL), using that C is a projector
+// (A - A^2 = F F^H: entangled orbitals = left singular vectors of F with sigma^2 = e (1 - e), the same set
+// as slater.py:350):
+//   E1  Y = F Omega                 running sums over the nested blocks of all cuts (nested.hip)
+//   E2  Q = qr(Y)                   Householder slab kernel (or blocked Gram-Schmidt)
+//   E3  B^H = F^H Q ; R^H           GEMM + slab QR (R only)
+//   E4  R^H = U diag(sigma) V^H     one-sided Jacobi in LDS, left vectors only
+//   E5  U0 = Q U[:, sigma^2 >= thr] GEMM
+//   E6  T = U0^H A U0 ; T X = X e   2 GEMMs + Jacobi (Rayleigh-Ritz)
+//   E7  U_E = U0 X                  GEMM
+//   F   filled basis: orthonormalise (1 - U_E U_E^H) A Omega_f ; centre right orbitals = C_RL v_L
+// Per site:
+//   S1  O = V_bra^H V_ket           MFMA GEMM (slater.py:1071)
+//   S2  W = signed gather of O      [always | sometimes] + physical orbital
+//   S3  det_always, Schur complement (slater.py:1077-1090)
+//   S4  all minors of all sectors   (slater.py:828-869)
+// Self-check (testing.py:131-177): reconstruction deviations of the centre cut (recon.hip).
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <numeric>
+#include <vector>
+
+#include "common.hpp"
+
+namespace tmf {
+namespace {
+
+using i64 = int64_t;
+using u64 = uint64_t;
+
+constexpr int PANEL_W = 16;
+constexpr int N_STAGES = 16;
+const char* kStageNames[N_STAGES] = {"upload",        "E_entangled",      "host_classify",   "F_filled",
+                                     "S_overlap_gemm", "host_enumerate",   "host_site_prepare", "S_overlap_schur",
+                                     "S_determinants", "host_result",      "download",        "total",
+                                     "host_wait_eigenvalues", "host_wait_threads", "", ""};
+enum Stage { ST_UPLOAD, ST_E, ST_CLASSIFY, ST_F, ST_S1, ST_ENUM, ST_SITEPREP, ST_SCHUR, ST_DET, ST_RESULT, ST_DOWNLOAD,
+             ST_TOTAL, ST_WAIT_E, ST_WAIT_T };
+
+inline double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline i64 cdiv(i64 a, i64 b) { return (a + b - 1) / b; }
+inline i64 a16(i64 x) { return (x + 15) & ~(i64)15; }
+
+#define TMF_TRY(expr)            \
+  do {                           \
+    const int st__ = (expr);     \
+    if (st__ != TMF_OK) return st__; \
+  } while (0)
+#define HIP_TRY(expr) TMF_TRY(check_hip((expr), #expr))
+
+// ---- memory -----------------------------------------------------------------------------------------
+// Temporaries of one sweep: bump allocation out of large device blocks that are kept between sweeps.
+struct DeviceArena {
+  struct Chunk {
+    char* p;
+    size_t cap, off;
+  };
+  std::vector<Chunk> chunks;
+  size_t cur = 0, total = 0;
+  int alloc(size_t bytes, void** out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    for (; cur < chunks.size(); ++cur) {
+      Chunk& c = chunks[cur];
+      if (c.off + bytes <= c.cap) {
+        *out = c.p + c.off;
+        c.off += bytes;
+        return TMF_OK;
+      }
+    }
+    Chunk c;
+    c.cap = std::max(bytes, (size_t)1 << 30);
+    c.off = bytes;
+    HIP_TRY(hipMalloc((void**)&c.p, c.cap));
+    total += c.cap;
+    chunks.push_back(c);
+    cur = chunks.size() - 1;
+    *out = c.p;
+    return TMF_OK;
+  }
+  void reset() {
+    for (auto& c : chunks) c.off = 0;
+    cur = 0;
+  }
+  void release() {
+    for (auto& c : chunks) (void)hipFree(c.p);
+    chunks.clear();
+    cur = total = 0;
+  }
+};
+
+// Page-locked staging memory with a mirrored device block: descriptor uploads are a host memcpy plus an
+// asynchronous copy on the launch stream (a pageable copy blocks the host and drains the stream).
+struct StagingArena {
+  char *h = nullptr, *d = nullptr;
+  size_t cap = 0, off = 0;
+  std::vector<std::pair<char*, char*>> retired;  // blocks still referenced by queued copies of this sweep
+  int reserve(size_t bytes) {
+    size_t o = (off + 255) & ~(size_t)255;
+    if (h == nullptr || o + bytes > cap) {
+      if (h != nullptr) retired.emplace_back(h, d);
+      const size_t ncap = std::max(std::max(2 * cap, 2 * bytes), (size_t)64 << 20);
+      HIP_TRY(hipHostMalloc((void**)&h, ncap, hipHostMallocDefault));
+      HIP_TRY(hipMalloc((void**)&d, ncap));
+      cap = ncap;
+      o = 0;
+    }
+    off = o;
+    return TMF_OK;
+  }
+  void reset() {  // only after the launch stream has drained
+    for (auto& r : retired) {
+      (void)hipHostFree(r.first);
+      (void)hipFree(r.second);
+    }
+    retired.clear();
+    off = 0;
+  }
+  void release() {
+    reset();
+    if (h) (void)hipHostFree(h);
+    if (d) (void)hipFree(d);
+    h = d = nullptr;
+    cap = off = 0;
+  }
+};
+
+struct PinnedBuf {  // grow-only page-locked host buffer
+  char* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return TMF_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t ncap = std::max(bytes + bytes / 4, (size_t)4096);
+    HIP_TRY(hipHostMalloc((void**)&p, ncap, hipHostMallocDefault));
+    memset(p, 0, ncap);  // fault the pages in now, not inside the worker threads
+    cap = ncap;
+    return TMF_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// Output block of one conversion (tensors + det_always): stays alive until its download has finished, so
+// two or three of them rotate while downloads overlap the next conversion.
+struct OutSlot {
+  char* d = nullptr;
+  size_t cap = 0;
+  hipEvent_t done = nullptr;
+  bool busy = false;
+  i64 ticket = -1;
+  PinnedBuf checks;  // 8 doubles
+  int n_checks = 0;
+  int det_off_elems = 0;
+};
+
+struct KernelEvent {
+  hipEvent_t e0, e1;
+  double flops;
+  i64 n;
+  int kind, order;
+};
+
+}  // namespace
+}  // namespace tmf
+
+using namespace tmf;
+
+struct tmf_ctx {
+  int device = 0;
+  hipStream_t s_main = nullptr, s_down = nullptr, s_up = nullptr;
+  DeviceArena dev;
+  StagingArena stage;
+  std::vector<OutSlot> slots;
+  i64 next_ticket = 1;
+  PinnedBuf fetch;     // eigenvalues / counts coming down
+  PinnedBuf pool_pin;  // index lists going up
+  PinnedBuf c_pin;     // C going up
+  std::vector<hipEvent_t> event_pool;
+  size_t events_used = 0;
+
+  // ---- state of the current sweep ----
+  tmf_sweep_params par{};
+  std::vector<i64> sectors;
+  bool have_sectors = false;
+  int dtype = TMF_F64;
+  i64 el = 8, L = 0, oc = 0, s_lo = 0, s_hi = 0;
+  bool cplx = false, begun = false, have_sites = false;
+  double cutoff = 0, thr2 = 0;
+  std::vector<double> diag;
+  char *d_Crm = nullptr, *d_C = nullptr;
+  // cut-side problems
+  i64 ncs = 0;
+  std::vector<i64> cs_b, cs_side, n, m, ld1;
+  std::vector<u64> blk, off;
+  std::vector<char> doE;
+  bool has_centre = false;
+  i64 centre_L = -1, centre_R = -1;
+  // entangled stage
+  int P = 0;
+  std::vector<i64> p, oS;
+  std::vector<u64> UEp;
+  std::vector<double> h_sig, h_e;
+  std::vector<int32_t> h_cnt;
+  int range_iterations = 0;
+  double range_floor = 0;
+  // classification
+  std::vector<i64> k, nf, ent0;
+  std::vector<std::vector<double>> e_side;
+  i64 n_fermion = 0;
+  // host phase outputs
+  std::vector<i64> my_cuts, cpos, e_off, c_chi, c_chk;
+  std::vector<int32_t> kk_cut, nfl, nfr;
+  std::vector<double> e_pool, c_lam;
+  std::vector<u64> c_sets;
+  std::vector<int32_t> c_q;
+  i64 cap = 0, ncut = 0, ns = 0;
+  std::vector<tmf_site_job> jobs;
+  std::vector<tmf_site_out> souts;
+  std::vector<int32_t> row_sel, col_sel, bra_p, bra_alpha, mode;
+  std::vector<int8_t> row_sign, col_sign;
+  std::vector<tmf_sector> sec_buf;
+  std::vector<i64> chi_b, chi_k, out_off, nsec;
+  i64 out_tot = 0, sc_tot = 0, br_tot = 0, ix_tot = 0;
+  // device results
+  OutSlot* slot = nullptr;
+  char *d_out = nullptr, *d_det = nullptr, *d_chk = nullptr;
+  int n_checks = 0;
+  std::vector<int32_t*> sweep_counters;  // device arrays of Jacobi sweep counts
+  std::vector<i64> sweep_counts_n;
+  // timings
+  double stage_ms[N_STAGES] = {0};
+  double t_begin = 0;
+  std::vector<KernelEvent> gemm_events, det_events;
+  i64 n_det = 0;
+};
+
+namespace tmf {
+namespace {
+
+struct Sweep {
+  tmf_ctx& c;
+  explicit Sweep(tmf_ctx& ctx) : c(ctx) {}
+
+  // ------------------------------------------------------------------ plumbing
+  int dalloc(i64 count, i64 elem, void** out, bool zero = false) {
+    const size_t bytes = (size_t)std::max<i64>(count, 1) * (size_t)elem;
+    TMF_TRY(c.dev.alloc(bytes, out));
+    if (zero) HIP_TRY(hipMemsetAsync(*out, 0, bytes, c.s_main));
+    return TMF_OK;
+  }
+  int alloc_el(i64 count, u64* out, bool zero = false) {  // elements of the sweep's dtype
+    void* p = nullptr;
+    TMF_TRY(dalloc(count, c.el, &p, zero));
+    *out = (u64)p;
+    return TMF_OK;
+  }
+  int up(const void* host, size_t bytes, u64* dev) {
+    if (bytes == 0) bytes = 1;
+    TMF_TRY(c.stage.reserve(bytes));
+    memcpy(c.stage.h + c.stage.off, host, bytes);
+    HIP_TRY(hipMemcpyAsync(c.stage.d + c.stage.off, c.stage.h + c.stage.off, bytes, hipMemcpyHostToDevice, c.s_main));
+    *dev = (u64)(c.stage.d + c.stage.off);
+    c.stage.off += bytes;
+    return TMF_OK;
+  }
+  template <typename T>
+  int up_vec(const std::vector<T>& v, u64* dev) {
+    return up(v.data(), v.size() * sizeof(T), dev);
+  }
+  int new_event(hipEvent_t* e) {
+    if (c.events_used == c.event_pool.size()) {
+      hipEvent_t ev;
+      HIP_TRY(hipEventCreate(&ev));
+      c.event_pool.push_back(ev);
+    }
+    *e = c.event_pool[c.events_used++];
+    return TMF_OK;
+  }
+  void tick(int stage, double t0) { c.stage_ms[stage] += now_ms() - t0; }
+  bool timing() const { return (c.par.flags & TMF_SWEEP_TIME_KERNELS) != 0; }
+
+  // ------------------------------------------------------------------ batched ops
+  struct Gemm {
+    std::vector<tmf_gemm_desc> d;
+    void add(u64 A, u64 B, u64 C, i64 M, i64 N, i64 K, i64 lda, i64 ldb, i64 ldc) {
+      if (M <= 0 || N <= 0) return;
+      tmf_gemm_desc g;
+      g.A = A, g.B = B, g.C = C;
+      g.M = (int32_t)M, g.N = (int32_t)N, g.K = (int32_t)K;
+      g.lda = (int32_t)std::max<i64>(lda, 1), g.ldb = (int32_t)std::max<i64>(ldb, 1), g.ldc = (int32_t)ldc;
+      d.push_back(g);
+    }
+  };
+  // C = alpha op(A) B + beta C over a list of problems (tile table: longest contractions first)
+  int gemm(int opA, double alpha, double beta, const Gemm& g) {
+    const size_t np = g.d.size();
+    if (np == 0) return TMF_OK;
+    int maxN = 0;
+    for (auto& x : g.d) maxN = std::max(maxN, x.N);
+    const int tn = maxN <= 16 ? 16 : 64;
+    struct Tile {
+      int32_t prob, tm, tnn, z;
+    };
+    std::vector<Tile> tiles;
+    for (size_t i = 0; i < np; ++i) {
+      const i64 tm = cdiv(g.d[i].M, 64), tnn = cdiv(g.d[i].N, tn);
+      for (i64 t = 0; t < tm * tnn; ++t) tiles.push_back(Tile{(int32_t)i, (int32_t)(t % tm), (int32_t)(t / tm), 0});
+    }
+    std::stable_sort(tiles.begin(), tiles.end(), [&](const Tile& a, const Tile& b) { return g.d[a.prob].K > g.d[b.prob].K; });
+    u64 dd, dt;
+    TMF_TRY(up(g.d.data(), np * sizeof(tmf_gemm_desc), &dd));
+    TMF_TRY(up(tiles.data(), tiles.size() * sizeof(Tile), &dt));
+    KernelEvent ev{};
+    if (timing()) {
+      TMF_TRY(new_event(&ev.e0));
+      TMF_TRY(new_event(&ev.e1));
+      HIP_TRY(hipEventRecord(ev.e0, c.s_main));
+    }
+    TMF_TRY(tmf_gemm_batched(c.dtype, opA, alpha, beta, (const tmf_gemm_desc*)dd, (const int32_t*)dt, (int)tiles.size(), tn,
+                             c.s_main));
+    if (timing()) {
+      HIP_TRY(hipEventRecord(ev.e1, c.s_main));
+      double fl = 0;
+      for (auto& x : g.d) fl += (double)x.M * x.N * x.K;
+      ev.flops = fl * (c.cplx ? 8.0 : 2.0);
+      c.gemm_events.push_back(ev);
+    }
+    return TMF_OK;
+  }
+
+  struct Slab {
+    u64 base;
+    i64 rows, ld, c0, c1;
+    u64 scratch;
+  };
+  // blocked classical Gram-Schmidt with re-orthogonalisation (tmf_bcgs_batched)
+  int bcgs(std::vector<Slab> s, int passes, bool cholqr) {
+    s.erase(std::remove_if(s.begin(), s.end(), [](const Slab& x) { return !(x.rows > 0 && x.c1 > x.c0); }), s.end());
+    if (s.empty()) return TMF_OK;
+    std::stable_sort(s.begin(), s.end(), [](const Slab& a, const Slab& b) { return a.rows > b.rows; });
+    i64 span_tot = 0;
+    for (auto& x : s) span_tot += x.c1 - x.c0;
+    void* d_nrm;
+    TMF_TRY(dalloc(span_tot, 8, &d_nrm, true));
+    std::vector<tmf_norms_desc> nd(s.size());
+    std::vector<tmf_bcgs_desc> bd(s.size());
+    i64 noff = 0;
+    for (size_t i = 0; i < s.size(); ++i) {
+      const u64 nrm = (u64)d_nrm + 8 * noff;
+      nd[i].src = s[i].base + (u64)(s[i].c0 * s[i].ld * c.el);
+      nd[i].out = nrm;
+      nd[i].n = (int32_t)s[i].rows, nd[i].c = (int32_t)(s[i].c1 - s[i].c0), nd[i].lds_ = (int32_t)s[i].ld, nd[i].pad = 0;
+      bd[i].base = s[i].base, bd[i].scratch = s[i].scratch, bd[i].norms = nrm;
+      bd[i].rows = (int32_t)s[i].rows, bd[i].ld = (int32_t)s[i].ld, bd[i].c_begin = (int32_t)s[i].c0, bd[i].c_end = (int32_t)s[i].c1;
+      noff += s[i].c1 - s[i].c0;
+    }
+    u64 t_nd, t_bd;
+    TMF_TRY(up_vec(nd, &t_nd));
+    TMF_TRY(tmf_column_norms_batched(c.dtype, (const tmf_norms_desc*)t_nd, (int)s.size(), c.s_main));
+    TMF_TRY(up_vec(bd, &t_bd));
+    const i64 wb = tmf_bcgs_work_bytes(bd.data(), (int)bd.size());
+    void* d_work;
+    TMF_TRY(dalloc(wb, 1, &d_work));
+    return tmf_bcgs_batched(c.dtype, (const tmf_bcgs_desc*)t_bd, bd.data(), (int)bd.size(), passes, cholqr ? 1 : 0, d_work, wb,
+                            c.s_main);
+  }
+
+  struct HSlab {
+    size_t idx;  // position in the caller's arrays
+    u64 base;
+    i64 rows, ld, cols;
+    u64 r;
+    i64 r_ld;
+  };
+  // Householder QR of tall slabs.  r_only: only R^H into s.r (slab destroyed).  Otherwise the orthonormal factor
+  // is built in a scratch whose address is written to out[s.idx] (leading dimension = rows).
+  int house_slab(std::vector<HSlab> s, bool r_only, std::vector<u64>* out) {
+    s.erase(std::remove_if(s.begin(), s.end(), [](const HSlab& x) { return !(x.rows > 0 && x.cols > 0); }), s.end());
+    if (s.empty()) return TMF_OK;
+    std::stable_sort(s.begin(), s.end(), [](const HSlab& a, const HSlab& b) { return a.rows > b.rows; });
+    std::vector<tmf_slab_desc> d(s.size());
+    i64 maxn = 0, maxc = 0;
+    for (auto& x : s) maxn = std::max(maxn, x.rows), maxc = std::max(maxc, x.cols);
+    if (r_only) {
+      for (size_t i = 0; i < s.size(); ++i) {
+        d[i].A = s[i].base, d[i].Q = 0, d[i].R = s[i].r;
+        d[i].n = (int32_t)s[i].rows, d[i].c = (int32_t)s[i].cols, d[i].lda = (int32_t)s[i].ld, d[i].ldq = 1;
+        d[i].ldr = (int32_t)s[i].r_ld, d[i].flags = 1 | 4;
+      }
+    } else {
+      i64 tot = 0;
+      std::vector<i64> o(s.size());
+      for (size_t i = 0; i < s.size(); ++i) {
+        o[i] = tot;
+        tot += (s[i].rows * s[i].cols + 1) & ~(i64)1;
+      }
+      u64 d_q;
+      TMF_TRY(alloc_el(tot + 2, &d_q));
+      for (size_t i = 0; i < s.size(); ++i) {
+        d[i].A = s[i].base, d[i].Q = d_q + (u64)(o[i] * c.el), d[i].R = 0;
+        d[i].n = (int32_t)s[i].rows, d[i].c = (int32_t)s[i].cols, d[i].lda = (int32_t)s[i].ld, d[i].ldq = (int32_t)s[i].rows;
+        d[i].ldr = 1, d[i].flags = 2;
+        (*out)[s[i].idx] = d[i].Q;
+      }
+    }
+    u64 t_d;
+    TMF_TRY(up_vec(d, &t_d));
+    return tmf_house_slab_batched(c.dtype, (const tmf_slab_desc*)t_d, (int)d.size(), (int)maxn, (int)maxc, c.s_main);
+  }
+
+  // One-sided Jacobi per problem (p > 0 only).  left_only: U receives the normalised left singular vectors.
+  int jacobi(const std::vector<u64>& X, const std::vector<u64>& V, const std::vector<u64>& s, const std::vector<u64>* count,
+             double thresh2, const std::vector<i64>& p, bool left_only) {
+    std::vector<tmf_jacobi_desc> d;
+    i64 maxp = 0;
+    for (size_t i = 0; i < p.size(); ++i) maxp = std::max(maxp, p[i]);
+    if (maxp == 0) return TMF_OK;
+    const bool big = maxp > 64;
+    const bool outU = left_only || big;
+    std::vector<i64> pp;
+    for (size_t i = 0; i < p.size(); ++i) {
+      if (p[i] <= 0) continue;
+      tmf_jacobi_desc j{};
+      j.X = X[i];
+      (outU ? j.U : j.V) = V[i];
+      j.s = s[i];
+      j.count = count ? (*count)[i] : 0;
+      j.thresh2 = thresh2;
+      j.p = (int32_t)p[i], j.ldx = (int32_t)std::max<i64>(p[i], 1);
+      j.ldv = outU ? 0 : (int32_t)std::max<i64>(p[i], 1);
+      j.ldu = outU ? (int32_t)std::max<i64>(p[i], 1) : 1;
+      d.push_back(j);
+      pp.push_back(p[i]);
+    }
+    void* d_sw;
+    TMF_TRY(dalloc((i64)d.size(), 4, &d_sw, true));
+    c.sweep_counters.push_back((int32_t*)d_sw);
+    c.sweep_counts_n.push_back((i64)d.size());
+    if (big) {
+      if (!left_only) {  // workspace for the accumulated rotations
+        i64 tot = 0;
+        for (auto q : pp) tot += q * q;
+        u64 d_ws;
+        TMF_TRY(alloc_el(tot, &d_ws));
+        i64 o = 0;
+        for (size_t i = 0; i < d.size(); ++i) {
+          d[i].V = d_ws + (u64)(o * c.el), d[i].ldv = (int32_t)pp[i];
+          o += pp[i] * pp[i];
+        }
+      }
+      u64 dd;
+      TMF_TRY(up_vec(d, &dd));
+      return tmf_jacobi_block_batched(c.dtype, left_only ? 0 : 1, (const tmf_jacobi_desc*)dd, (int)d.size(), (int)maxp,
+                                      (int32_t*)d_sw, c.s_main);
+    }
+    u64 dd;
+    TMF_TRY(up_vec(d, &dd));
+    return left_only ? tmf_svd_left_batched(c.dtype, (const tmf_jacobi_desc*)dd, (int)d.size(), (int)maxp, (int32_t*)d_sw, c.s_main)
+                     : tmf_jacobi_batched(c.dtype, (const tmf_jacobi_desc*)dd, (int)d.size(), (int)maxp, (int32_t*)d_sw, c.s_main);
+  }
+
+  // Y_i = A_i Omega (kind 'A') or F_i Omega (kind 'F') for all cut sides at once through running sums
+  int nested(char kind, u64 Omp, i64 ldo, const std::vector<u64>& dest, const std::vector<i64>& ncol) {
+    const i64 D = c.L;
+    tmf_nested_desc descs[2];
+    int nd = 0, maxc_all = 0;
+    for (int sd = 0; sd < 2; ++sd) {
+      std::vector<u64> tab_d(D + 1, 0);
+      std::vector<int32_t> tab_n(D + 1, 0), tab_l(D + 1, 1);
+      i64 xlo = D + 1, xhi = -1, maxc = 0;
+      for (i64 i = 0; i < c.ncs; ++i) {
+        if (c.cs_side[i] != sd || ncol[i] <= 0) continue;
+        const i64 x = c.cs_b[i];
+        tab_d[x] = dest[i], tab_n[x] = (int32_t)ncol[i], tab_l[x] = (int32_t)c.ld1[i];
+        xlo = std::min(xlo, x), xhi = std::max(xhi, x), maxc = std::max(maxc, ncol[i]);
+      }
+      if (xhi < 0) continue;
+      u64 t_d, t_n, t_l;
+      TMF_TRY(up_vec(tab_d, &t_d));
+      TMF_TRY(up_vec(tab_n, &t_n));
+      TMF_TRY(up_vec(tab_l, &t_l));
+      const bool suffix = (kind == 'A') ? (sd == 1) : (sd == 0);
+      tmf_nested_desc& q = descs[nd++];
+      q.C = (u64)c.d_C, q.Omega = Omp, q.dest = t_d, q.ncol = t_n, q.ld = t_l;
+      q.D = (int32_t)D, q.ldc = (int32_t)D, q.ldo = (int32_t)ldo, q.suffix = suffix ? 1 : 0, q.rows_ge = sd;
+      q.x_lo = (int32_t)xlo, q.x_hi = (int32_t)xhi, q.maxc = (int32_t)maxc;
+      maxc_all = std::max<int>(maxc_all, (int)maxc);
+    }
+    if (nd == 0) return TMF_OK;
+    u64 t_desc;
+    TMF_TRY(up(descs, nd * sizeof(tmf_nested_desc), &t_desc));
+    return tmf_nested_products_batched(c.dtype, (const tmf_nested_desc*)t_desc, nd, (int)D, maxc_all, c.s_main);
+  }
+
+  // normalised column copies (tmf_normalise_columns_batched)
+  int colcopy(std::vector<tmf_colnorm_desc>& d) {
+    d.erase(std::remove_if(d.begin(), d.end(), [](const tmf_colnorm_desc& x) { return !(x.n > 0 && x.c > 0); }), d.end());
+    if (d.empty()) return TMF_OK;
+    u64 dd;
+    TMF_TRY(up_vec(d, &dd));
+    return tmf_normalise_columns_batched(c.dtype, (const tmf_colnorm_desc*)dd, (int)d.size(), c.s_main);
+  }
+
+  // ------------------------------------------------------------------ begin
+  int begin(const void* C, const tmf_sweep_params* par) {
+    HIP_TRY(hipSetDevice(c.device));
+    c.t_begin = now_ms();
+    memset(c.stage_ms, 0, sizeof(c.stage_ms));
+    HIP_TRY(hipStreamSynchronize(c.s_main));  // staging arena and temporaries of the previous sweep are free
+    c.dev.reset();
+    c.stage.reset();
+    c.events_used = 0;
+    c.gemm_events.clear();
+    c.det_events.clear();
+    c.sweep_counters.clear();
+    c.sweep_counts_n.clear();
+    c.begun = c.have_sites = false;
+    c.par = *par;
+    c.have_sectors = par->sectors != nullptr;
+    c.sectors.clear();
+    if (c.have_sectors) c.sectors.assign(par->sectors, par->sectors + par->n_sectors);
+    c.sectors.push_back(0);  // never empty: data() stays a valid non-null pointer for "no sector allowed"
+    c.par.sectors = nullptr;
+    const i64 L = par->L;
+    if (L <= 0 || par->site_lo < 0 || par->site_hi > L || par->site_lo >= par->site_hi || par->ortho_center < 0 ||
+        par->ortho_center > L || !(par->svd_min > 0 && par->svd_min < 1) || !(par->degeneracy_tol > 0)) {
+      set_error("tmf_sweep_begin: bad parameters (L = %lld, sites [%lld, %lld), centre %lld)", (long long)L,
+                (long long)par->site_lo, (long long)par->site_hi, (long long)par->ortho_center);
+      return TMF_E_ARG;
+    }
+    c.L = L, c.oc = par->ortho_center, c.s_lo = par->site_lo, c.s_hi = par->site_hi;
+    c.cplx = par->is_complex != 0;
+    c.dtype = c.cplx ? TMF_C128 : TMF_F64;
+    c.el = c.cplx ? 16 : 8;
+    c.cutoff = par->svd_min * par->svd_min;  // slater.py:318
+    c.thr2 = c.cutoff * (1.0 - c.cutoff);
+
+    double t0 = now_ms();
+    const size_t cbytes = (size_t)L * L * c.el;
+    void* p;
+    TMF_TRY(c.dev.alloc(cbytes, &p));
+    c.d_C = (char*)p;
+    c.diag.assign(L, 0.0);
+    if (par->flags & TMF_SWEEP_C_ON_DEVICE) {
+      c.d_Crm = (char*)C;
+      // the diagonal (particle counts per cut) comes down with a strided copy
+      TMF_TRY(c.fetch.ensure((size_t)L * 16));
+      HIP_TRY(hipMemcpy2DAsync(c.fetch.p, c.el, C, (size_t)(L + 1) * c.el, c.el, L, hipMemcpyDeviceToHost, c.s_main));
+      HIP_TRY(hipStreamSynchronize(c.s_main));
+      for (i64 i = 0; i < L; ++i) c.diag[i] = ((const double*)c.fetch.p)[i * (c.cplx ? 2 : 1)];
+    } else {
+      TMF_TRY(c.dev.alloc(cbytes, &p));
+      c.d_Crm = (char*)p;
+      TMF_TRY(c.c_pin.ensure(cbytes));
+      memcpy(c.c_pin.p, C, cbytes);
+      HIP_TRY(hipMemcpyAsync(c.d_Crm, c.c_pin.p, cbytes, hipMemcpyHostToDevice, c.s_main));
+      const double* h = (const double*)C;
+      for (i64 i = 0; i < L; ++i) c.diag[i] = h[(size_t)i * (L + 1) * (c.cplx ? 2 : 1)];
+    }
+    TMF_TRY(tmf_transpose(c.dtype, c.d_Crm, c.d_C, (int)L, c.s_main));
+    tick(ST_UPLOAD, t0);
+
+    // ---- cut-side problems ----
+    std::vector<char> need((size_t)(L + 1) * 2, 0);
+    const i64 oc = c.oc;
+    for (i64 i = c.s_lo; i < c.s_hi; ++i) {
+      const int sd = i < oc ? 0 : 1;
+      need[(size_t)i * 2 + sd] = 1, need[(size_t)(i + 1) * 2 + sd] = 1;
+    }
+    if (need[(size_t)oc * 2 + 1] || (c.s_lo <= oc && oc <= c.s_hi))
+      need[(size_t)oc * 2 + 0] = need[(size_t)oc * 2 + 1] = 1;  // the centre's right orbitals are paired with its left ones
+    c.cs_b.clear(), c.cs_side.clear();
+    for (i64 b = 0; b <= L; ++b)
+      for (int sd = 0; sd < 2; ++sd)
+        if (need[(size_t)b * 2 + sd]) c.cs_b.push_back(b), c.cs_side.push_back(sd);
+    c.ncs = (i64)c.cs_b.size();
+    c.n.resize(c.ncs), c.m.resize(c.ncs), c.ld1.resize(c.ncs), c.blk.resize(c.ncs), c.off.resize(c.ncs), c.doE.resize(c.ncs);
+    c.has_centre = need[(size_t)oc * 2 + 0] != 0;
+    c.centre_L = c.centre_R = -1;
+    for (i64 i = 0; i < c.ncs; ++i) {
+      const i64 b = c.cs_b[i];
+      const bool left = c.cs_side[i] == 0;
+      c.n[i] = left ? b : L - b;
+      c.m[i] = L - c.n[i];
+      c.ld1[i] = std::max<i64>(c.n[i], 1);
+      c.blk[i] = (u64)c.d_C + (u64)((left ? 0 : (b + b * L)) * c.el);  // A = C_LL or C_RR
+      c.off[i] = (u64)c.d_C + (u64)((left ? b * L : b) * c.el);        // F (n x m)
+      c.doE[i] = (c.n[i] > 0 && c.m[i] > 0) ? 1 : 0;
+      if (c.has_centre && b == oc) (left ? c.centre_L : c.centre_R) = i;
+    }
+    // the right side of the centre cut is paired with the left side through C_RL (block_svd, slater.py:407)
+    if (c.has_centre) c.doE[c.centre_R] = 0;
+    c.begun = true;
+    return TMF_OK;
+  }
+
+  // ------------------------------------------------------------------ entangled stage (E1-E7)
+  int entangled(int P, int iterations, double* worst_out, int32_t* sat_out, int32_t* weak_out, int32_t* sweeps_out,
+                i64* bad_cut) {
+    if (!c.begun) {
+      set_error("tmf_sweep_entangled: no sweep in progress");
+      return TMF_E_ARG;
+    }
+    const double t0 = now_ms();
+    const i64 L = c.L, el = c.el, ncs = c.ncs;
+    c.P = P;
+    u64 d_Om;
+    TMF_TRY(alloc_el(L * P, &d_Om));
+    TMF_TRY(tmf_fill_normal(c.dtype, (void*)d_Om, L * P, 0x5EED1, c.s_main));
+    std::vector<i64>& p = c.p;
+    p.assign(ncs, 0);
+    std::vector<char> full(ncs, 0);
+    for (i64 i = 0; i < ncs; ++i) {
+      const i64 mn = std::min(c.n[i], c.m[i]);
+      p[i] = c.doE[i] ? std::min<i64>(P, mn) : 0;
+      full[i] = (c.doE[i] && p[i] == P && P < mn) ? 1 : 0;  // cuts the range finder truncates
+    }
+    std::vector<i64> oY(ncs), oB(ncs), oR(ncs);
+    c.oS.assign(ncs, 0);
+    i64 tY = 0, tB = 0, tR = 0, tS = 0;
+    for (i64 i = 0; i < ncs; ++i) {
+      oY[i] = tY, oB[i] = tB, oR[i] = tR, c.oS[i] = tS;
+      tY += c.n[i] * p[i], tB += c.m[i] * p[i], tR += p[i] * p[i], tS += p[i];
+    }
+    u64 d_Y, d_U0, d_W1, d_Bt, d_Q2, d_R, d_Z, d_T, d_X, d_scr;
+    TMF_TRY(alloc_el(tY, &d_Y)); TMF_TRY(alloc_el(tY, &d_U0)); TMF_TRY(alloc_el(tY, &d_W1));
+    TMF_TRY(alloc_el(tB, &d_Bt)); TMF_TRY(alloc_el(tB, &d_Q2));
+    TMF_TRY(alloc_el(tR, &d_R)); TMF_TRY(alloc_el(tR, &d_Z)); TMF_TRY(alloc_el(tR, &d_T)); TMF_TRY(alloc_el(tR, &d_X));
+    void *d_sig, *d_e, *d_cnt;
+    TMF_TRY(dalloc(tS, 8, &d_sig, true)); TMF_TRY(dalloc(tS, 8, &d_e, true)); TMF_TRY(dalloc(ncs, 4, &d_cnt, true));
+    TMF_TRY(alloc_el(ncs * P * PANEL_W, &d_scr));
+    std::vector<u64> Yp(ncs), U0p(ncs), W1p(ncs), Btp(ncs), Q2p(ncs), Rp(ncs), Zp(ncs), Tp(ncs), Xp(ncs), sigp(ncs), ep(ncs),
+        cntp(ncs), scrp(ncs), omp(ncs);
+    for (i64 i = 0; i < ncs; ++i) {
+      Yp[i] = d_Y + (u64)(oY[i] * el), U0p[i] = d_U0 + (u64)(oY[i] * el), W1p[i] = d_W1 + (u64)(oY[i] * el);
+      Btp[i] = d_Bt + (u64)(oB[i] * el), Q2p[i] = d_Q2 + (u64)(oB[i] * el);
+      Rp[i] = d_R + (u64)(oR[i] * el), Zp[i] = d_Z + (u64)(oR[i] * el), Tp[i] = d_T + (u64)(oR[i] * el), Xp[i] = d_X + (u64)(oR[i] * el);
+      sigp[i] = (u64)d_sig + (u64)(c.oS[i] * 8), ep[i] = (u64)d_e + (u64)(c.oS[i] * 8);
+      cntp[i] = (u64)d_cnt + (u64)(i * 4);
+      scrp[i] = d_scr + (u64)(i * P * PANEL_W * el);
+      omp[i] = d_Om + (u64)((c.cs_side[i] == 0 ? c.cs_b[i] : 0) * el);  // rows of Omega on the other side
+    }
+    // E1: Y = F Omega
+    TMF_TRY(nested('F', d_Om, L, Yp, p));
+    // E2: Q = qr(Y)
+    const i64 slab_rows = c.cplx ? 1024 : 2048;  // row limit of the slab kernel (registers)
+    i64 maxp = 0, maxm = 0;
+    for (i64 i = 0; i < ncs; ++i)
+      if (c.doE[i]) maxp = std::max(maxp, p[i]), maxm = std::max(maxm, c.m[i]);
+    const bool house_ok = !(c.par.flags & TMF_SWEEP_RANGE_BCGS) && maxp <= 64;
+    const bool house = house_ok && maxm <= slab_rows;  // the longer slabs: F^H Q is m x p
+    auto rqr = [&](std::vector<u64>& ptr, const std::vector<i64>& rows) -> int {
+      i64 maxr = 0;
+      for (i64 i = 0; i < ncs; ++i)
+        if (c.doE[i]) maxr = std::max(maxr, rows[i]);
+      if (house_ok && maxr <= slab_rows) {  // Q stays in the buffer the kernel builds it in (no copy back)
+        std::vector<HSlab> s;
+        for (i64 i = 0; i < ncs; ++i)
+          if (c.doE[i]) s.push_back(HSlab{(size_t)i, ptr[i], rows[i], rows[i], p[i], 0, 0});
+        return house_slab(s, false, &ptr);
+      }
+      std::vector<Slab> s;
+      for (i64 i = 0; i < ncs; ++i)
+        if (c.doE[i]) s.push_back(Slab{ptr[i], rows[i], rows[i], 0, p[i], scrp[i]});
+      return bcgs(s, 3, false);
+    };
+    TMF_TRY(rqr(Yp, c.n));
+    // E3: B^H = F^H Q (m x p); R^H.  With `iterations`: one round of orthogonal (subspace) iteration first - the
+    // range-finder error of a direction is ~ sigma_(p+1) / sigma_i; Y <- F orth(F^H Q) cubes that ratio.
+    bool r_from_kernel = false;
+    for (int it = 0; it <= iterations; ++it) {
+      Gemm g;
+      for (i64 i = 0; i < ncs; ++i) g.add(c.off[i], Yp[i], Btp[i], c.m[i], p[i], c.n[i], L, c.ld1[i], std::max<i64>(c.m[i], 1));
+      TMF_TRY(gemm(1, 1.0, 0.0, g));
+      if (house && iterations == 0) {
+        // only R^H = (F^H Q)^H Q2 is needed below: factor B^H in place and take R^H from the kernel
+        HIP_TRY(hipMemsetAsync((void*)d_R, 0, (size_t)std::max<i64>(tR, 1) * el, c.s_main));
+        std::vector<HSlab> s;
+        for (i64 i = 0; i < ncs; ++i)
+          if (c.doE[i]) s.push_back(HSlab{(size_t)i, Btp[i], c.m[i], std::max<i64>(c.m[i], 1), p[i], Rp[i], std::max<i64>(p[i], 1)});
+        TMF_TRY(house_slab(s, true, nullptr));
+        r_from_kernel = true;
+        break;
+      }
+      HIP_TRY(hipMemcpyAsync((void*)d_Q2, (void*)d_Bt, (size_t)std::max<i64>(tB, 1) * el, hipMemcpyDeviceToDevice, c.s_main));
+      for (i64 i = 0; i < ncs; ++i) Q2p[i] = d_Q2 + (u64)(oB[i] * el);
+      TMF_TRY(rqr(Q2p, c.m));
+      if (it < iterations) {
+        Gemm g2;
+        for (i64 i = 0; i < ncs; ++i) g2.add(c.off[i], Q2p[i], Yp[i], c.n[i], p[i], c.m[i], L, std::max<i64>(c.m[i], 1), c.ld1[i]);
+        TMF_TRY(gemm(0, 1.0, 0.0, g2));
+        TMF_TRY(rqr(Yp, c.n));
+      }
+    }
+    if (!r_from_kernel) {
+      Gemm g;
+      for (i64 i = 0; i < ncs; ++i)
+        g.add(Btp[i], Q2p[i], Rp[i], p[i], p[i], c.m[i], std::max<i64>(c.m[i], 1), std::max<i64>(c.m[i], 1), std::max<i64>(p[i], 1));
+      TMF_TRY(gemm(1, 1.0, 0.0, g));
+    }
+    // E4: Jacobi SVD of R^H: left singular vectors Z, sigma; columns below the threshold zeroed
+    TMF_TRY(jacobi(Rp, Zp, sigp, &cntp, c.thr2, p, true));
+    {  // E5: U0 = Q Z
+      Gemm g;
+      for (i64 i = 0; i < ncs; ++i) g.add(Yp[i], Zp[i], U0p[i], c.n[i], p[i], p[i], c.ld1[i], std::max<i64>(p[i], 1), c.ld1[i]);
+      TMF_TRY(gemm(0, 1.0, 0.0, g));
+    }
+    {  // E6: T = U0^H (A U0), Jacobi eigen-decomposition
+      Gemm g1, g2;
+      for (i64 i = 0; i < ncs; ++i) {
+        g1.add(c.blk[i], U0p[i], W1p[i], c.n[i], p[i], c.n[i], L, c.ld1[i], c.ld1[i]);
+        g2.add(U0p[i], W1p[i], Tp[i], p[i], p[i], c.n[i], c.ld1[i], c.ld1[i], std::max<i64>(p[i], 1));
+      }
+      TMF_TRY(gemm(0, 1.0, 0.0, g1));
+      TMF_TRY(gemm(1, 1.0, 0.0, g2));
+      TMF_TRY(jacobi(Tp, Xp, ep, nullptr, 0.0, p, false));
+    }
+    {  // E7: U_E = U0 X (reuses the Y buffer; Q is no longer needed)
+      Gemm g;
+      for (i64 i = 0; i < ncs; ++i) g.add(U0p[i], Xp[i], Yp[i], c.n[i], p[i], p[i], c.ld1[i], std::max<i64>(p[i], 1), c.ld1[i]);
+      TMF_TRY(gemm(0, 1.0, 0.0, g));
+    }
+    c.UEp = Yp;
+    // ---- host round trip 1: singular values, counts, Ritz values, sweep counts ----
+    size_t nsw = 0;
+    for (auto q : c.sweep_counts_n) nsw += (size_t)q;
+    const size_t b_sig = (size_t)std::max<i64>(tS, 1) * 8, b_cnt = (size_t)ncs * 4;
+    TMF_TRY(c.fetch.ensure(2 * b_sig + b_cnt + nsw * 4 + 64));
+    char* h = c.fetch.p;
+    HIP_TRY(hipMemcpyAsync(h, d_sig, b_sig, hipMemcpyDeviceToHost, c.s_main));
+    HIP_TRY(hipMemcpyAsync(h + b_sig, d_e, b_sig, hipMemcpyDeviceToHost, c.s_main));
+    HIP_TRY(hipMemcpyAsync(h + 2 * b_sig, d_cnt, b_cnt, hipMemcpyDeviceToHost, c.s_main));
+    size_t o = 2 * b_sig + ((b_cnt + 7) & ~(size_t)7);
+    for (size_t j = 0; j < c.sweep_counters.size(); ++j) {
+      HIP_TRY(hipMemcpyAsync(h + o, c.sweep_counters[j], (size_t)c.sweep_counts_n[j] * 4, hipMemcpyDeviceToHost, c.s_main));
+      o += (size_t)c.sweep_counts_n[j] * 4;
+    }
+    tick(ST_E, t0);
+    const double tw = now_ms();
+    HIP_TRY(hipStreamSynchronize(c.s_main));
+    tick(ST_WAIT_E, tw);
+    c.h_sig.assign((const double*)h, (const double*)h + std::max<i64>(tS, 1));
+    c.h_e.assign((const double*)(h + b_sig), (const double*)(h + b_sig) + std::max<i64>(tS, 1));
+    c.h_cnt.assign((const int32_t*)(h + 2 * b_sig), (const int32_t*)(h + 2 * b_sig) + ncs);
+    int32_t maxsw = 0;
+    {
+      const int32_t* sw = (const int32_t*)(h + 2 * b_sig + ((b_cnt + 7) & ~(size_t)7));
+      for (size_t j = 0; j < nsw; ++j) maxsw = std::max(maxsw, sw[j]);
+    }
+    c.sweep_counters.clear();
+    c.sweep_counts_n.clear();
+    double worst = 0.0;
+    int32_t sat = 0, weak = 0;
+    i64 bad = -1;
+    for (i64 i = 0; i < ncs; ++i) {
+      if (!full[i]) continue;
+      const double sP = c.h_sig[c.oS[i] + P - 1];
+      worst = std::max(worst, sP);
+      if (c.h_cnt[i] >= p[i]) {
+        sat = 1;
+        if (bad < 0) bad = c.cs_b[i];
+      }
+      if (iterations > 0 && sP > 4.6e-4 * sqrt(c.thr2)) {  // (s_P / sqrt(thr2))^3 > 1e-10 even after the iteration
+        weak = 1;
+        bad = c.cs_b[i];
+      }
+    }
+    c.range_floor = worst;
+    c.range_iterations = iterations;
+    *worst_out = worst, *sat_out = sat, *weak_out = weak, *sweeps_out = maxsw;
+    if (bad_cut) *bad_cut = bad;
+    return TMF_OK;
+  }
+
+  // ------------------------------------------------------------------ classification (host round trip 1)
+  void classify() {
+    const double t0 = now_ms();
+    const i64 ncs = c.ncs, L = c.L;
+    std::vector<double> csum(L + 1, 0.0);
+    for (i64 i = 0; i < L; ++i) csum[i + 1] = csum[i] + c.diag[i];
+    c.n_fermion = (i64)nearbyint(csum[L]);  // slater.py:414
+    c.k.assign(ncs, 0), c.nf.assign(ncs, 0), c.ent0.assign(ncs, 0);
+    c.e_side.assign(ncs, {});
+    std::vector<double> esum(ncs, 0.0);
+    for (i64 i = 0; i < ncs; ++i) {
+      if (!c.doE[i]) continue;
+      const i64 cnt = c.h_cnt[i];
+      const double* e = c.h_e.data() + c.oS[i];
+      i64 x_hi = 0, x_lo = 0;
+      for (i64 j = 0; j < cnt; ++j) {
+        if (e[j] >= 1.0 - c.cutoff) ++x_hi;  // kept but 'filled' by slater.py:350
+        if (e[j] < c.cutoff) ++x_lo;
+      }
+      c.ent0[i] = x_hi;
+      c.k[i] = cnt - x_hi - x_lo;
+      c.e_side[i].assign(e + x_hi, e + x_hi + c.k[i]);
+      double s = 0;
+      for (double v : c.e_side[i]) s += v;
+      esum[i] = s;
+    }
+    if (c.has_centre) {  // right-side eigenvalues are 1 - e_L reversed (slater.py:386 convention)
+      const i64 cl = c.centre_L, cr = c.centre_R;
+      c.k[cr] = c.k[cl];
+      c.e_side[cr].resize(c.k[cl]);
+      double s = 0;
+      for (i64 j = 0; j < c.k[cl]; ++j) c.e_side[cr][j] = 1.0 - c.e_side[cl][c.k[cl] - 1 - j], s += c.e_side[cr][j];
+      esum[cr] = s;
+    }
+    for (i64 i = 0; i < ncs; ++i) {
+      const double tr = c.cs_side[i] == 0 ? csum[c.cs_b[i]] : csum[L] - csum[c.cs_b[i]];
+      const i64 v = (i64)nearbyint(tr - esum[i]);
+      c.nf[i] = std::min(std::max<i64>(v, 0), c.n[i] - c.k[i]);
+    }
+    tick(ST_CLASSIFY, t0);
+  }
+
+  // ------------------------------------------------------------------ host phase: enumeration + site preparation
+  int host_phase() {
+    double t0 = now_ms();
+    const i64 L = c.L, ncs = c.ncs;
+    std::vector<i64> side_idx((size_t)(L + 1) * 2, -1);
+    for (i64 i = 0; i < ncs; ++i) side_idx[(size_t)c.cs_b[i] * 2 + c.cs_side[i]] = i;
+    c.my_cuts.clear();
+    for (i64 i = 0; i < ncs; ++i)
+      if (c.my_cuts.empty() || c.my_cuts.back() != c.cs_b[i]) c.my_cuts.push_back(c.cs_b[i]);
+    const i64 ncut = c.ncut = (i64)c.my_cuts.size();
+    c.cpos.assign(L + 1, -1);
+    for (i64 j = 0; j < ncut; ++j) c.cpos[c.my_cuts[j]] = j;
+    c.kk_cut.assign(ncut, 0), c.nfl.assign(ncut, 0), c.nfr.assign(ncut, 0), c.e_off.assign(ncut, 0);
+    std::vector<i64> src(ncut);
+    std::vector<char> hasL(ncut);
+    i64 tot = 0;
+    for (i64 j = 0; j < ncut; ++j) {
+      const i64 iL = side_idx[(size_t)c.my_cuts[j] * 2], iR = side_idx[(size_t)c.my_cuts[j] * 2 + 1];
+      hasL[j] = iL >= 0;
+      src[j] = hasL[j] ? iL : iR;  // the side whose eigenvalues define e_left
+      c.kk_cut[j] = (int32_t)c.k[src[j]];
+      const i64 nf_src = c.nf[src[j]];
+      const i64 other = c.n_fermion - c.kk_cut[j] - nf_src;  // slater.py:167 / :172
+      c.nfl[j] = (int32_t)(hasL[j] ? nf_src : (iR >= 0 ? other : 0));
+      c.nfr[j] = (int32_t)(hasL[j] ? (iR >= 0 ? c.nf[iR] : other) : nf_src);
+      c.e_off[j] = tot;
+      tot += c.kk_cut[j];
+    }
+    // left eigenvalues of every cut, flat: from the left block as they are, from the right block as 1 - e reversed
+    c.e_pool.assign(tot + 1, 0.0);
+    for (i64 j = 0; j < ncut; ++j) {
+      const std::vector<double>& es = c.e_side[src[j]];
+      const i64 kk = c.kk_cut[j];
+      for (i64 t = 0; t < kk; ++t) c.e_pool[c.e_off[j] + t] = hasL[j] ? es[t] : 1.0 - es[kk - 1 - t];
+    }
+    i64 cap = c.par.chi_max > 0 ? c.par.chi_max + 1 : 4096;
+    const int threads = std::max(1, c.par.host_threads);
+    for (;;) {
+      // (no re-zeroing: every kept entry is written by the enumeration; the pages are faulted in by the first sweep)
+      c.c_sets.resize((size_t)ncut * cap * 2), c.c_lam.resize((size_t)ncut * cap), c.c_q.resize((size_t)ncut * cap);
+      c.c_chi.assign(ncut, 0), c.c_chk.assign(ncut, 0);
+      const int st = tmf_cut_vectors_batch((int)ncut, c.e_pool.data(), c.e_off.data(), c.kk_cut.data(), c.nfl.data(),
+                                           c.par.chi_max > 0 ? c.par.chi_max : 0, c.par.svd_min, c.par.degeneracy_tol,
+                                           c.have_sectors ? c.sectors.data() : nullptr,
+                                           c.have_sectors ? (int)c.sectors.size() - 1 : 0, cap, c.c_sets.data(), c.c_lam.data(), c.c_q.data(), c.c_chi.data(),
+                                           c.c_chk.data(), threads);
+      const i64 mx = *std::max_element(c.c_chi.begin(), c.c_chi.end());
+      if (st == TMF_E_LIMIT && c.par.chi_max <= 0 && mx > cap) {
+        cap = mx + 1;  // unlimited chi: grow the per-cut capacity and redo
+        continue;
+      }
+      TMF_TRY(st);
+      break;
+    }
+    c.cap = cap;
+    for (i64 j = 0; j < ncut; ++j)
+      if (c.c_chi[j] == 0) {
+        set_error("No Schmidt vectors left after filtering by `trunc_par.sectors`!");  // slater.py:668
+        return TMF_E_ARG;
+      }
+    tick(ST_ENUM, t0);
+
+    // ---- per-site integer preparation ----
+    t0 = now_ms();
+    const i64 ns = c.ns = c.s_hi - c.s_lo;
+    c.jobs.assign(ns, tmf_site_job{});
+    c.souts.assign(ns, tmf_site_out{});
+    c.mode.assign(ns, 0), c.chi_b.assign(ns, 0), c.chi_k.assign(ns, 0);
+    i64 rs = 0, cs = 0, br = 0, sc = 0, ix = 0;
+    for (i64 j = 0; j < ns; ++j) {
+      const i64 site = c.s_lo + j;
+      const int md = site >= c.oc ? 1 : 0;
+      const i64 bb = md == 0 ? site : site + 1, kb = md == 0 ? site + 1 : site;
+      const i64 ib = side_idx[(size_t)bb * 2 + md], ik = side_idx[(size_t)kb * 2 + md];
+      const i64 cb = c.cpos[bb], ck = c.cpos[kb];
+      c.mode[j] = md;
+      c.chi_b[j] = c.c_chi[cb], c.chi_k[j] = c.c_chi[ck];
+      tmf_site_job& q = c.jobs[j];
+      q.mode = md, q.cut_b = (int32_t)cb, q.cut_k = (int32_t)ck;
+      q.k_b = (int32_t)c.k[ib], q.nf_b = (int32_t)c.nf[ib], q.k_k = (int32_t)c.k[ik], q.nf_k = (int32_t)c.nf[ik];
+      const i64 mb_cap = c.k[ib] + c.nf[ib] + 1, mk_cap = std::max<i64>(c.k[ik] + c.nf[ik], 1), sec_cap = c.k[ik] + 2;
+      const i64 n_bound = std::min<i64>(255, c.k[ik] + std::max<i64>(0, c.nf[ik] + c.k[ik] - c.nf[ib]) + 1);
+      const i64 idx_cap = (2 * c.chi_b[j] + c.chi_k[j]) * n_bound + 16;
+      q.sec_cap = (int32_t)sec_cap;
+      q.row_off = rs, q.col_off = cs, q.bra_off = br, q.sec_off = sc, q.idx_off = ix, q.idx_cap = idx_cap;
+      rs += mb_cap, cs += mk_cap, br += 2 * c.chi_b[j], sc += sec_cap, ix += idx_cap;
+    }
+    c.sc_tot = sc, c.br_tot = br, c.ix_tot = ix;
+    c.row_sel.assign(rs + 1, 0), c.row_sign.assign(rs + 1, 0), c.col_sel.assign(cs + 1, 0), c.col_sign.assign(cs + 1, 0);
+    c.bra_p.resize(br + 1), c.bra_alpha.resize(br + 1);   // every merged row is written by the site preparation
+    c.sec_buf.assign(sc + 1, tmf_sector{});
+    TMF_TRY(c.pool_pin.ensure((size_t)ix + 1));  // uploaded straight from page-locked memory
+    TMF_TRY(tmf_site_prepare_batch((int)ns, c.jobs.data(), c.c_sets.data(), c.c_q.data(), c.c_chi.data(), cap, c.row_sel.data(),
+                                   c.row_sign.data(), c.col_sel.data(), c.col_sign.data(), c.bra_p.data(), c.bra_alpha.data(),
+                                   c.sec_buf.data(), (uint8_t*)c.pool_pin.p, c.souts.data(), threads));
+    tick(ST_SITEPREP, t0);
+    return TMF_OK;
+  }
+
+  // ------------------------------------------------------------------ F: orbital matrices V = [U_E (k) | Q_f (nf)]
+  std::vector<i64> ncolV;
+  std::vector<u64> Vp;
+  int filled_stage() {
+    const double t0 = now_ms();
+    const i64 ncs = c.ncs, L = c.L, el = c.el;
+    ncolV.assign(ncs, 0);
+    Vp.assign(ncs, 0);
+    i64 tV = 0;
+    std::vector<i64> oV(ncs);
+    for (i64 i = 0; i < ncs; ++i) {
+      ncolV[i] = c.k[i] + c.nf[i];
+      oV[i] = tV;
+      tV += c.n[i] * ncolV[i];
+    }
+    u64 d_V;
+    TMF_TRY(alloc_el(tV, &d_V));
+    for (i64 i = 0; i < ncs; ++i) Vp[i] = d_V + (u64)(oV[i] * el);
+    {  // entangled columns (renormalised copy)
+      std::vector<tmf_colnorm_desc> d;
+      for (i64 i = 0; i < ncs; ++i) {
+        if (!c.doE[i]) continue;
+        tmf_colnorm_desc q{};
+        q.src = c.UEp[i] + (u64)(c.ent0[i] * c.ld1[i] * el), q.dst = Vp[i];
+        q.n = (int32_t)c.n[i], q.c = (int32_t)c.k[i], q.lds_ = (int32_t)c.ld1[i], q.ldd = (int32_t)c.ld1[i];
+        d.push_back(q);
+      }
+      TMF_TRY(colcopy(d));
+    }
+    // centre-right: C_RL U_E(left), reversed, odd columns flipped (slater.py:407-410)
+    if (c.has_centre && c.k[c.centre_L] > 0 && c.n[c.centre_R] > 0) {
+      const i64 cl = c.centre_L, cr = c.centre_R;
+      const i64 kc = c.k[cl], nR = c.n[cr], ldR = c.ld1[cr];
+      u64 d_pair, d_T, d_scrc;
+      TMF_TRY(alloc_el(nR * kc, &d_pair));
+      Gemm g;
+      g.add(c.off[cr], Vp[cl], d_pair, nR, kc, c.m[cr], L, c.ld1[cl], ldR);
+      TMF_TRY(gemm(0, 1.0, 0.0, g));
+      // The partners of weak orbitals (sigma -> 1e-6) carry errors ~1e-7 from the division by sigma, so they are
+      // Gram-Schmidt orthonormalised in order of DECREASING sigma: strong partners stay as computed, weak ones are
+      // corrected against them.  Column permutations are k x k (signed) permutation GEMMs.
+      const std::vector<double>& eL = c.e_side[cl];
+      std::vector<i64> order(kc);
+      std::iota(order.begin(), order.end(), 0);
+      std::stable_sort(order.begin(), order.end(), [&](i64 a, i64 b) { return eL[a] * (1.0 - eL[a]) > eL[b] * (1.0 - eL[b]); });
+      const size_t w = c.cplx ? 2 : 1;
+      std::vector<double> Pm((size_t)kc * kc * w, 0.0), Sm((size_t)kc * kc * w, 0.0);  // column-major
+      for (i64 a = 0; a < kc; ++a) {
+        const i64 j = order[a];
+        Pm[(size_t)(a * kc + j) * w] = 1.0;                                             // T[:, a] = pair[:, order[a]]
+        const i64 col = kc - 1 - j;
+        Sm[(size_t)(col * kc + a) * w] = (col & 1) ? -1.0 : 1.0;                         // slater.py:410 reversal + signs
+      }
+      u64 t_P, t_S;
+      TMF_TRY(up_vec(Pm, &t_P));
+      TMF_TRY(up_vec(Sm, &t_S));
+      TMF_TRY(alloc_el(nR * kc, &d_T));
+      Gemm g1;
+      g1.add(d_pair, t_P, d_T, nR, kc, kc, ldR, kc, ldR);
+      TMF_TRY(gemm(0, 1.0, 0.0, g1));
+      TMF_TRY(alloc_el((kc + 1) * PANEL_W, &d_scrc));
+      TMF_TRY(bcgs({Slab{d_T, nR, ldR, 0, kc, d_scrc}}, 2, false));
+      Gemm g2;
+      g2.add(d_T, t_S, Vp[cr], nR, kc, kc, ldR, kc, ldR);
+      TMF_TRY(gemm(0, 1.0, 0.0, g2));
+    }
+    // filled: Y = A Omega_f, projected off U_E and orthonormalised
+    i64 maxnf = 0, maxcol = 0;
+    for (i64 i = 0; i < ncs; ++i) maxnf = std::max(maxnf, c.nf[i]), maxcol = std::max(maxcol, ncolV[i]);
+    if (maxnf > 0) {
+      u64 d_OmF, d_scr2;
+      TMF_TRY(alloc_el(L * maxnf, &d_OmF));
+      TMF_TRY(tmf_fill_normal(c.dtype, (void*)d_OmF, L * maxnf, 0xF111ED, c.s_main));
+      std::vector<u64> Vf(ncs);
+      for (i64 i = 0; i < ncs; ++i) Vf[i] = Vp[i] + (u64)(c.k[i] * c.ld1[i] * el);
+      // one multiplication by A: the filled space has eigenvalue >= 1 - 1e-12, everything that is not projected off
+      // with U_E below has eigenvalue <= 1e-12 (the reference's own cutoff)
+      TMF_TRY(nested('A', d_OmF, L, Vf, c.nf));
+      const i64 per = (maxcol + 1) * PANEL_W;
+      TMF_TRY(alloc_el(per * ncs, &d_scr2));
+      std::vector<Slab> s;
+      for (i64 i = 0; i < ncs; ++i)
+        if (c.nf[i] > 0) s.push_back(Slab{Vp[i], c.n[i], c.ld1[i], c.k[i], ncolV[i], d_scr2 + (u64)(i * per * el)});
+      TMF_TRY(bcgs(s, (c.par.flags & TMF_SWEEP_TWO_PASSES) ? 2 : 1, !(c.par.flags & TMF_SWEEP_NO_CHOLQR)));
+    }
+    // self-check of the centre cut (testing.py:131-177; slater.py:419-420 runs it only there)
+    c.n_checks = 0;
+    c.d_chk = nullptr;
+    if ((c.par.flags & TMF_SWEEP_CHECKS) && c.has_centre && c.doE[c.centre_L]) {
+      const i64 iL = c.centre_L, iR = c.centre_R;
+      const i64 qL = ncolV[iL], qR = ncolV[iR], kc = c.k[iL];
+      std::vector<double> w;  // wL | wR | sv
+      for (double v : c.e_side[iL]) w.push_back(v);
+      for (i64 j = 0; j < c.nf[iL]; ++j) w.push_back(1.0);
+      const size_t oR_ = w.size();
+      for (double v : c.e_side[iR]) w.push_back(v);
+      for (i64 j = 0; j < c.nf[iR]; ++j) w.push_back(1.0);
+      const size_t oS_ = w.size();
+      for (i64 j = 0; j < kc; ++j) {
+        const double e = c.e_side[iL][j];
+        w.push_back(sqrt(e * (1.0 - e)) * (((kc - 1 - j) & 1) ? -1.0 : 1.0));  // slater.py:266-268
+      }
+      w.push_back(0.0);
+      u64 t_w;
+      TMF_TRY(up_vec(w, &t_w));
+      void* chk;
+      TMF_TRY(dalloc(8, 8, &chk, true));
+      c.d_chk = (char*)chk;
+      tmf_recon_desc d[5];
+      memset(d, 0, sizeof(d));
+      auto item = [&](int i, u64 T, u64 X, u64 Y, u64 wp, i64 rows, i64 cols, i64 q, i64 inner, i64 ldt, i64 ldx, i64 ldy, int md,
+                      int yrev) {
+        d[i].T = T, d[i].X = X, d[i].Y = Y, d[i].w = wp, d[i].out = (u64)chk + 8 * i;
+        d[i].rows = (int32_t)rows, d[i].cols = (int32_t)cols, d[i].q = (int32_t)q, d[i].inner = (int32_t)inner;
+        d[i].ldt = (int32_t)ldt, d[i].ldx = (int32_t)ldx, d[i].ldy = (int32_t)ldy, d[i].mode = md, d[i].y_reverse = yrev;
+      };
+      item(0, 0, Vp[iL], Vp[iL], 0, qL, qL, 0, c.n[iL], 1, c.ld1[iL], c.ld1[iL], 1, 0);                       // vL is not unitary
+      item(1, c.blk[iL], Vp[iL], Vp[iL], t_w, c.n[iL], c.n[iL], qL, 0, L, c.ld1[iL], c.ld1[iL], 0, 0);        // vL does not diagonalise C_LL
+      item(2, 0, Vp[iR], Vp[iR], 0, qR, qR, 0, c.n[iR], 1, c.ld1[iR], c.ld1[iR], 1, 0);                       // vR is not unitary
+      item(3, c.blk[iR], Vp[iR], Vp[iR], t_w + 8 * oR_, c.n[iR], c.n[iR], qR, 0, L, c.ld1[iR], c.ld1[iR], 0, 0);  // vR ... C_RR
+      item(4, c.off[iL], Vp[iL], Vp[iR], t_w + 8 * oS_, c.n[iL], c.n[iR], kc, 0, L, c.ld1[iL], c.ld1[iR], 0, 1);  // SVD of C_LR
+      std::vector<int32_t> tiles;
+      for (int i = 0; i < 5; ++i) {
+        const i64 tr = cdiv(d[i].rows, 64), tc = cdiv(d[i].cols, 64);
+        for (i64 t = 0; t < tr * tc; ++t) {
+          tiles.push_back(i), tiles.push_back((int32_t)(t / std::max<i64>(tc, 1))), tiles.push_back((int32_t)(t % std::max<i64>(tc, 1)));
+        }
+      }
+      if (!tiles.empty()) {
+        u64 t_d, t_t;
+        TMF_TRY(up(d, sizeof(d), &t_d));
+        TMF_TRY(up_vec(tiles, &t_t));
+        TMF_TRY(tmf_recon_error_batched(c.dtype, (const tmf_recon_desc*)t_d, (const int32_t*)t_t, (int)(tiles.size() / 3), c.s_main));
+      }
+      c.n_checks = 5;
+    }
+    tick(ST_F, t0);
+    return TMF_OK;
+  }
+
+  // ------------------------------------------------------------------ S1: O = V_bra^H V_ket (needs the orbital matrices only)
+  std::vector<i64> e_ib, e_ik, cb_, ck_;
+  std::vector<u64> Op, physp;
+  int overlap_stage() {
+    const double t0 = now_ms();
+    const i64 ns = c.s_hi - c.s_lo, L = c.L, el = c.el;
+    std::vector<i64> side_idx((size_t)(L + 1) * 2, -1);
+    for (i64 i = 0; i < c.ncs; ++i) side_idx[(size_t)c.cs_b[i] * 2 + c.cs_side[i]] = i;
+    e_ib.resize(ns), e_ik.resize(ns), cb_.resize(ns), ck_.resize(ns), Op.resize(ns), physp.resize(ns);
+    i64 tO = 0;
+    std::vector<i64> oO(ns);
+    for (i64 j = 0; j < ns; ++j) {
+      const i64 site = c.s_lo + j;
+      const int md = site >= c.oc ? 1 : 0;
+      e_ib[j] = side_idx[(size_t)(md == 0 ? site : site + 1) * 2 + md];
+      e_ik[j] = side_idx[(size_t)(md == 0 ? site + 1 : site) * 2 + md];
+      cb_[j] = ncolV[e_ib[j]], ck_[j] = ncolV[e_ik[j]];
+      oO[j] = tO;
+      tO += cb_[j] * ck_[j];
+    }
+    u64 d_O;
+    TMF_TRY(alloc_el(tO, &d_O));
+    Gemm g;
+    for (i64 j = 0; j < ns; ++j) {
+      const int md = (c.s_lo + j) >= c.oc ? 1 : 0;
+      const i64 nb_rows = c.n[e_ib[j]];  // contraction length = bra orbitals
+      Op[j] = d_O + (u64)(oO[j] * el);
+      const u64 Vk_sub = Vp[e_ik[j]] + (u64)((md == 1 ? 1 : 0) * el);  // right mode: physical orbital is row 0 of the ket block
+      physp[j] = Vp[e_ik[j]] + (u64)((md == 1 ? 0 : nb_rows) * el);
+      g.add(Vp[e_ib[j]], Vk_sub, Op[j], cb_[j], ck_[j], nb_rows, c.ld1[e_ib[j]], c.ld1[e_ik[j]], std::max<i64>(cb_[j], 1));
+    }
+    TMF_TRY(gemm(1, 1.0, 0.0, g));
+    tick(ST_S1, t0);
+    return TMF_OK;
+  }
+
+  int acquire_slot(size_t bytes) {
+    OutSlot* s = nullptr;
+    for (auto& x : c.slots) {
+      if (x.busy && hipEventQuery(x.done) == hipSuccess) x.busy = false;
+      if (!x.busy && (s == nullptr || (x.cap >= bytes && s->cap < bytes))) s = &x;
+    }
+    if (s == nullptr) {
+      c.slots.emplace_back();
+      s = &c.slots.back();
+      HIP_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+    }
+    if (s->cap < bytes) {
+      if (s->d) HIP_TRY(hipFree(s->d));
+      s->d = nullptr, s->cap = 0;
+      const size_t ncap = bytes + bytes / 8 + 4096;
+      HIP_TRY(hipMalloc((void**)&s->d, ncap));
+      s->cap = ncap;
+    }
+    TMF_TRY(s->checks.ensure(64));
+    c.slot = s;
+    return TMF_OK;
+  }
+
+  // ------------------------------------------------------------------ S2-S4 after the host phase
+  int site_stage() {
+    double t0 = now_ms();
+    const i64 ns = c.ns, el = c.el;
+    // the index pool was written into pinned memory by the site preparation; it goes up on a side stream while the
+    // gather and the LU run
+    void* t_pool;
+    TMF_TRY(dalloc(c.ix_tot + 1, 1, &t_pool));
+    hipEvent_t ev_main, ev_pool;
+    TMF_TRY(new_event(&ev_main));
+    TMF_TRY(new_event(&ev_pool));
+    HIP_TRY(hipEventRecord(ev_main, c.s_main));
+    HIP_TRY(hipStreamWaitEvent(c.s_up, ev_main, 0));
+    HIP_TRY(hipMemcpyAsync(t_pool, c.pool_pin.p, (size_t)c.ix_tot + 1, hipMemcpyHostToDevice, c.s_up));
+    HIP_TRY(hipEventRecord(ev_pool, c.s_up));
+
+    std::vector<i64> mb(ns), mk(ns), ka(ns), sbv(ns), skv(ns);
+    i64 tW = 0, maxmb = 0;
+    std::vector<i64> oW(ns);
+    c.out_off.assign(ns, 0), c.nsec.assign(ns, 0);
+    i64 out_tot = 0;
+    for (i64 j = 0; j < ns; ++j) {
+      const tmf_site_out& o = c.souts[j];
+      mb[j] = o.mb, mk[j] = o.mk, ka[j] = o.k_always, sbv[j] = o.sb, skv[j] = o.sk;
+      if (sbv[j] * skv[j] * el > 64 * 1024) {
+        set_error("sometimes-matrix larger than the 64 KiB LDS stage of the determinant kernel");
+        return TMF_E_LIMIT;
+      }
+      oW[j] = tW;
+      tW += mb[j] * mk[j];
+      maxmb = std::max(maxmb, mb[j]);
+      c.out_off[j] = out_tot;
+      out_tot += o.out_elems;
+      c.nsec[j] = o.n_sectors;
+    }
+    c.out_tot = out_tot;
+    u64 d_W;
+    TMF_TRY(alloc_el(tW, &d_W));
+    // output block: tensors followed by det_always per site
+    TMF_TRY(acquire_slot((size_t)(out_tot + ns + 2) * el));
+    c.d_out = c.slot->d;
+    c.d_det = c.slot->d + (size_t)out_tot * el;
+    u64 t_rs, t_cs, t_rg, t_cg;
+    TMF_TRY(up_vec(c.row_sel, &t_rs)); TMF_TRY(up_vec(c.col_sel, &t_cs)); TMF_TRY(up_vec(c.row_sign, &t_rg)); TMF_TRY(up_vec(c.col_sign, &t_cg));
+    std::vector<tmf_gather_desc> gd(ns);
+    std::vector<tmf_schur_desc> sd(ns);
+    std::vector<u64> Wp(ns), detp(ns), Sp(ns);
+    for (i64 j = 0; j < ns; ++j) {
+      Wp[j] = d_W + (u64)(oW[j] * el);
+      detp[j] = (u64)c.d_det + (u64)(j * el);
+      tmf_gather_desc& g = gd[j];
+      g.src = Op[j], g.dst = Wp[j];
+      g.row_sel = t_rs + (u64)(c.jobs[j].row_off * 4), g.col_sel = t_cs + (u64)(c.jobs[j].col_off * 4);
+      g.row_sign = t_rg + (u64)c.jobs[j].row_off, g.col_sign = t_cg + (u64)c.jobs[j].col_off;
+      g.phys = physp[j];
+      g.rows = (int32_t)mb[j], g.cols = (int32_t)mk[j];
+      g.lds_ = (int32_t)std::max<i64>(cb_[j], 1), g.ldd = (int32_t)std::max<i64>(mb[j], 1), g.ldp = (int32_t)c.ld1[e_ik[j]], g.pad = 0;
+      tmf_schur_desc& s = sd[j];
+      s.W = Wp[j], s.S = 0, s.det = detp[j];
+      s.mb = (int32_t)mb[j], s.mk = (int32_t)mk[j], s.k = (int32_t)ka[j], s.ldw = (int32_t)std::max<i64>(mb[j], 1), s.lds = 1, s.pad = 0;
+      Sp[j] = Wp[j] + (u64)((ka[j] + ka[j] * std::max<i64>(mb[j], 1)) * el);
+    }
+    u64 t_gd, t_sd;
+    TMF_TRY(up_vec(gd, &t_gd));
+    TMF_TRY(tmf_gather_signed_batched(c.dtype, (const tmf_gather_desc*)t_gd, (int)ns, c.s_main));
+    TMF_TRY(up_vec(sd, &t_sd));
+    TMF_TRY(tmf_lu_schur_batched(c.dtype, (const tmf_schur_desc*)t_sd, (int)ns, (int)maxmb, c.s_main));
+    tick(ST_SCHUR, t0);
+
+    // ---- S4: all minors ----
+    t0 = now_ms();
+    HIP_TRY(hipStreamWaitEvent(c.s_main, ev_pool, 0));  // the determinant kernels read the pool
+    const double flop_per_det = c.cplx ? (8.0 / 3.0) : (2.0 / 3.0);  // LU of an n x n complex / real matrix
+    c.n_det = 0;
+    std::vector<i64> rest_keys;
+    bool have_rest_keys = false;
+    const bool use_ppt = !(c.par.flags & (TMF_SWEEP_DET_REDUCED | TMF_SWEEP_DET_DIRECT));
+    if (use_ppt) {
+      std::vector<tmf_det_site> ds(ns);
+      for (i64 j = 0; j < ns; ++j) {
+        ds[j].S = Sp[j], ds[j].scale = detp[j], ds[j].lds = (int32_t)std::max<i64>(mb[j], 1), ds[j].pad = 0;
+        ds[j].idx_base = (u64)t_pool + (u64)c.jobs[j].idx_off;
+        ds[j].out_base = (u64)c.d_out + (u64)(c.out_off[j] * el);
+      }
+      i64 n_rest = 0, npairs = 0;
+      int32_t lds_max = 0;
+      double fl3 = 0;
+      i64 nt = tmf_det_tiles_build((int)ns, c.jobs.data(), c.souts.data(), c.sec_buf.data(), ds.data(), (int)el, 16384, nullptr, 0,
+                                   nullptr, 0, &n_rest, &lds_max, &fl3, &npairs);
+      std::vector<tmf_det_desc> tiles((size_t)std::max<i64>(nt, 1));
+      rest_keys.assign((size_t)std::max<i64>(n_rest, 1), 0);
+      nt = tmf_det_tiles_build((int)ns, c.jobs.data(), c.souts.data(), c.sec_buf.data(), ds.data(), (int)el, 16384, tiles.data(), nt,
+                               rest_keys.data(), (i64)rest_keys.size(), &n_rest, &lds_max, &fl3, &npairs);
+      rest_keys.resize((size_t)n_rest);
+      have_rest_keys = true;
+      if (nt > 0) {
+        u64 t_dd;
+        TMF_TRY(up(tiles.data(), (size_t)nt * sizeof(tmf_det_desc), &t_dd));
+        KernelEvent ev{};
+        if (timing()) {
+          TMF_TRY(new_event(&ev.e0));
+          TMF_TRY(new_event(&ev.e1));
+          HIP_TRY(hipEventRecord(ev.e0, c.s_main));
+        }
+        TMF_TRY(tmf_det_ppt_batched(c.dtype, (const tmf_det_desc*)t_dd, (int)nt, lds_max, c.s_main));
+        if (timing()) {
+          HIP_TRY(hipEventRecord(ev.e1, c.s_main));
+          ev.flops = fl3 * flop_per_det, ev.n = npairs, ev.kind = 0, ev.order = 0;
+          c.det_events.push_back(ev);
+        }
+        c.n_det += npairs;
+      }
+    }
+    // general path: every sector (A/B switches) or the ones the exchange kernel does not take
+    struct Rest {
+      i64 site, loc;
+    };
+    std::vector<Rest> rs;
+    if (!have_rest_keys) {
+      for (i64 j = 0; j < ns; ++j)
+        for (i64 q = 0; q < c.nsec[j]; ++q) rs.push_back(Rest{j, q});
+    } else {
+      for (i64 key : rest_keys) rs.push_back(Rest{key >> 32, key & 0xFFFFFFFF});
+    }
+    if (!rs.empty()) {
+      struct TileX {
+        tmf_det_desc d;
+        int cls;
+        bool red;
+        i64 lneed, pairs, nq;
+      };
+      std::vector<TileX> tx;
+      const bool force_direct = (c.par.flags & TMF_SWEEP_DET_DIRECT) != 0;
+      for (const Rest& r : rs) {
+        const tmf_sector& sec = c.sec_buf[c.jobs[r.site].sec_off + r.loc];
+        const i64 nq = sec.n, nsb = sec.r1 - sec.r0, nsk = sec.c1 - sec.c0, j = r.site;
+        const int cls = nq <= 32 ? (int)nq : 64;  // exact order for n <= 32 (templated kernels), generic above
+        const i64 ta = std::min(std::max<i64>(cdiv(4096, nsk), 1), nsb);
+        const i64 ntile = cdiv(nsb, ta);
+        const u64 pbase = (u64)t_pool + (u64)c.jobs[j].idx_off;
+        for (i64 t = 0; t < ntile; ++t) {
+          TileX x{};
+          x.d.S = Sp[j], x.d.scale = detp[j];
+          x.d.bra_idx = pbase + (u64)sec.bra_off, x.d.ket_idx = pbase + (u64)sec.ket_off;
+          x.d.out = (u64)c.d_out + (u64)((c.out_off[j] + sec.out_off) * el);
+          x.d.sb = (int32_t)sbv[j], x.d.sk = (int32_t)skv[j], x.d.lds = (int32_t)std::max<i64>(mb[j], 1);
+          x.d.n = (int32_t)nq, x.d.nsb = (int32_t)nsb, x.d.nsk = (int32_t)nsk;
+          x.d.a0 = (int32_t)(t * ta), x.d.a1 = (int32_t)std::min(nsb, t * ta + ta);
+          x.cls = cls, x.nq = nq;
+          // LDS per workgroup (det_gather.hip): M, index lists, then per wave the gathered rows M[rows(a), :] (n*sk) +
+          // 64 scratch elements; class 64 instead holds one n x n minor
+          const i64 gpw = nq <= 8 ? 8 : (nq <= 16 ? 4 : 2);
+          i64 lneed = a16(sbv[j] * skv[j] * el) + a16(nsk * nq) + a16(ta * nq) +
+                      (cls == 64 ? nq * nq * el : 4 * ((nq | 1) * skv[j] + gpw * (nq + 1)) * el);
+          x.pairs = (i64)(x.d.a1 - x.d.a0) * nsk;
+          // reduced-minor kernel (one Gauss-Jordan per bra row-set) whenever the sometimes-matrix has <= 64 columns
+          // and 1 <= n <= 32; the direct kernel covers the rest
+          bool red = cls >= 1 && cls <= 32 && skv[j] <= 64 && !force_direct;
+          const i64 lred = a16(sbv[j] * skv[j] * el) + a16(nsk * nq) + a16(nsk * 8) + a16(ta * nq) +
+                           4 * (((nq | 1) * skv[j] + 264) * el + 576);  // _native.reduced_det_lds - 16
+          red = red && (lred + 16 <= 160 * 1024);
+          x.red = red;
+          x.lneed = red ? lred : lneed;
+          if (x.lneed > 160 * 1024) {
+            set_error("determinant tile exceeds the 160 KiB LDS of a CU");
+            return TMF_E_LIMIT;
+          }
+          tx.push_back(x);
+        }
+      }
+      // one launch per (class, kernel), the heaviest first; inside a launch the biggest tiles first
+      struct Group {
+        int cls;
+        bool red;
+        i64 pairs;
+      };
+      std::vector<Group> groups;
+      for (auto& x : tx) {
+        auto it = std::find_if(groups.begin(), groups.end(), [&](const Group& g) { return g.cls == x.cls && g.red == x.red; });
+        if (it == groups.end()) groups.push_back(Group{x.cls, x.red, x.pairs});
+        else it->pairs += x.pairs;
+      }
+      std::sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) {
+        if (a.cls != b.cls) return a.cls < b.cls;
+        return (int)a.red < (int)b.red;
+      });
+      std::stable_sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) { return a.pairs > b.pairs; });
+      for (const Group& gq : groups) {
+        std::vector<const TileX*> sel;
+        for (auto& x : tx)
+          if (x.cls == gq.cls && x.red == gq.red) sel.push_back(&x);
+        std::stable_sort(sel.begin(), sel.end(), [](const TileX* a, const TileX* b) {
+          return a->pairs * (a->nq + 1) * (a->nq + 1) > b->pairs * (b->nq + 1) * (b->nq + 1);
+        });
+        std::vector<tmf_det_desc> dd(sel.size());
+        i64 lmax = 0, pairs = 0;
+        double fl = 0;
+        for (size_t i = 0; i < sel.size(); ++i) {
+          dd[i] = sel[i]->d;
+          lmax = std::max(lmax, sel[i]->lneed);
+          pairs += sel[i]->pairs;
+          fl += (double)sel[i]->pairs * (double)sel[i]->nq * (double)sel[i]->nq * (double)sel[i]->nq;
+        }
+        u64 t_dd;
+        TMF_TRY(up_vec(dd, &t_dd));
+        KernelEvent ev{};
+        if (timing()) {
+          TMF_TRY(new_event(&ev.e0));
+          TMF_TRY(new_event(&ev.e1));
+          HIP_TRY(hipEventRecord(ev.e0, c.s_main));
+        }
+        TMF_TRY((gq.red ? tmf_det_reduced_batched : tmf_det_gather_batched)(c.dtype, gq.cls, (const tmf_det_desc*)t_dd, (int)dd.size(),
+                                                                           (int)lmax + 16, c.s_main));
+        if (timing()) {
+          HIP_TRY(hipEventRecord(ev.e1, c.s_main));
+          ev.flops = fl * flop_per_det, ev.n = pairs, ev.kind = gq.red ? 1 : 2, ev.order = gq.cls;
+          c.det_events.push_back(ev);
+        }
+        c.n_det += pairs;
+      }
+    }
+    tick(ST_DET, t0);
+    return TMF_OK;
+  }
+
+  int sites(tmf_sweep_dims* dims) {
+    if (!c.begun || c.h_cnt.empty()) {
+      set_error("tmf_sweep_sites: call tmf_sweep_begin and tmf_sweep_entangled first");
+      return TMF_E_ARG;
+    }
+    classify();
+    TMF_TRY(filled_stage());
+    TMF_TRY(overlap_stage());
+    TMF_TRY(host_phase());  // integer work on host threads while the GPU runs the filled-basis launches
+    TMF_TRY(site_stage());
+    c.have_sites = true;
+    dims->ncut = c.ncut, dims->cap = c.cap, dims->ns = c.ns, dims->sec_tot = c.sc_tot, dims->bra_tot = c.br_tot;
+    dims->e_tot = (i64)c.e_pool.size() - 1, dims->out_elems = c.out_tot, dims->elem_bytes = c.el;
+    return TMF_OK;
+  }
+
+  // ------------------------------------------------------------------ result
+  int download(const tmf_sweep_ptrs* q, int want_tensors, i64* ticket) {
+    if (!c.have_sites) {
+      set_error("tmf_sweep_download: no finished sweep");
+      return TMF_E_ARG;
+    }
+    double t0 = now_ms();
+    auto cp = [](void* dst, const void* src, size_t bytes) {
+      if (dst && bytes) memcpy(dst, src, bytes);
+    };
+    const i64 ns = c.ns, ncut = c.ncut;
+    cp(q->my_cuts, c.my_cuts.data(), (size_t)ncut * 8);
+    cp(q->c_sets, c.c_sets.data(), c.c_sets.size() * 8);
+    cp(q->c_lam, c.c_lam.data(), c.c_lam.size() * 8);
+    cp(q->c_q, c.c_q.data(), c.c_q.size() * 4);
+    cp(q->c_chi, c.c_chi.data(), (size_t)ncut * 8);
+    cp(q->c_chk, c.c_chk.data(), (size_t)ncut * 8);
+    cp(q->e_pool, c.e_pool.data(), c.e_pool.size() * 8);
+    cp(q->e_off, c.e_off.data(), (size_t)ncut * 8);
+    cp(q->kk_cut, c.kk_cut.data(), (size_t)ncut * 4);
+    cp(q->nfl, c.nfl.data(), (size_t)ncut * 4);
+    cp(q->nfr, c.nfr.data(), (size_t)ncut * 4);
+    cp(q->mode, c.mode.data(), (size_t)ns * 4);
+    if (q->sec_off)
+      for (i64 j = 0; j < ns; ++j) ((i64*)q->sec_off)[j] = c.jobs[j].sec_off;
+    if (q->bra_off)
+      for (i64 j = 0; j < ns; ++j) ((i64*)q->bra_off)[j] = c.jobs[j].bra_off;
+    cp(q->nsec, c.nsec.data(), (size_t)ns * 8);
+    cp(q->sectors, c.sec_buf.data(), c.sec_buf.size() * sizeof(tmf_sector));
+    cp(q->out_off, c.out_off.data(), (size_t)ns * 8);
+    cp(q->chi_b, c.chi_b.data(), (size_t)ns * 8);
+    cp(q->chi_k, c.chi_k.data(), (size_t)ns * 8);
+    cp(q->bra_p, c.bra_p.data(), c.bra_p.size() * 4);
+    cp(q->bra_alpha, c.bra_alpha.data(), c.bra_alpha.size() * 4);
+    tick(ST_RESULT, t0);
+    t0 = now_ms();
+    // tensors: asynchronous DMA on the download stream (the launch stream is free for the next conversion; the output
+    // block stays reserved until the copy has finished)
+    OutSlot* s = c.slot;
+    hipEvent_t ev;
+    TMF_TRY(new_event(&ev));
+    HIP_TRY(hipEventRecord(ev, c.s_main));
+    HIP_TRY(hipStreamWaitEvent(c.s_down, ev, 0));
+    if (q->det) HIP_TRY(hipMemcpyAsync(q->det, c.d_det, (size_t)ns * c.el, hipMemcpyDeviceToHost, c.s_down));
+    if (want_tensors && q->out) {
+      const size_t total = (size_t)c.out_tot * c.el, chunk = (size_t)64 << 20;
+      for (size_t o = 0; o < total; o += chunk)  // in pieces: small copies of other streams get a turn
+        HIP_TRY(hipMemcpyAsync((char*)q->out + o, c.d_out + o, std::min(chunk, total - o), hipMemcpyDeviceToHost, c.s_down));
+    }
+    s->n_checks = c.n_checks;
+    if (c.n_checks > 0)
+      HIP_TRY(hipMemcpyAsync(s->checks.p, c.d_chk, (size_t)c.n_checks * 8, hipMemcpyDeviceToHost, c.s_down));
+    HIP_TRY(hipEventRecord(s->done, c.s_down));
+    s->busy = true;
+    s->ticket = c.next_ticket++;
+    *ticket = s->ticket;
+    tick(ST_DOWNLOAD, t0);
+    c.stage_ms[ST_TOTAL] = now_ms() - c.t_begin;
+    return TMF_OK;
+  }
+};
+
+}  // namespace
+}  // namespace tmf
+
+// ====================================================================================== C ABI
+extern "C" int tmf_ctx_create(int device, tmf_ctx** out) {
+  int ndev = 0;
+  TMF_TRY(check_hip(hipGetDeviceCount(&ndev), "hipGetDeviceCount"));
+  if (device < 0 || device >= ndev) {
+    set_error("tmf_ctx_create: device %d of %d", device, ndev);
+    return TMF_E_ARG;
+  }
+  HIP_TRY(hipSetDevice(device));
+  tmf_ctx* c = new tmf_ctx();
+  c->device = device;
+  int st = check_hip(hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking), "hipStreamCreate");
+  if (st == TMF_OK) st = check_hip(hipStreamCreateWithFlags(&c->s_down, hipStreamNonBlocking), "hipStreamCreate");
+  if (st == TMF_OK) st = check_hip(hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking), "hipStreamCreate");
+  if (st != TMF_OK) {
+    delete c;
+    return st;
+  }
+  c->slots.reserve(16);  // OutSlot addresses stay valid
+  *out = c;
+  return TMF_OK;
+}
+
+extern "C" void tmf_ctx_destroy(tmf_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (auto& s : c->slots) {
+    if (s.d) (void)hipFree(s.d);
+    if (s.done) (void)hipEventDestroy(s.done);
+    s.checks.release();
+  }
+  for (auto e : c->event_pool) (void)hipEventDestroy(e);
+  c->dev.release();
+  c->stage.release();
+  c->fetch.release(), c->pool_pin.release(), c->c_pin.release();
+  if (c->s_main) (void)hipStreamDestroy(c->s_main);
+  if (c->s_down) (void)hipStreamDestroy(c->s_down);
+  if (c->s_up) (void)hipStreamDestroy(c->s_up);
+  delete c;
+}
+
+extern "C" int tmf_sweep_begin(tmf_ctx* ctx, const void* C, const tmf_sweep_params* par) {
+  if (!ctx || !C || !par) {
+    set_error("tmf_sweep_begin: null argument");
+    return TMF_E_ARG;
+  }
+  return Sweep(*ctx).begin(C, par);
+}
+
+extern "C" int tmf_sweep_entangled(tmf_ctx* ctx, int P, int iterations, double* smallest_sigma, int32_t* saturated, int32_t* weak,
+                                   int32_t* max_sweeps, int64_t* bad_cut) {
+  if (!ctx || P < 1 || iterations < 0) {
+    set_error("tmf_sweep_entangled: bad argument");
+    return TMF_E_ARG;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  return Sweep(*ctx).entangled(P, iterations, smallest_sigma, saturated, weak, max_sweeps, bad_cut);
+}
+
+extern "C" int tmf_sweep_sites(tmf_ctx* ctx, tmf_sweep_dims* dims) {
+  if (!ctx || !dims) {
+    set_error("tmf_sweep_sites: null argument");
+    return TMF_E_ARG;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  return Sweep(*ctx).sites(dims);
+}
+
+extern "C" int tmf_sweep_download(tmf_ctx* ctx, const tmf_sweep_ptrs* dst, int want_tensors, int64_t* ticket) {
+  if (!ctx || !dst || !ticket) {
+    set_error("tmf_sweep_download: null argument");
+    return TMF_E_ARG;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  return Sweep(*ctx).download(dst, want_tensors, ticket);
+}
+
+static OutSlot* find_ticket(tmf_ctx* ctx, int64_t ticket) {
+  for (auto& s : ctx->slots)
+    if (s.ticket == ticket) return &s;
+  return nullptr;
+}
+
+extern "C" int tmf_sweep_query(tmf_ctx* ctx, int64_t ticket) {
+  OutSlot* s = ctx ? find_ticket(ctx, ticket) : nullptr;
+  if (!s) return 1;  // its block has been reused: that download finished long ago
+  const hipError_t e = hipEventQuery(s->done);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) return 0;
+  return check_hip(e, "hipEventQuery");
+}
+
+extern "C" int tmf_sweep_wait(tmf_ctx* ctx, int64_t ticket, double* checks, int32_t* n_checks) {
+  if (n_checks) *n_checks = 0;
+  OutSlot* s = ctx ? find_ticket(ctx, ticket) : nullptr;
+  if (!s) return TMF_OK;
+  HIP_TRY(hipEventSynchronize(s->done));
+  s->busy = false;
+  if (checks && n_checks) {
+    *n_checks = s->n_checks;
+    memcpy(checks, s->checks.p, (size_t)s->n_checks * 8);
+  }
+  return TMF_OK;
+}
+
+extern "C" const char* tmf_sweep_stage_name(int i) { return (i >= 0 && i < N_STAGES) ? kStageNames[i] : ""; }
+
+extern "C" int tmf_sweep_device_out(tmf_ctx* ctx, uint64_t* d_out, int64_t* elems) {
+  if (!ctx || !ctx->have_sites) {
+    set_error("tmf_sweep_device_out: no finished sweep");
+    return TMF_E_ARG;
+  }
+  *d_out = (uint64_t)ctx->d_out, *elems = ctx->out_tot;
+  return TMF_OK;
+}
+
+extern "C" int tmf_sweep_info_get(tmf_ctx* ctx, tmf_sweep_info* o) {
+  if (!ctx || !o) {
+    set_error("tmf_sweep_info_get: null argument");
+    return TMF_E_ARG;
+  }
+  memset(o, 0, sizeof(*o));
+  memcpy(o->stage_ms, ctx->stage_ms, sizeof(double) * N_STAGES);
+  o->range_width = ctx->P, o->range_iterations = ctx->range_iterations, o->range_floor = ctx->range_floor;
+  o->n_fermion = ctx->n_fermion, o->device_bytes = (int64_t)ctx->dev.total;
+  o->n_det = ctx->n_det;
+  const int64_t n_det_all = ctx->n_det;
+  (void)n_det_all;
+  if (!ctx->gemm_events.empty() || !ctx->det_events.empty()) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->s_main));
+    for (auto& e : ctx->gemm_events) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, e.e0, e.e1));
+      o->gemm_ms += ms, o->gemm_flops += e.flops;
+    }
+    o->n_gemm_launches = (int64_t)ctx->gemm_events.size();
+    for (auto& e : ctx->det_events) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, e.e0, e.e1));
+      o->det_all_ms += ms;
+      if (ms > o->det_ms) o->det_ms = ms, o->det_flops = e.flops, o->det_kind = e.kind, o->det_order = e.order, o->n_det = e.n;
+    }
+  }
+  return TMF_OK;
+}
+
+// ---- one call: whole conversion, result owned by the library -------------------------------------------
+struct tmf_result {
+  tmf_ctx* ctx;
+  tmf_sweep_dims dims;
+  int64_t L, s_lo, s_hi, oc;
+  int cplx;
+  PinnedBuf buf;
+  tmf_sweep_ptrs p;
+  std::vector<int64_t> cpos;
+  double checks[8];
+  int32_t n_checks;
+};
+
+extern "C" int tmf_slater_sweep(tmf_ctx* ctx, const void* C, const tmf_sweep_params* par, double range_floor_tol,
+                                tmf_result** out) {
+  if (!ctx || !C || !par || !out) {
+    set_error("tmf_slater_sweep: null argument");
+    return TMF_E_ARG;
+  }
+  if (!(range_floor_tol > 0)) range_floor_tol = 1e-11;
+  TMF_TRY(tmf_sweep_begin(ctx, C, par));
+  // Adequacy of the range finder is CHECKED, not assumed (see temfpy_amd/engine.py: entangled_stage_adaptive): the
+  // state error is ~ the smallest captured singular value; above the tolerance one subspace iteration cubes the
+  // ratio; a saturated or still too weak cut moves on to the next width.
+  const int ladder[3] = {64, 128, 256};
+  bool done = false;
+  for (int li = 0; li < 3 && !done; ++li) {
+    double worst;
+    int32_t sat, weak, sweeps;
+    int64_t bad;
+    TMF_TRY(tmf_sweep_entangled(ctx, ladder[li], 0, &worst, &sat, &weak, &sweeps, &bad));
+    if (sweeps >= 60) {
+      set_error("Jacobi iteration did not converge in 60 sweeps");
+      return TMF_E_HIP;
+    }
+    if (worst > range_floor_tol) {
+      TMF_TRY(tmf_sweep_entangled(ctx, ladder[li], 1, &worst, &sat, &weak, &sweeps, &bad));
+      if (sweeps >= 60) {
+        set_error("Jacobi iteration did not converge in 60 sweeps");
+        return TMF_E_HIP;
+      }
+      if (weak) continue;
+    }
+    if (sat) continue;
+    done = true;
+  }
+  if (!done) {
+    set_error("entanglement rank beyond the widest range finder (256 columns)");
+    return TMF_E_LIMIT;
+  }
+  tmf_result* r = new tmf_result();
+  r->ctx = ctx;
+  int st = tmf_sweep_sites(ctx, &r->dims);
+  if (st != TMF_OK) {
+    delete r;
+    return st;
+  }
+  const tmf_sweep_dims& d = r->dims;
+  r->L = par->L, r->s_lo = par->site_lo, r->s_hi = par->site_hi, r->oc = par->ortho_center, r->cplx = par->is_complex;
+  // one page-locked block for everything, 4096-byte aligned pieces
+  size_t off = 0;
+  auto place = [&](size_t bytes) {
+    const size_t o = off;
+    off = (off + bytes + 4095) & ~(size_t)4095;
+    return o;
+  };
+  const size_t el = (size_t)d.elem_bytes;
+  size_t o[23];
+  const size_t sz[23] = {(size_t)d.ncut * 8, (size_t)d.ncut * d.cap * 16, (size_t)d.ncut * d.cap * 8, (size_t)d.ncut * d.cap * 4,
+                         (size_t)d.ncut * 8, (size_t)d.ncut * 8, (size_t)(d.e_tot + 1) * 8, (size_t)d.ncut * 8, (size_t)d.ncut * 4,
+                         (size_t)d.ncut * 4, (size_t)d.ncut * 4, (size_t)d.ns * 4, (size_t)d.ns * 8, (size_t)d.ns * 8,
+                         (size_t)(d.sec_tot + 1) * sizeof(tmf_sector), (size_t)d.ns * 8, (size_t)d.ns * 8, (size_t)d.ns * 8,
+                         (size_t)d.ns * 8, (size_t)(d.bra_tot + 1) * 4, (size_t)(d.bra_tot + 1) * 4, (size_t)d.ns * el,
+                         (size_t)d.out_elems * el};
+  for (int i = 0; i < 23; ++i) o[i] = place(sz[i]);
+  st = r->buf.ensure(off + 4096);
+  if (st != TMF_OK) {
+    delete r;
+    return st;
+  }
+  void** pp = (void**)&r->p;
+  for (int i = 0; i < 23; ++i) pp[i] = r->buf.p + o[i];
+  int64_t ticket = 0;
+  st = tmf_sweep_download(ctx, &r->p, 1, &ticket);
+  if (st == TMF_OK) st = tmf_sweep_wait(ctx, ticket, r->checks, &r->n_checks);
+  if (st != TMF_OK) {
+    r->buf.release();
+    delete r;
+    return st;
+  }
+  r->cpos.assign((size_t)r->L + 1, -1);
+  for (int64_t j = 0; j < d.ncut; ++j) r->cpos[((const int64_t*)r->p.my_cuts)[j]] = j;
+  // singular always-block: the reference fails in numpy.linalg.inv (slater.py:1079 / :1086)
+  const double* det = (const double*)r->p.det;
+  for (int64_t j = 0; j < d.ns; ++j) {
+    const double re = det[j * (r->cplx ? 2 : 1)], im = r->cplx ? det[2 * j + 1] : 0.0;
+    if (!(std::isfinite(re) && std::isfinite(im)) || (re == 0.0 && im == 0.0)) {
+      r->buf.release();
+      delete r;
+      set_error("Singular matrix");
+      return TMF_E_ARG;
+    }
+  }
+  *out = r;
+  return TMF_OK;
+}
+
+extern "C" int tmf_result_dims(const tmf_result* r, tmf_sweep_dims* dims, int64_t* L, int64_t* site_lo, int64_t* site_hi) {
+  if (!r) return TMF_E_ARG;
+  if (dims) *dims = r->dims;
+  if (L) *L = r->L;
+  if (site_lo) *site_lo = r->s_lo;
+  if (site_hi) *site_hi = r->s_hi;
+  return TMF_OK;
+}
+
+extern "C" int tmf_result_bond(const tmf_result* r, int64_t b, tmf_bond_view* o) {
+  if (!r || !o || b < 0 || b > r->L || r->cpos[(size_t)b] < 0) {
+    set_error("tmf_result_bond: bond %lld is not held by this site range", (long long)b);
+    return TMF_E_ARG;
+  }
+  const int64_t j = r->cpos[(size_t)b], cap = r->dims.cap;
+  o->x = b, o->chi = ((const int64_t*)r->p.c_chi)[j], o->k = ((const int32_t*)r->p.kk_cut)[j];
+  o->n_filled_left = ((const int32_t*)r->p.nfl)[j], o->n_filled_right = ((const int32_t*)r->p.nfr)[j];
+  o->n_checked = ((const int64_t*)r->p.c_chk)[j];
+  o->e = (const double*)r->p.e_pool + ((const int64_t*)r->p.e_off)[j];
+  o->masks = (const uint64_t*)r->p.c_sets + (size_t)j * cap * 2;
+  o->lam_raw = (const double*)r->p.c_lam + (size_t)j * cap;
+  o->q_left = (const int32_t*)r->p.c_q + (size_t)j * cap;
+  return TMF_OK;
+}
+
+extern "C" int tmf_result_site(const tmf_result* r, int64_t i, tmf_site_view* o) {
+  if (!r || !o || i < r->s_lo || i >= r->s_hi) {
+    set_error("tmf_result_site: site %lld is outside this site range", (long long)i);
+    return TMF_E_ARG;
+  }
+  const int64_t j = i - r->s_lo;
+  o->site = i, o->chi_bra = ((const int64_t*)r->p.chi_b)[j], o->chi_ket = ((const int64_t*)r->p.chi_k)[j];
+  o->n_blocks = ((const int64_t*)r->p.nsec)[j];
+  o->mode = ((const int32_t*)r->p.mode)[j], o->pad = 0;
+  const double* det = (const double*)r->p.det;
+  o->det_always[0] = det[j * (r->cplx ? 2 : 1)], o->det_always[1] = r->cplx ? det[2 * j + 1] : 0.0;
+  const int64_t bo = ((const int64_t*)r->p.bra_off)[j];
+  o->bra_p = (const int32_t*)r->p.bra_p + bo, o->bra_alpha = (const int32_t*)r->p.bra_alpha + bo;
+  return TMF_OK;
+}
+
+extern "C" int tmf_result_block(const tmf_result* r, int64_t i, int64_t jb, tmf_block_view* o) {
+  if (!r || !o || i < r->s_lo || i >= r->s_hi) {
+    set_error("tmf_result_block: site %lld is outside this site range", (long long)i);
+    return TMF_E_ARG;
+  }
+  const int64_t j = i - r->s_lo;
+  if (jb < 0 || jb >= ((const int64_t*)r->p.nsec)[j]) {
+    set_error("tmf_result_block: site %lld has %lld blocks", (long long)i, (long long)((const int64_t*)r->p.nsec)[j]);
+    return TMF_E_ARG;
+  }
+  const tmf_sector& s = ((const tmf_sector*)r->p.sectors)[((const int64_t*)r->p.sec_off)[j] + jb];
+  o->q = s.q, o->r0 = s.r0, o->r1 = s.r1, o->c0 = s.c0, o->c1 = s.c1, o->n = s.n;
+  o->data = (const char*)r->p.out + (size_t)(((const int64_t*)r->p.out_off)[j] + s.out_off) * (size_t)r->dims.elem_bytes;
+  return TMF_OK;
+}
+
+extern "C" int tmf_result_checks(const tmf_result* r, double* checks, int32_t* n_checks) {
+  if (!r || !checks || !n_checks) return TMF_E_ARG;
+  *n_checks = r->n_checks;
+  memcpy(checks, r->checks, sizeof(double) * (size_t)r->n_checks);
+  return TMF_OK;
+}
+
+extern "C" void tmf_result_free(tmf_result* r) {
+  if (!r) return;
+  r->buf.release();
+  delete r;
+}

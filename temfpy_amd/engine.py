@@ -166,10 +166,14 @@ class Engine:
         self.force_direct_det = bool(int(os.environ.get("TMF_DIRECT_DET", "0")))  # A/B switch
         self.time_gemm = False   # bench.py: HIP events around every MFMA GEMM launch
         self.gemm_events = []
+        self._sweep_max = []     # device scalars: largest Jacobi sweep count of every launch since the last check
         self._inflight = []      # (event, references) of downloads still running on the copy stream
         self._copy_stream = torch.cuda.Stream(device=self.device)   # device -> host: the tensors of a result
         self._up_stream = torch.cuda.Stream(device=self.device)     # host -> device: index lists
         self._sink = None
+        self._ctx = None         # tmf_ctx of the C++ sweep (created on first use)
+        self._tickets = []       # (download ticket, host buffer) of results still being copied
+        self.kernel_info = None
         self.coord = None        # multi-rank runs: object with .max(np.ndarray) -> elementwise max over the ranks
 
     # ------------------------------------------------------------------ plumbing
@@ -332,6 +336,9 @@ class Engine:
         d["thresh2"] = thresh2
         if out_field == "V":
             d["ldu"] = 1
+        # sweep count of every problem: the cap (60) means "not converged" and is checked at the next host round trip
+        d_sw = self.torch.zeros(sel.size, dtype=self.torch.int32, device=self.device)
+        self._keep.append(d_sw)
         if big:
             if not left_only:   # workspace for the accumulated rotations
                 pp = p[sel]
@@ -341,16 +348,14 @@ class Engine:
                 d["V"], d["ldv"] = d_ws.data_ptr() + wo[:-1] * self.elem, pp
             dd = self._up(d)
             nat.check(self.lib.tmf_jacobi_block_batched(self.dtype, 0 if left_only else 1, dd.data_ptr(), sel.size,
-                                                        int(p.max()), None, self.stream), "tmf_jacobi_block_batched")
-            return
-        dd = self._up(d)
-        fn = self.lib.tmf_svd_left_batched if left_only else self.lib.tmf_jacobi_batched
-        d_sw = None
+                                                        int(p.max()), d_sw.data_ptr(), self.stream), "tmf_jacobi_block_batched")
+        else:
+            dd = self._up(d)
+            fn = self.lib.tmf_svd_left_batched if left_only else self.lib.tmf_jacobi_batched
+            nat.check(fn(self.dtype, dd.data_ptr(), sel.size, int(p.max()), d_sw.data_ptr(), self.stream),
+                      "tmf_svd_left_batched" if left_only else "tmf_jacobi_batched")
+        self._sweep_max.append(d_sw.amax())
         if os.environ.get("TMF_JACOBI_SWEEPS"):  # debugging aid: sweep statistics of every launch
-            d_sw = self.torch.zeros(sel.size, dtype=self.torch.int32, device=self.device)
-        nat.check(fn(self.dtype, dd.data_ptr(), sel.size, int(p.max()), None if d_sw is None else d_sw.data_ptr(),
-                     self.stream), "tmf_svd_left_batched" if left_only else "tmf_jacobi_batched")
-        if d_sw is not None:
             h = d_sw.cpu().numpy()
             print(f"jacobi(left_only={left_only}) p<= {int(p.max())}: sweeps min {h.min()} mean {h.mean():.1f} "
                   f"max {h.max()}; hist {np.bincount(h).tolist()}", flush=True)
@@ -547,6 +552,13 @@ class Engine:
             views.append(h[: t.numel()].numpy())
         return _GpuWait(self.torch, self.device), views
 
+    def _sweeps_tensor(self):
+        """Largest sweep count of every Jacobi launch since the last call, as one small device tensor."""
+        t = (self.torch.stack(self._sweep_max) if self._sweep_max
+             else self.torch.zeros(1, dtype=self.torch.int32, device=self.device))
+        self._sweep_max = []
+        return t
+
     def _hbuf(self, name, shape, dtype, zero=False, pinned=False):
         """Persistent host scratch (grow-only, pre-faulted).  Fresh ``np.zeros`` arrays of this size
         are lazily mapped, and their first-touch page faults inside the 16 enumeration threads
@@ -623,8 +635,9 @@ class Engine:
             nest = (x, side, Cp, d_Om.data_ptr())
             full = doE & (p == P) & (P < np.minimum(n, m))              # cuts the range finder truncates
             st = self.entangled_stage(L, n, m, blk, off, omp, doE, p, thr2, P, iterations=0, nest=nest)
-            w_, (h_sig, h_cnt, h_e) = self._fetch_async([st["d_sig"], st["d_cnt"], st["d_e"]])
+            w_, (h_sig, h_cnt, h_e, h_sw) = self._fetch_async([st["d_sig"], st["d_cnt"], st["d_e"], self._sweeps_tensor()])
             yield w_
+            nat.check_jacobi_sweeps(h_sw, "Jacobi SVD / eigendecomposition of a cut (replaces eigh, slater.py:347)")
             h_sig, h_cnt, h_e, oS = h_sig.copy(), h_cnt.copy(), h_e.copy(), st["oS"]
             worst = max((h_sig[oS[i] + P - 1] for i in np.nonzero(full)[0]), default=0.0)
             sat = np.nonzero(full & (h_cnt >= p))[0]
@@ -635,8 +648,9 @@ class Engine:
             if worst > self.range_floor_tol:
                 st = self.entangled_stage(L, n, m, blk, off, omp, doE, p, thr2, P, iterations=1, nest=nest)
                 its = 1
-                w_, (h_sig, h_cnt, h_e) = self._fetch_async([st["d_sig"], st["d_cnt"], st["d_e"]])
+                w_, (h_sig, h_cnt, h_e, h_sw) = self._fetch_async([st["d_sig"], st["d_cnt"], st["d_e"], self._sweeps_tensor()])
                 yield w_
+                nat.check_jacobi_sweeps(h_sw, "Jacobi SVD / eigendecomposition of a cut (replaces eigh, slater.py:347)")
                 h_sig, h_cnt, h_e, oS = h_sig.copy(), h_cnt.copy(), h_e.copy(), st["oS"]
                 bad = [i for i in np.nonzero(full)[0] if h_sig[oS[i] + P - 1] > 4.6e-4 * thr2**0.5]
                 sat = np.nonzero(full & (h_cnt >= p))[0]
@@ -706,9 +720,160 @@ class Engine:
         return (C + C.conj().T) / 2, steps
 
     # ------------------------------------------------------------------ the sweep
+    sweep_impl = os.environ.get("TMF_SWEEP", "cpp")    # "cpp": tmf_sweep_* (csrc/sweep.cpp); "python": run_gen below (A/B)
+
     def run(self, C, trunc, ortho_center, unit_cell_width, threads=None, download=True, site_range=None, sink=None):
-        """One C -> MPS conversion (blocking form of :meth:`run_gen`)."""
-        return _drive(self.run_gen(C, trunc, ortho_center, unit_cell_width, threads, download, site_range, sink=sink))
+        """One C -> MPS conversion.  The sweep itself - descriptor construction, stage sequencing, the two host round
+        trips - runs in C++ behind the staged C ABI ``tmf_sweep_*``; this method checks arguments, applies the adaptive
+        range-finder rule (reduced over the ranks of a sharded conversion) and wraps the result.
+
+        C            (L, L) NumPy array, or a row-major torch tensor already resident in HBM
+        download     True: tensors in host memory on return.  "async": returns once everything is enqueued; the tensors
+                     land in page-locked host memory while the caller goes on (the next conversion's kernels overlap
+                     the 1.5 GB transfer); ``result.wait()`` - called by the site objects on first access - blocks
+                     until they are there.  False keeps the tensors in HBM and returns no site blocks
+        site_range   (a, b): only sites a <= i < b and the cuts next to them (one rank's shard)
+        sink         where the host copy of the result lives (default: page-locked memory; the multi-GPU path passes
+                     shared-memory segments, multi_gpu.ShmSink)"""
+        if self.sweep_impl != "cpp":
+            return _drive(self.run_gen(C, trunc, ortho_center, unit_cell_width, threads, download, site_range, sink=sink))
+        import ctypes
+        torch, lib = self.torch, self.lib
+        t_all = time.perf_counter()
+        if self._ctx is None:
+            ctx = ctypes.c_void_p()
+            nat.check(lib.tmf_ctx_create(self.device.index or 0, ctypes.byref(ctx)), "tmf_ctx_create")
+            self._ctx = ctx
+        ctx = self._ctx
+        self._tickets = [f for f in self._tickets if not self._ticket_done(f[0])]
+        flags = 0
+        if isinstance(C, torch.Tensor):
+            torch.cuda.current_stream(self.device).synchronize()     # the sweep runs on the context's own streams
+            d_Crm = C.reshape(-1)
+            cplx = d_Crm.is_complex()
+            L = int(round(d_Crm.numel() ** 0.5))
+            c_ptr, flags, keep_c = d_Crm.data_ptr(), nat.SWEEP_C_ON_DEVICE, d_Crm
+        else:
+            C = np.asarray(C)
+            cplx = np.iscomplexobj(C)
+            C = np.ascontiguousarray(C, np.complex128 if cplx else np.float64)
+            L = len(C)
+            c_ptr, keep_c = C.ctypes.data, C
+        self.dtype, self.elem = (nat.TMF_C128, 16) if cplx else (nat.TMF_F64, 8)
+        s_lo, s_hi = site_range if site_range is not None else (0, L)
+        sectors = _sector_list(trunc, L)
+        sec = None if sectors is None else np.ascontiguousarray(sectors, np.int64)
+        flags |= (nat.SWEEP_CHECKS if self.checks else 0) | (nat.SWEEP_TIME_KERNELS if self.time_gemm else 0)
+        flags |= (nat.SWEEP_RANGE_BCGS if self.range_qr != "house" else 0) | (0 if self.filled_cholqr else nat.SWEEP_NO_CHOLQR)
+        flags |= nat.SWEEP_TWO_PASSES if self.filled_passes >= 2 else 0
+        flags |= nat.SWEEP_DET_DIRECT if self.force_direct_det else (nat.SWEEP_DET_REDUCED if self.det_method != "ppt" else 0)
+        par = nat.SweepParams(L=L, chi_max=int(trunc.chi_max or 0), svd_min=float(trunc.svd_min),
+                              degeneracy_tol=float(trunc.degeneracy_tol), sectors=None if sec is None else sec.ctypes.data,
+                              ortho_center=int(ortho_center), site_lo=int(s_lo), site_hi=int(s_hi),
+                              n_sectors=0 if sec is None else int(sec.size), is_complex=int(cplx),
+                              host_threads=int(threads or min(16, os.cpu_count() or 1)), flags=flags)
+        nat.check(lib.tmf_sweep_begin(ctx, c_ptr, ctypes.byref(par)), "tmf_sweep_begin")
+        del keep_c
+
+        # ---- entangled stage with the narrowest adequate range finder (see entangled_stage_adaptive_gen): adequacy is
+        # CHECKED, the decisions are taken on the maximum over all ranks ----
+        worst, sat, weak, sw, bad = (ctypes.c_double(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64())
+
+        def stage(P, its):
+            nat.check(lib.tmf_sweep_entangled(ctx, P, its, ctypes.byref(worst), ctypes.byref(sat), ctypes.byref(weak),
+                                              ctypes.byref(sw), ctypes.byref(bad)), "tmf_sweep_entangled")
+            nat.check_jacobi_sweeps([sw.value], "Jacobi SVD / eigendecomposition of a cut (replaces eigh, slater.py:347)")
+
+        reason, accepted = "", False
+        for P in self.range_ladder:
+            stage(P, 0)
+            g_worst, any_sat = self._gmax([worst.value, float(sat.value)])
+            self.range_floor, its = float(g_worst), 0
+            if g_worst > self.range_floor_tol:
+                stage(P, 1)
+                its = 1
+                any_weak, any_sat = self._gmax([float(weak.value), float(sat.value)])
+                if any_weak:
+                    reason = (f"cut {bad.value}: smallest captured singular value {worst.value:.1e} vs threshold "
+                              f"{(trunc.svd_min ** 2 * (1 - trunc.svd_min ** 2)) ** 0.5:.1e} with {P} columns" if weak.value
+                              else "another rank's cut needs a wider range finder")
+                    continue
+            if any_sat:
+                reason = (f"cut {bad.value}: {P} or more orbitals above the range-finder threshold" if sat.value
+                          else "another rank's cut has more orbitals above the threshold than the range finder is wide")
+                continue
+            self.range_iterations_used, self.range_width, accepted = its, P, True
+            break
+        if not accepted:
+            raise NotImplementedError(f"entanglement rank beyond the widest range finder ({self.range_ladder[-1]} "
+                                      f"columns): {reason}")
+
+        dims = nat.SweepDims()
+        nat.check(lib.tmf_sweep_sites(ctx, ctypes.byref(dims)), "tmf_sweep_sites")
+        want_out = download is not False
+        entries, total = ShardArrays.plan(nat.sweep_spec(dims, cplx, want_out))
+        buf, keep = (sink or self.default_sink()).alloc(total)
+        shard = ShardArrays.create(buf, entries, dict(L=int(L), s_lo=int(s_lo), s_hi=int(s_hi), ortho_center=int(ortho_center),
+                                                      complex=bool(cplx)), keepalive=keep)
+        ptrs = nat.SweepPtrs(**{k_: shard.arrays[k_].ctypes.data for k_ in nat.SWEEP_ARRAYS})
+        ticket = ctypes.c_int64()
+        nat.check(lib.tmf_sweep_download(ctx, ctypes.byref(ptrs), int(want_out), ctypes.byref(ticket)), "tmf_sweep_download")
+        self._tickets.append((ticket.value, keep))      # the host buffer stays referenced until the copy is done
+        chk_names = ["vL is not unitary", "vL does not diagonalise C_LL", "vR is not unitary", "vR does not diagonalise C_RR",
+                     "vL and vR do not SVD C_LR"]
+        state = {}
+
+        def wait():
+            if "checks" in state:
+                return
+            vals, nchk = (ctypes.c_double * 8)(), ctypes.c_int32()
+            nat.check(lib.tmf_sweep_wait(ctx, ticket.value, vals, ctypes.byref(nchk)), "tmf_sweep_wait")
+            state["checks"] = dict(zip(chk_names, (float(v) for v in vals[: nchk.value])))
+            shard.wait = None
+            shard.check_det()
+
+        shard.wait = wait
+        self.timings = self._stage_timings()
+        res = MPSData.from_shards([shard], ortho_center, unit_cell_width, self.timings, with_sites=want_out)
+        if want_out and isinstance(keep, torch.Tensor):
+            # the page-locked array all blocks are views of, as a tensor (gutzwiller: re-upload in one copy)
+            o_ = entries["out"][2]
+            res._flat_t = keep[o_: o_ + int(dims.out_elems) * self.elem].view(torch.complex128 if cplx else torch.float64)
+        if download == "async":
+            self.check_results = {}
+            res._lazy_checks = lambda: (wait(), state["checks"])[1]
+            return self._finish(res)
+        wait()
+        self.check_results = state["checks"]
+        self.timings = self._stage_timings()
+        self.timings["total"] = time.perf_counter() - t_all
+        res.timings = dict(self.timings)
+        return self._finish(res)
+
+    def _ticket_done(self, ticket):
+        return self.lib.tmf_sweep_query(self._ctx, ticket) != 0
+
+    def _stage_timings(self):
+        """Host wall time per stage of the last sweep (seconds), and - with ``time_gemm`` - the kernel times measured with
+        HIP events on the launch stream (``self.kernel_info``: gemm_ms / gemm_flops over all MFMA GEMM launches of the
+        conversion, det_ms / det_flops of the dominant determinant launch, det_all_ms, n_det)."""
+        import ctypes
+        info = nat.SweepInfo()
+        nat.check(self.lib.tmf_sweep_info_get(self._ctx, ctypes.byref(info)), "tmf_sweep_info_get")
+        self.kernel_info = info
+        out = {}
+        for i in range(16):
+            name = self.lib.tmf_sweep_stage_name(i).decode()
+            if name:
+                out[name] = info.stage_ms[i] * 1e-3
+        return out
+
+    def device_result(self):
+        """(device address, element count) of the tensors of the last conversion (valid until the next one)."""
+        import ctypes
+        p, n = ctypes.c_uint64(), ctypes.c_int64()
+        nat.check(self.lib.tmf_sweep_device_out(self._ctx, ctypes.byref(p), ctypes.byref(n)), "tmf_sweep_device_out")
+        return p.value, n.value
 
     def run_gen(self, C, trunc, ortho_center, unit_cell_width, threads=None, download=True, site_range=None,
                 diag=None, presynced=False, sink=None):

@@ -686,23 +686,22 @@ class _Projector:
             # (the last tensor was normalised by its own QR: X of the right end stays 1)
             d_sv[So[Ls][end]] = 1.0
             d_cnt[cnt_index[(Ls, end)]] = 1
-            d_sw = None
-            if os.environ.get("TMF_JACOBI_SWEEPS"):     # development aid: sweep counts of every Jacobi problem
-                d_sw = torch.zeros(n_sec_tot, dtype=torch.int32, device=self.device)
+            d_sw = torch.zeros(n_sec_tot, dtype=torch.int32, device=self.device)   # sweep count of every Jacobi problem
             for gw_, cw_, qw_, qw2_, (i0, nj, pmax), gb_, gx_ in steps2:
                 gemm(gw_, s1)
                 copy(cw_, s1)
                 qr(qw_, s1)
                 qr(qw2_, s1)
                 nat.check(lib.tmf_jacobi_compact_batched(self.dt, tabs_d["jc"].data_ptr() + 64 * i0, nj, pmax,
-                                                         None if d_sw is None else d_sw.data_ptr() + 4 * i0, s1),
+                                                         d_sw.data_ptr() + 4 * i0, s1),
                           "tmf_jacobi_compact_batched")
                 gemm(gb_, s1)
                 gemm(gx_, s1)
             torch.cuda.synchronize(self.device)
             self.timings["sweep2"] = time.perf_counter() - t3
-            if d_sw is not None:
-                h = d_sw.cpu().numpy()
+            h = d_sw.cpu().numpy()
+            nat.check_jacobi_sweeps(h, "Jacobi SVD of the canonicalisation sweep (npc.svd in canonical_form_finite)")
+            if os.environ.get("TMF_JACOBI_SWEEPS"):     # development aid
                 big = jd["p"] >= 0.8 * jd["p"].max()
                 print(f"[gutzwiller] Jacobi sweeps: all problems mean {h.mean():.1f} max {h.max()}; p >= {int(0.8 * jd['p'].max())}: "
                       f"mean {h[big].mean():.1f} hist {np.bincount(h[big]).tolist()}", flush=True)
@@ -726,11 +725,13 @@ class _Projector:
             t3 = time.perf_counter()
             gemm(tail[0], s1, alpha=1.0 / norm)
             qr(tail[3], s1)
-            nat.check(lib.tmf_jacobi_compact_batched(self.dt, tabs_d["jc"].data_ptr(), n_sec_tot, int(jd["p"].max()), None,
-                                                     s1), "tmf_jacobi_compact_batched")
+            d_sw = torch.zeros(n_sec_tot, dtype=torch.int32, device=self.device)
+            nat.check(lib.tmf_jacobi_compact_batched(self.dt, tabs_d["jc"].data_ptr(), n_sec_tot, int(jd["p"].max()),
+                                                     d_sw.data_ptr(), s1), "tmf_jacobi_compact_batched")
             gemm(tail[1], s1)
             gemm(tail[2], s1, opA=1)
             torch.cuda.synchronize(self.device)
+            nat.check_jacobi_sweeps(d_sw.cpu().numpy(), "Jacobi SVD of the bond matrices (npc.svd in canonical_form_finite)")
             self.timings["svd+gauge"] = time.perf_counter() - t3
         # ================= results =================
         t4 = time.perf_counter()

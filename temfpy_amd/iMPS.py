@@ -377,14 +377,16 @@ def basis_rotation(overlap: BlockMatrix, Schmidt_bra: np.ndarray, Schmidt_ket: n
         gr.append((d_U.data_ptr() + el * o, d_VH.data_ptr() + el * o, d_R.data_ptr() + el * o, p, p, p, p, p, p))
     if keys:
         t_j = dev.up(jd.view(np.uint8).reshape(-1))
-        nat.check(dev.lib.tmf_jacobi_compact_batched(dev.dt, t_j.data_ptr(), len(keys), int(max(ps)), None, dev.stream),
-                  "tmf_jacobi_compact_batched")
+        d_sw = dev.torch.zeros(len(keys), dtype=dev.torch.int32, device=dev.device)
+        nat.check(dev.lib.tmf_jacobi_compact_batched(dev.dt, t_j.data_ptr(), len(keys), int(max(ps)), d_sw.data_ptr(),
+                                                     dev.stream), "tmf_jacobi_compact_batched")
         dev.gemm(gg)                                               # G = M V = U S
         t_n = dev.up(cn.view(np.uint8).reshape(-1))
         nat.check(dev.lib.tmf_normalise_columns_batched(dev.dt, t_n.data_ptr(), len(keys), dev.stream), "normalise")
         dev.copy(cp)                                               # V^H
         dev.gemm(gr)                                               # rotation = U V^H
         dev.torch.cuda.synchronize(dev.device)
+        nat.check_jacobi_sweeps(d_sw.cpu().numpy(), "Jacobi SVD of the overlap blocks (npc.svd, iMPS.py:158)")
     h_R = d_R.cpu().numpy()
     rot = {}
     for k, p, o in zip(keys, ps, off[:-1]):

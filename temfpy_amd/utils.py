@@ -55,13 +55,16 @@ def _device_svd(mats, device, want_vectors):
                  1e-300, p, p, p, p)
         items.append((d_M.data_ptr() + el * o, d_V.data_ptr() + el * o, d_G.data_ptr() + el * o, p, p, p, p, p, p))
     t_j = torch.from_numpy(jd.view(np.uint8).reshape(-1).copy()).to(dev)
-    nat.check(lib.tmf_jacobi_compact_batched(dt, t_j.data_ptr(), len(mats), int(max(ps)), None, stream), "tmf_jacobi_compact_batched")
+    d_sw = torch.zeros(len(mats), dtype=torch.int32, device=dev)
+    nat.check(lib.tmf_jacobi_compact_batched(dt, t_j.data_ptr(), len(mats), int(max(ps)), d_sw.data_ptr(), stream),
+              "tmf_jacobi_compact_batched")
     if want_vectors:     # U S = M V
         g = _gemm_recs(items)
         tiles, tn = _gemm_tiles(g)
         t_g, t_t = torch.from_numpy(g.view(np.uint8).reshape(-1).copy()).to(dev), torch.from_numpy(tiles.reshape(-1).copy()).to(dev)
         nat.check(lib.tmf_gemm_batched(dt, 0, 1.0, 0.0, t_g.data_ptr(), t_t.data_ptr(), len(tiles), tn, stream), "tmf_gemm_batched")
     torch.cuda.synchronize(dev)
+    nat.check_jacobi_sweeps(d_sw.cpu().numpy(), "Jacobi SVD (numpy.linalg.svd in utils.block_svd)")
     h_s, h_V, h_G = d_s.cpu().numpy(), d_V.cpu().numpy(), d_G.cpu().numpy()
     out = []
     for i, (m, p, o) in enumerate(zip(mats, ps, off[:-1])):

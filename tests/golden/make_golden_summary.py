@@ -9,8 +9,8 @@ gauge transformation cannot change (eigenvectors are defined up to a phase, so t
 equal only up to a diagonal unitary on every bond):
 
   per bond   chi, the normalised Schmidt values (float64), S(b), the unnormalised norm,
-             n_filled L/R, the entangled eigenvalues e, SHA-1 of the occupation patterns
-             (``sets`` packed little-endian, rows in the reference's order) and of q_left
+             n_filled L/R, the entangled eigenvalues e, the occupation patterns (``sets`` packed
+             little-endian, rows in the reference's order; also their SHA-1) and SHA-1 of q_left
   per site   Frobenius norm of every charge block (det_always included, slater.py:1137-1141),
              |det_always|, and the 2-norm of every row of the merged (p, bra) leg (float32)
 
@@ -60,6 +60,7 @@ def summarise(slater, C, chi_max, ortho_center=None, spinful=None, log=None):
     nfill = np.zeros((L + 1, 2), np.int64)
     lam, e, h_sets, h_q = [None] * (L + 1), [None] * (L + 1), np.zeros((L + 1, 20), np.uint8), np.zeros((L + 1, 20), np.uint8)
     blkq, blkn, rown, deta = [None] * L, [None] * L, [None] * L, np.zeros(L)
+    packed = [None] * (L + 1)
 
     def put_bond(b, V):
         m = V.modes
@@ -74,7 +75,8 @@ def summarise(slater, C, chi_max, ortho_center=None, spinful=None, log=None):
         chi[b] = len(sv)
         e[b] = np.asarray(m.e, np.float64)
         nfill[b] = m.n_filled("L"), m.n_filled("R")
-        h_sets[b] = sha(np.packbits(np.asarray(sets, bool), axis=1, bitorder="little"))
+        packed[b] = np.packbits(np.asarray(sets, bool), axis=1, bitorder="little").reshape(-1)
+        h_sets[b] = sha(packed[b])
         q = np.zeros(len(sv), np.int64)
         for k, sl in V.idx_L.items():
             q[sl] = k
@@ -128,8 +130,9 @@ def summarise(slater, C, chi_max, ortho_center=None, spinful=None, log=None):
     bq_f, b_off = flat(blkq, np.int64)
     bn_f, _ = flat(blkn, np.float64)
     rn_f, r_off = flat(rown, np.float32)
+    pk_f, pk_off = flat(packed, np.uint8)
     return dict(L=L, ortho_center=oc, chi_max=chi_max, chi=chi, S=S, lam_norm=nrm, n_filled=nfill, lam=lam_f, lam_off=lam_off,
-                e=e_f, e_off=e_off, sets_sha1=h_sets, q_sha1=h_q, blk_q=bq_f, blk_norm=bn_f, blk_off=b_off,
+                e=e_f, e_off=e_off, sets_packed=pk_f, sets_off=pk_off, sets_sha1=h_sets, q_sha1=h_q, blk_q=bq_f, blk_norm=bn_f, blk_off=b_off,
                 row_norm=rn_f, row_off=r_off, abs_det_always=deta, reference_wall_s=np.array(wall),
                 reference_cores=np.array(len(os.sched_getaffinity(0))))
 

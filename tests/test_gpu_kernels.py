@@ -892,3 +892,50 @@ def test_house_slab_qr(eng, cplx):
         assert np.all(Q[:, K:] == 0)
         scale = max(np.abs(A).max(), 1e-300)
         np.testing.assert_allclose(Q @ (Q.conj().T @ A), A, rtol=0, atol=1e-13 * scale * n ** 0.5)   # span(Q) contains A
+
+
+def test_single_call_sweep_entry_point_and_accessors():
+    """tmf_slater_sweep (the one-call form of the staged sweep ABI, include/temfpy_hip.h "Sweep level") through ctypes,
+    read back with the tmf_result_* accessors, against the Python entry point that drives the staged calls."""
+    import ctypes
+    from tests_inputs import random_hopping
+    from temfpy_amd import slater, _native as nat
+
+    L, chi = 40, 24
+    C, _ = slater.correlation_matrix(random_hopping(L, 4))
+    ref = slater.C_to_MPS(C, {"chi_max": chi}, as_tenpy=False)
+    lib = nat.load()
+    ctx, res = ctypes.c_void_p(), ctypes.c_void_p()
+    nat.check(lib.tmf_ctx_create(0, ctypes.byref(ctx)), "tmf_ctx_create")
+    Cc = np.ascontiguousarray(C, np.complex128)
+    par = nat.SweepParams(L=L, chi_max=chi, svd_min=1e-6, degeneracy_tol=1e-12, sectors=None, ortho_center=L // 2, site_lo=0,
+                          site_hi=L, n_sectors=0, is_complex=1, host_threads=4, flags=nat.SWEEP_CHECKS)
+    nat.check(lib.tmf_slater_sweep(ctx, Cc.ctypes.data, ctypes.byref(par), 0.0, ctypes.byref(res)), "tmf_slater_sweep")
+    try:
+        for b in range(L + 1):
+            v = nat.BondView()
+            nat.check(lib.tmf_result_bond(res, b, ctypes.byref(v)), "tmf_result_bond")
+            bd = ref.bonds[b]
+            assert (v.chi, v.k, v.n_filled_left, v.n_filled_right) == (bd.chi, len(bd.e), bd.n_filled_left, bd.n_filled_right)
+            lam = np.ctypeslib.as_array(ctypes.cast(v.lam_raw, ctypes.POINTER(ctypes.c_double)), (v.chi,))
+            masks = np.ctypeslib.as_array(ctypes.cast(v.masks, ctypes.POINTER(ctypes.c_uint64)), (v.chi, 2))
+            assert np.array_equal(lam, bd.lam_raw) and np.array_equal(masks, bd.masks)
+        for i in range(L):
+            sv = nat.SiteView()
+            nat.check(lib.tmf_result_site(res, i, ctypes.byref(sv)), "tmf_result_site")
+            s = ref.sites[i]
+            assert (sv.chi_bra, sv.chi_ket, sv.n_blocks) == (s.chi_bra, s.chi_ket, len(s.blocks))
+            assert complex(sv.det_always[0], sv.det_always[1]) == s.det_always
+            for j, (q, r0, r1, c0, c1, blk) in enumerate(s.blocks):
+                bv = nat.BlockView()
+                nat.check(lib.tmf_result_block(res, i, j, ctypes.byref(bv)), "tmf_result_block")
+                assert (bv.q, bv.r0, bv.r1, bv.c0, bv.c1) == (q, r0, r1, c0, c1)
+                got = np.ctypeslib.as_array(ctypes.cast(bv.data, ctypes.POINTER(ctypes.c_double)), (r1 - r0, c1 - c0, 2))
+                assert np.array_equal(got[..., 0] + 1j * got[..., 1], blk)
+        checks, n = (ctypes.c_double * 8)(), ctypes.c_int32()
+        nat.check(lib.tmf_result_checks(res, checks, ctypes.byref(n)), "tmf_result_checks")
+        assert n.value == 5 and max(checks[:5]) < 1e-6
+        assert lib.tmf_result_bond(res, L + 3, ctypes.byref(nat.BondView())) == -1
+    finally:
+        lib.tmf_result_free(res)
+        lib.tmf_ctx_destroy(ctx)

@@ -170,3 +170,42 @@ def test_report_schmidt_checks_follows_test_action():
             testing.report_schmidt_checks(dev, 1e-8)
     finally:
         testing.TEST_ACTION = old
+
+
+def test_batch_error_message_reaches_the_calling_thread():
+    """tmf_last_error is thread-local; a failure inside a worker thread of the batched host entry points must
+    still surface with its text (limit: 128 entangled orbitals per cut) on the thread that called."""
+    lib = nat.load()
+    ncut = 12
+    k = np.full(ncut, 4, np.int32)
+    k[9] = 130                               # handled by a worker thread, not by the caller
+    e_off = np.concatenate(([0], np.cumsum(k)[:-1])).astype(np.int64)
+    e_pool = np.linspace(0.1, 0.9, int(k.sum()))
+    nfl = np.zeros(ncut, np.int32)
+    cap = 9
+    sets, lam, q = np.zeros((ncut, cap, 2), np.uint64), np.zeros((ncut, cap)), np.zeros((ncut, cap), np.int32)
+    chi, chk = np.zeros(ncut, np.int64), np.zeros(ncut, np.int64)
+    st = lib.tmf_cut_vectors_batch(ncut, nat._p(e_pool), nat._p(e_off), nat._p(k), nat._p(nfl), 8, 1e-6, 1e-12, None, 0, cap,
+                                   nat._p(sets), nat._p(lam), nat._p(q), nat._p(chi), nat._p(chk), 4)
+    assert st == -3
+    msg = lib.tmf_last_error().decode()
+    assert "130 entangled orbitals" in msg and "item 9" in msg, msg
+    with pytest.raises(NotImplementedError, match="130 entangled orbitals"):
+        nat.check(st, "tmf_cut_vectors_batch")
+
+
+@pytest.mark.skipif(not os.environ.get("TMF_ASAN_LIB"), reason="set TMF_ASAN_LIB to the sanitizer build (make -C temfpy_amd/csrc asan)")
+def test_sanitizer_build_marker():
+    """`make -C temfpy_amd/csrc asan` builds host_enum.cpp with -fsanitize=address,undefined into
+    libtemfpy_host_asan.so; tools/run_host_asan.sh runs this file against it (the GPU objects are absent there,
+    so only the host entry points are exercised)."""
+    assert os.path.exists(os.environ["TMF_ASAN_LIB"])
+
+
+def test_jacobi_sweep_cap_means_not_converged():
+    """The Jacobi kernels report their sweep count per problem; the cap is 'rotations still pending' and must
+    raise like LAPACK's non-convergence (numpy.linalg.LinAlgError), not flow on silently."""
+    nat.check_jacobi_sweeps(np.array([3, 7, 59], np.int32))
+    nat.check_jacobi_sweeps(np.zeros(0, np.int32))
+    with pytest.raises(np.linalg.LinAlgError, match="did not converge in 60 sweeps"):
+        nat.check_jacobi_sweeps(np.array([3, 60, 5], np.int32))
