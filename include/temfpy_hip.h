@@ -156,6 +156,24 @@ typedef struct {
  * read in place at W + k + k*ldw. */
 int tmf_lu_schur_batched(int dtype, const tmf_schur_desc* d_desc, int nprob, int max_mb, void* stream);
 
+/* The same factorisation as tmf_lu_schur_batched, blocked over several launches so that the rank-64 trailing
+ * update of all sites is one batched MFMA GEMM (tmf_gemm_batched with alpha = -1, beta = 1) instead of VALU code
+ * inside a one-workgroup-per-site kernel.  For j0 = 0, 64, 128, ... < max k:
+ *   tmf_lu_block_batched   pivoted LU (pivots among the always rows) of the columns [j0, min(k, j0 + 64)) of every
+ *                          site with k > j0, rows j0 .. mb-1; L stays in W, the pivot rows go to `piv`, det(A) is
+ *                          accumulated in `det` (j0 = 0 initialises it; sites with k = 0 get det = 1)
+ *   tmf_lu_trsm_batched    the block's row interchanges on the trailing columns, then U12 = L11^-1 A12 into `T`
+ *   tmf_gemm_batched       A22 -= L21 U12   (A = W + cend + j0 ldw, B = T, C = W + cend + cend ldw, K = cend - j0)
+ * Afterwards det holds det(W[:k,:k]) and W[k:,k:] the Schur complement (slater.py:1077-1090). */
+typedef struct {
+  uint64_t W, det;           /* mb x mk workspace (ldw); one element                                 */
+  uint64_t piv;              /* int32[k]: absolute pivot row of every always column                  */
+  uint64_t T;                /* scratch 64 x mk elements (leading dimension 64)                      */
+  int32_t mb, mk, k, ldw;
+} tmf_lublock_desc;          /* 48 bytes */
+int tmf_lu_block_batched(int dtype, const tmf_lublock_desc* d_desc, int nprob, int j0, int wb, int max_mb, void* stream);
+int tmf_lu_trsm_batched(int dtype, const tmf_lublock_desc* d_desc, int nprob, int j0, int wb, int max_cols, void* stream);
+
 /* The hot kernel: batched gathered determinants (slater.py:828-869, `_tensor_block`,
  * 90 % of the reference's wall time).  For every tile, for every pair (a, b) of a bra
  * row and a ket row of one charge sector, out[a, b] = scale * det(S[rows(a)][:, cols(b)]).
@@ -492,6 +510,7 @@ void tmf_ctx_destroy(tmf_ctx* ctx);
 #define TMF_SWEEP_DET_DIRECT 32u   /* ... through tmf_det_gather_batched                                  */
 #define TMF_SWEEP_C_ON_DEVICE 64u  /* C is a device pointer (row-major) instead of host memory            */
 #define TMF_SWEEP_TWO_PASSES 128u  /* two projection passes in the filled-basis Gram-Schmidt              */
+#define TMF_SWEEP_LU_SINGLE 256u   /* Schur complements by tmf_lu_schur_batched (one workgroup per site; A/B)  */
 
 typedef struct {
   int64_t L;                 /* C is L x L, row-major, real (double) or complex (re, im doubles)          */

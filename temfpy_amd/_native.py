@@ -37,6 +37,9 @@ jacobi_desc = np.dtype([("X", "<u8"), ("V", "<u8"), ("U", "<u8"), ("s", "<u8"), 
                         ("thresh2", "<f8"), ("p", "<i4"), ("ldx", "<i4"), ("ldv", "<i4"), ("ldu", "<i4")])
 schur_desc = np.dtype([("W", "<u8"), ("S", "<u8"), ("det", "<u8"), ("mb", "<i4"), ("mk", "<i4"), ("k", "<i4"),
                        ("ldw", "<i4"), ("lds", "<i4"), ("pad", "<i4")])
+lublock_desc = np.dtype([("W", "<u8"), ("det", "<u8"), ("piv", "<u8"), ("T", "<u8"), ("mb", "<i4"), ("mk", "<i4"),
+                         ("k", "<i4"), ("ldw", "<i4")])
+assert lublock_desc.itemsize == 48
 det_desc = np.dtype([("S", "<u8"), ("scale", "<u8"), ("bra_idx", "<u8"), ("ket_idx", "<u8"), ("out", "<u8"),
                      ("sb", "<i4"), ("sk", "<i4"), ("lds", "<i4"), ("n", "<i4"), ("nsb", "<i4"), ("nsk", "<i4"),
                      ("a0", "<i4"), ("a1", "<i4")])
@@ -87,7 +90,7 @@ SYMBOLS = [
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_column_norms_batched", "tmf_cut_vectors",
     "tmf_site_prepare", "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_det_tiles_build", "tmf_pf_gather_batched",
     "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched", "tmf_copy_blocks_batched", "tmf_house_qr_batched", "tmf_jacobi_compact_batched", "tmf_house_slab_batched",
-    "tmf_host_register", "tmf_host_unregister", "tmf_memcpy_async",
+    "tmf_host_register", "tmf_host_unregister", "tmf_memcpy_async", "tmf_lu_block_batched", "tmf_lu_trsm_batched",
     "tmf_ctx_create", "tmf_ctx_destroy", "tmf_sweep_begin", "tmf_sweep_entangled", "tmf_sweep_sites", "tmf_sweep_download",
     "tmf_sweep_query", "tmf_sweep_wait", "tmf_sweep_info_get", "tmf_sweep_stage_name", "tmf_sweep_device_out",
     "tmf_slater_sweep", "tmf_result_dims", "tmf_result_bond", "tmf_result_site", "tmf_result_block", "tmf_result_checks",
@@ -96,7 +99,7 @@ SYMBOLS = [
 
 # ---- sweep-level structs (include/temfpy_hip.h, "Sweep level") ---------------------------------------------
 SWEEP_CHECKS, SWEEP_TIME_KERNELS, SWEEP_RANGE_BCGS, SWEEP_NO_CHOLQR = 1, 2, 4, 8
-SWEEP_DET_REDUCED, SWEEP_DET_DIRECT, SWEEP_C_ON_DEVICE, SWEEP_TWO_PASSES = 16, 32, 64, 128
+SWEEP_DET_REDUCED, SWEEP_DET_DIRECT, SWEEP_C_ON_DEVICE, SWEEP_TWO_PASSES, SWEEP_LU_SINGLE = 16, 32, 64, 128, 256
 
 
 class SweepParams(C.Structure):
@@ -213,6 +216,8 @@ def load():
     lib.tmf_normalise_columns_batched.argtypes = [i32, vp, i32, vp]
     lib.tmf_column_norms_batched.argtypes = [i32, vp, i32, vp]
     _set_host_argtypes(lib)
+    lib.tmf_lu_block_batched.argtypes = [i32, vp, i32, i32, i32, i32, vp]
+    lib.tmf_lu_trsm_batched.argtypes = [i32, vp, i32, i32, i32, i32, vp]
     lib.tmf_ctx_create.argtypes = [i32, C.POINTER(vp)]
     lib.tmf_ctx_destroy.argtypes = [vp]
     lib.tmf_ctx_destroy.restype = None

@@ -169,6 +169,233 @@ __global__ __launch_bounds__(256) void lu_schur_kernel(const tmf_schur_desc* __r
   }
 }
 
+
+// -------------------------------------------------------------------------------------------
+// Blocked form over several launches (tmf_lu_block_batched / tmf_lu_trsm_batched + the MFMA GEMM):
+// the one-workgroup-per-site kernel above streams the whole trailing matrix through L2 once per
+// 16-column panel with VALU arithmetic (13 % of the fp64 peak, 4.7x the algorithmic traffic,
+// measured).  Here an outer block of WB = 64 columns is factored by one workgroup per site
+// (lu_block_kernel: the same panel code, trailing updates confined to the block), the block's row
+// interchanges and the triangular solve U12 = L11^-1 A12 run one thread per trailing column
+// (lu_trsm_kernel), and the rank-64 update A22 -= L21 U12 of ALL sites is one batched MFMA GEMM
+// launch: the trailing matrix is read and written k / 64 times, by every CU.
+// -------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void lu_block_kernel(const tmf_lublock_desc* __restrict__ desc, const int j0, const int WB,
+                                                       const int NB) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const tmf_lublock_desc d = desc[blockIdx.x];
+  const int mb = d.mb, k = d.k, ldw = d.ldw;
+  T* __restrict__ W = reinterpret_cast<T*>(d.W);
+  int32_t* __restrict__ gpiv = reinterpret_cast<int32_t*>(d.piv);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (j0 >= k) {
+    if (j0 == 0 && tid == 0) *reinterpret_cast<T*>(d.det) = sc<T>::one();  // no always-block: det of the empty matrix
+    return;
+  }
+  const int cend = min(k, j0 + WB);  // columns of this outer block: [j0, cend)
+
+  T* P = reinterpret_cast<T*>(smem);
+  T* Uc = P + (size_t)(mb - j0) * NB;
+  double* rv = reinterpret_cast<double*>(Uc + UCH * NBMAX);
+  int* ri = reinterpret_cast<int*>(rv + 4);
+  int* pivs = ri + 4;
+
+  T det = (j0 == 0) ? sc<T>::one() : *reinterpret_cast<const T*>(d.det);
+
+  for (int jj = j0; jj < cend; jj += NB) {
+    const int jb = min(NB, cend - jj);
+    const int rows = mb - jj;   // panel rows jj .. mb-1
+    const int prow = k - jj;    // rows eligible as pivots: local [j, prow)
+    for (int e = tid; e < rows * jb; e += 256) {
+      const int r = e % rows, c = e / rows;
+      P[(size_t)c * rows + r] = W[(size_t)(jj + r) + (size_t)(jj + c) * ldw];
+    }
+    __syncthreads();
+    for (int j = 0; j < jb; ++j) {
+      T* pj = P + (size_t)j * rows;
+      double bv = -1.0;
+      int bi = j;
+      for (int r = j + tid; r < prow; r += 256) {
+        const double v = sc<T>::abs2(pj[r]);
+        if (v > bv) bv = v, bi = r;
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
+      }
+      if (lane == 0) rv[wave] = bv, ri[wave] = bi;
+      __syncthreads();
+      if (tid == 0) {
+        double b = rv[0];
+        int ix = ri[0];
+        for (int q = 1; q < 4; ++q)
+          if (rv[q] > b || (rv[q] == b && ri[q] < ix)) b = rv[q], ix = ri[q];
+        pivs[j] = ix;
+      }
+      __syncthreads();
+      const int piv = pivs[j];
+      if (piv != j && tid < jb) {
+        const T t = P[(size_t)tid * rows + j];
+        P[(size_t)tid * rows + j] = P[(size_t)tid * rows + piv];
+        P[(size_t)tid * rows + piv] = t;
+      }
+      __syncthreads();
+      const T pv = pj[j];
+      det = sc<T>::mul(det, pv);
+      if (piv != j) det = sc<T>::neg(det);
+      const T pinv = sc<T>::abs2(pv) > 0.0 ? sc<T>::inv(pv) : sc<T>::zero();
+      for (int r = j + 1 + tid; r < rows; r += 256) {
+        const T l = sc<T>::mul(pj[r], pinv);
+        pj[r] = l;
+        for (int c = j + 1; c < jb; ++c) {
+          T* pc = P + (size_t)c * rows;
+          pc[r] = sc<T>::fms(pc[r], l, pc[j]);
+        }
+      }
+      __syncthreads();
+    }
+    // the factored panel goes back: L21 is the A operand of the GEMM, L11 that of the triangular solve
+    for (int e = tid; e < rows * jb; e += 256) {
+      const int r = e % rows, c = e / rows;
+      W[(size_t)(jj + r) + (size_t)(jj + c) * ldw] = P[(size_t)c * rows + r];
+    }
+    if (tid < jb) gpiv[jj + tid] = jj + pivs[tid];
+    // ---- row interchanges on the other columns of this block: [j0, jj) (earlier panels' L) and [jj+jb, cend) ----
+    // (composing the jb interchanges into one permutation per panel, with independent loads per column, measured
+    // SLOWER: 411 vs 362 us per launch - the arrays it needs go to scratch)
+    const int nleft = jj - j0, nright = cend - (jj + jb);
+    for (int c = tid; c < nleft + nright; c += 256) {
+      const int cc = c < nleft ? j0 + c : jj + jb + (c - nleft);
+      T* col = W + (size_t)cc * ldw + jj;
+      for (int j = 0; j < jb; ++j) {
+        const int piv = pivs[j];
+        if (piv != j) {
+          const T t = col[j];
+          col[j] = col[piv];
+          col[piv] = t;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- trailing update inside the block: U12 = L11^-1 A12 ; A22 -= L21 U12 for columns [jj+jb, cend) ----
+    const int c0 = jj + jb;
+    const int ncols = nright;
+    const int r2 = rows - jb;
+    for (int cc = 0; cc < ncols; cc += UCH) {
+      const int nc = min(UCH, ncols - cc);
+      if (tid < nc) {
+        T* col = W + (size_t)(c0 + cc + tid) * ldw + jj;
+        T u[NBMAX];
+#pragma unroll
+        for (int q = 0; q < NBMAX; ++q) u[q] = (q < jb) ? col[q] : sc<T>::zero();
+#pragma unroll
+        for (int q = 0; q < NBMAX; ++q) {
+          if (q < jb) {
+#pragma unroll
+            for (int r = q + 1; r < NBMAX; ++r)
+              if (r < jb) u[r] = sc<T>::fms(u[r], P[(size_t)q * rows + r], u[q]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NBMAX; ++q) {
+          if (q < jb) {
+            col[q] = u[q];
+            Uc[tid * NBMAX + q] = u[q];
+          }
+        }
+      }
+      __syncthreads();
+      for (int rb = 0; rb < r2; rb += 256) {
+        const int r = rb + tid;
+        if (r < r2) {
+          T l[NBMAX];
+#pragma unroll
+          for (int q = 0; q < NBMAX; ++q) l[q] = (q < jb) ? P[(size_t)q * rows + jb + r] : sc<T>::zero();
+          T* rowp = W + (size_t)(jj + jb + r) + (size_t)(c0 + cc) * ldw;
+          for (int cb = 0; cb < nc; cb += 8) {
+            T x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = (cb + u < nc) ? rowp[(size_t)(cb + u) * ldw] : sc<T>::zero();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+              for (int q = 0; q < NBMAX; ++q)
+                if (q < jb) x[u] = sc<T>::fms(x[u], l[q], Uc[(cb + u) * NBMAX + q]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (cb + u < nc) rowp[(size_t)(cb + u) * ldw] = x[u];
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) *reinterpret_cast<T*>(d.det) = det;
+}
+
+// Row interchanges of the outer block [j0, cend) applied to every trailing column, then U12 = L11^-1 A12 into the
+// scratch T (nbk x ncols, leading dimension WB): one thread per column, L11 (unit lower) in LDS, 16 rows at a time
+// in registers.  (Composing the interchanges into one permutation with gathered loads measured slower: 207 vs 183 us.)
+template <typename T>
+__global__ __launch_bounds__(256) void lu_trsm_kernel(const tmf_lublock_desc* __restrict__ desc, const int j0, const int WB) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const tmf_lublock_desc d = desc[blockIdx.x];
+  const int k = d.k, ldw = d.ldw;
+  if (j0 >= k) return;
+  const int cend = min(k, j0 + WB), nbk = cend - j0, ncols = d.mk - cend;
+  if ((int)blockIdx.y * 256 >= ncols) return;
+  T* __restrict__ W = reinterpret_cast<T*>(d.W);
+  T* Ls = reinterpret_cast<T*>(smem);                        // Ls[c * nbk + r] = L11[r][c]
+  int* pv = reinterpret_cast<int*>(Ls + (size_t)WB * WB);
+  const int tid = threadIdx.x;
+  for (int e = tid; e < nbk * nbk; e += 256) {
+    const int r = e % nbk, c = e / nbk;
+    if (r > c) Ls[e] = W[(size_t)(j0 + r) + (size_t)(j0 + c) * ldw];
+  }
+  if (tid < nbk) pv[tid] = reinterpret_cast<const int32_t*>(d.piv)[j0 + tid];
+  __syncthreads();
+  const int col = blockIdx.y * 256 + tid;
+  if (col >= ncols) return;
+  T* __restrict__ cp = W + (size_t)(cend + col) * ldw;
+  for (int j = 0; j < nbk; ++j) {
+    const int pr = pv[j];
+    if (pr != j0 + j) {
+      const T t = cp[j0 + j];
+      cp[j0 + j] = cp[pr];
+      cp[pr] = t;
+    }
+  }
+  T* __restrict__ tp = reinterpret_cast<T*>(d.T) + (size_t)col * WB;
+  for (int p0 = 0; p0 < nbk; p0 += NBMAX) {
+    const int pb = min(NBMAX, nbk - p0);
+    T a[NBMAX];
+#pragma unroll
+    for (int i = 0; i < NBMAX; ++i) a[i] = (i < pb) ? cp[j0 + p0 + i] : sc<T>::zero();
+    for (int q = 0; q < p0; ++q) {
+      const T tq = tp[q];
+      const T* lq = Ls + (size_t)q * nbk + p0;
+#pragma unroll
+      for (int i = 0; i < NBMAX; ++i)
+        if (i < pb) a[i] = sc<T>::fms(a[i], lq[i], tq);
+    }
+#pragma unroll
+    for (int i = 0; i < NBMAX; ++i) {
+      if (i < pb) {
+        const T* li = Ls + (size_t)(p0 + i) * nbk + p0;
+#pragma unroll
+        for (int r = i + 1; r < NBMAX; ++r)
+          if (r < pb) a[r] = sc<T>::fms(a[r], li[r], a[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NBMAX; ++i)
+      if (i < pb) tp[p0 + i] = a[i];
+  }
+}
+
 }  // namespace tmf
 
 extern "C" int tmf_lu_schur_batched(int dtype, const tmf_schur_desc* d_desc, int nprob, int max_mb, void* stream) {
@@ -200,4 +427,71 @@ extern "C" int tmf_lu_schur_batched(int dtype, const tmf_schur_desc* d_desc, int
     return TMF_E_ARG;
   }
   return check_hip(hipGetLastError(), "tmf_lu_schur_batched launch");
+}
+
+extern "C" int tmf_lu_block_batched(int dtype, const tmf_lublock_desc* d_desc, int nprob, int j0, int wb, int max_mb, void* stream) {
+  using namespace tmf;
+  if (nprob <= 0) return TMF_OK;
+  if (wb != 64 || j0 < 0 || (j0 % wb) != 0) {
+    set_error("tmf_lu_block_batched: block width %d (supported: 64), first column %d", wb, j0);
+    return TMF_E_ARG;
+  }
+  const size_t elem = (dtype == TMF_C128) ? 16 : 8;
+  const int rows = max_mb - j0 > 1 ? max_mb - j0 : 1;
+  int nb = NBMAX;
+  auto need = [&](int w) { return ((size_t)rows * w + UCH * NBMAX) * elem + 512; };
+  // narrower panels for tall blocks: three workgroups per CU instead of one (one workgroup per site, ~1000 sites, 256 CUs)
+  // (measured: 52 KiB budget 362 us per launch, 80 / 160 KiB 390 us, 34 KiB 407 us - the kernel is bound by its
+  // dependent steps, not by occupancy)
+  while (need(nb) > 52 * 1024 && nb > 4) nb >>= 1;
+  while (need(nb) > 160 * 1024 && nb > 1) nb >>= 1;
+  const size_t lds = need(nb);
+  if (lds > 160 * 1024) {
+    set_error("tmf_lu_block_batched: %d rows need %zu B of LDS (> 160 KiB)", rows, lds);
+    return TMF_E_LIMIT;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)lu_block_kernel<cd>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lu_block_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  if (dtype == TMF_C128)
+    hipLaunchKernelGGL(lu_block_kernel<cd>, dim3(nprob), dim3(256), lds, s, d_desc, j0, wb, nb);
+  else if (dtype == TMF_F64)
+    hipLaunchKernelGGL(lu_block_kernel<double>, dim3(nprob), dim3(256), lds, s, d_desc, j0, wb, nb);
+  else {
+    set_error("tmf_lu_block_batched: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+  return check_hip(hipGetLastError(), "tmf_lu_block_batched launch");
+}
+
+extern "C" int tmf_lu_trsm_batched(int dtype, const tmf_lublock_desc* d_desc, int nprob, int j0, int wb, int max_cols, void* stream) {
+  using namespace tmf;
+  if (nprob <= 0 || max_cols <= 0) return TMF_OK;
+  if (wb != 64) {
+    set_error("tmf_lu_trsm_batched: block width %d (supported: 64)", wb);
+    return TMF_E_ARG;
+  }
+  const size_t elem = (dtype == TMF_C128) ? 16 : 8;
+  const size_t lds = (size_t)wb * wb * elem + (size_t)wb * 4 * 4 + 64;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)lu_trsm_kernel<cd>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lu_trsm_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const dim3 grid(nprob, (max_cols + 255) / 256);
+  if (dtype == TMF_C128)
+    hipLaunchKernelGGL(lu_trsm_kernel<cd>, grid, dim3(256), lds, s, d_desc, j0, wb);
+  else if (dtype == TMF_F64)
+    hipLaunchKernelGGL(lu_trsm_kernel<double>, grid, dim3(256), lds, s, d_desc, j0, wb);
+  else {
+    set_error("tmf_lu_trsm_batched: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+  return check_hip(hipGetLastError(), "tmf_lu_trsm_batched launch");
 }

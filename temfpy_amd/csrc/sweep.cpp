@@ -164,9 +164,11 @@ struct PinnedBuf {  // grow-only page-locked host buffer
 // two or three of them rotate while downloads overlap the next conversion.
 struct OutSlot {
   char* d = nullptr;
+  char* d_chk = nullptr;  // 8 doubles: deviations of the self-check
   size_t cap = 0;
   hipEvent_t done = nullptr;
-  bool busy = false;
+  bool busy = false;      // a download is (or may be) running
+  bool reserved = false;  // taken by the sweep in progress
   i64 ticket = -1;
   PinnedBuf checks;  // 8 doubles
   int n_checks = 0;
@@ -188,14 +190,20 @@ using namespace tmf;
 struct tmf_ctx {
   int device = 0;
   hipStream_t s_main = nullptr, s_down = nullptr, s_up = nullptr;
-  DeviceArena dev;
-  StagingArena stage;
+  // Two sets of per-sweep memory, used alternately: the next sweep is enqueued behind the running one without
+  // waiting for its kernels (only for the sweep before that, which used the same set) - no idle GPU between
+  // conversions when the caller downloads asynchronously.
+  DeviceArena dev_set[2];
+  StagingArena stage_set[2];
+  std::vector<hipEvent_t> event_pool_set[2];
+  hipEvent_t set_done[2] = {nullptr, nullptr};
+  bool set_used[2] = {false, false};
+  int cur = 0;
   std::vector<OutSlot> slots;
   i64 next_ticket = 1;
   PinnedBuf fetch;     // eigenvalues / counts coming down
   PinnedBuf pool_pin;  // index lists going up
   PinnedBuf c_pin;     // C going up
-  std::vector<hipEvent_t> event_pool;
   size_t events_used = 0;
 
   // ---- state of the current sweep ----
@@ -204,7 +212,7 @@ struct tmf_ctx {
   bool have_sectors = false;
   int dtype = TMF_F64;
   i64 el = 8, L = 0, oc = 0, s_lo = 0, s_hi = 0;
-  bool cplx = false, begun = false, have_sites = false;
+  bool cplx = false, begun = false, have_sites = false, have_out = false;
   double cutoff = 0, thr2 = 0;
   std::vector<double> diag;
   char *d_Crm = nullptr, *d_C = nullptr;
@@ -264,7 +272,7 @@ struct Sweep {
   // ------------------------------------------------------------------ plumbing
   int dalloc(i64 count, i64 elem, void** out, bool zero = false) {
     const size_t bytes = (size_t)std::max<i64>(count, 1) * (size_t)elem;
-    TMF_TRY(c.dev.alloc(bytes, out));
+    TMF_TRY(c.dev_set[c.cur].alloc(bytes, out));
     if (zero) HIP_TRY(hipMemsetAsync(*out, 0, bytes, c.s_main));
     return TMF_OK;
   }
@@ -276,11 +284,11 @@ struct Sweep {
   }
   int up(const void* host, size_t bytes, u64* dev) {
     if (bytes == 0) bytes = 1;
-    TMF_TRY(c.stage.reserve(bytes));
-    memcpy(c.stage.h + c.stage.off, host, bytes);
-    HIP_TRY(hipMemcpyAsync(c.stage.d + c.stage.off, c.stage.h + c.stage.off, bytes, hipMemcpyHostToDevice, c.s_main));
-    *dev = (u64)(c.stage.d + c.stage.off);
-    c.stage.off += bytes;
+    TMF_TRY(c.stage_set[c.cur].reserve(bytes));
+    memcpy(c.stage_set[c.cur].h + c.stage_set[c.cur].off, host, bytes);
+    HIP_TRY(hipMemcpyAsync(c.stage_set[c.cur].d + c.stage_set[c.cur].off, c.stage_set[c.cur].h + c.stage_set[c.cur].off, bytes, hipMemcpyHostToDevice, c.s_main));
+    *dev = (u64)(c.stage_set[c.cur].d + c.stage_set[c.cur].off);
+    c.stage_set[c.cur].off += bytes;
     return TMF_OK;
   }
   template <typename T>
@@ -288,12 +296,13 @@ struct Sweep {
     return up(v.data(), v.size() * sizeof(T), dev);
   }
   int new_event(hipEvent_t* e) {
-    if (c.events_used == c.event_pool.size()) {
+    std::vector<hipEvent_t>& pool = c.event_pool_set[c.cur];
+    if (c.events_used == pool.size()) {
       hipEvent_t ev;
       HIP_TRY(hipEventCreate(&ev));
-      c.event_pool.push_back(ev);
+      pool.push_back(ev);
     }
-    *e = c.event_pool[c.events_used++];
+    *e = pool[c.events_used++];
     return TMF_OK;
   }
   void tick(int stage, double t0) { c.stage_ms[stage] += now_ms() - t0; }
@@ -526,15 +535,19 @@ struct Sweep {
     HIP_TRY(hipSetDevice(c.device));
     c.t_begin = now_ms();
     memset(c.stage_ms, 0, sizeof(c.stage_ms));
-    HIP_TRY(hipStreamSynchronize(c.s_main));  // staging arena and temporaries of the previous sweep are free
-    c.dev.reset();
-    c.stage.reset();
+    // the other memory set: free once the sweep before the previous one has finished on the GPU
+    c.cur ^= 1;
+    if (c.set_used[c.cur]) HIP_TRY(hipEventSynchronize(c.set_done[c.cur]));
+    c.dev_set[c.cur].reset();
+    c.stage_set[c.cur].reset();
     c.events_used = 0;
     c.gemm_events.clear();
     c.det_events.clear();
     c.sweep_counters.clear();
     c.sweep_counts_n.clear();
-    c.begun = c.have_sites = false;
+    c.begun = c.have_sites = c.have_out = false;
+    if (c.slot) c.slot->reserved = false;  // (a sweep that was never downloaded)
+    c.slot = nullptr;
     c.par = *par;
     c.have_sectors = par->sectors != nullptr;
     c.sectors.clear();
@@ -558,18 +571,19 @@ struct Sweep {
     double t0 = now_ms();
     const size_t cbytes = (size_t)L * L * c.el;
     void* p;
-    TMF_TRY(c.dev.alloc(cbytes, &p));
+    TMF_TRY(c.dev_set[c.cur].alloc(cbytes, &p));
     c.d_C = (char*)p;
     c.diag.assign(L, 0.0);
     if (par->flags & TMF_SWEEP_C_ON_DEVICE) {
       c.d_Crm = (char*)C;
       // the diagonal (particle counts per cut) comes down with a strided copy
       TMF_TRY(c.fetch.ensure((size_t)L * 16));
-      HIP_TRY(hipMemcpy2DAsync(c.fetch.p, c.el, C, (size_t)(L + 1) * c.el, c.el, L, hipMemcpyDeviceToHost, c.s_main));
-      HIP_TRY(hipStreamSynchronize(c.s_main));
+      // (on the upload stream: the launch stream may still be busy with the previous sweep)
+      HIP_TRY(hipMemcpy2DAsync(c.fetch.p, c.el, C, (size_t)(L + 1) * c.el, c.el, L, hipMemcpyDeviceToHost, c.s_up));
+      HIP_TRY(hipStreamSynchronize(c.s_up));
       for (i64 i = 0; i < L; ++i) c.diag[i] = ((const double*)c.fetch.p)[i * (c.cplx ? 2 : 1)];
     } else {
-      TMF_TRY(c.dev.alloc(cbytes, &p));
+      TMF_TRY(c.dev_set[c.cur].alloc(cbytes, &p));
       c.d_Crm = (char*)p;
       TMF_TRY(c.c_pin.ensure(cbytes));
       memcpy(c.c_pin.p, C, cbytes);
@@ -1038,8 +1052,11 @@ struct Sweep {
       w.push_back(0.0);
       u64 t_w;
       TMF_TRY(up_vec(w, &t_w));
-      void* chk;
-      TMF_TRY(dalloc(8, 8, &chk, true));
+      // the five deviations live in the output block (read by the download stream after this sweep's memory set
+      // may have been handed to the sweep after next)
+      TMF_TRY(acquire_slot(0));
+      void* chk = c.slot->d_chk;
+      HIP_TRY(hipMemsetAsync(chk, 0, 64, c.s_main));
       c.d_chk = (char*)chk;
       tmf_recon_desc d[5];
       memset(d, 0, sizeof(d));
@@ -1109,16 +1126,25 @@ struct Sweep {
     return TMF_OK;
   }
 
+  // The output block of this sweep (tensors, det_always, self-check deviations).  Called once per sweep with 0 bytes
+  // when only the check buffer is needed yet, and again with the real size once the host phase knows it.
   int acquire_slot(size_t bytes) {
-    OutSlot* s = nullptr;
-    for (auto& x : c.slots) {
-      if (x.busy && hipEventQuery(x.done) == hipSuccess) x.busy = false;
-      if (!x.busy && (s == nullptr || (x.cap >= bytes && s->cap < bytes))) s = &x;
-    }
+    OutSlot* s = c.slot;
     if (s == nullptr) {
-      c.slots.emplace_back();
-      s = &c.slots.back();
-      HIP_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+      for (auto& x : c.slots) {
+        if (x.busy && hipEventQuery(x.done) == hipSuccess) x.busy = false;
+        if (!x.busy && !x.reserved && (s == nullptr || x.cap > s->cap)) s = &x;
+      }
+      if (s == nullptr) {
+        c.slots.emplace_back();
+        s = &c.slots.back();
+        HIP_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+        HIP_TRY(hipMalloc((void**)&s->d_chk, 64));
+      }
+      s->reserved = true;
+      s->ticket = -1;
+      TMF_TRY(s->checks.ensure(64));
+      c.slot = s;
     }
     if (s->cap < bytes) {
       if (s->d) HIP_TRY(hipFree(s->d));
@@ -1127,8 +1153,6 @@ struct Sweep {
       HIP_TRY(hipMalloc((void**)&s->d, ncap));
       s->cap = ncap;
     }
-    TMF_TRY(s->checks.ensure(64));
-    c.slot = s;
     return TMF_OK;
   }
 
@@ -1194,11 +1218,59 @@ struct Sweep {
       s.mb = (int32_t)mb[j], s.mk = (int32_t)mk[j], s.k = (int32_t)ka[j], s.ldw = (int32_t)std::max<i64>(mb[j], 1), s.lds = 1, s.pad = 0;
       Sp[j] = Wp[j] + (u64)((ka[j] + ka[j] * std::max<i64>(mb[j], 1)) * el);
     }
-    u64 t_gd, t_sd;
+    u64 t_gd, t_sd = 0;
     TMF_TRY(up_vec(gd, &t_gd));
     TMF_TRY(tmf_gather_signed_batched(c.dtype, (const tmf_gather_desc*)t_gd, (int)ns, c.s_main));
-    TMF_TRY(up_vec(sd, &t_sd));
-    TMF_TRY(tmf_lu_schur_batched(c.dtype, (const tmf_schur_desc*)t_sd, (int)ns, (int)maxmb, c.s_main));
+    if (c.par.flags & TMF_SWEEP_LU_SINGLE) {  // A/B switch: the one-workgroup-per-site kernel
+      TMF_TRY(up_vec(sd, &t_sd));
+      TMF_TRY(tmf_lu_schur_batched(c.dtype, (const tmf_schur_desc*)t_sd, (int)ns, (int)maxmb, c.s_main));
+    } else {
+      // Blocked LU over several launches: 64 always-columns per outer step, the rank-64 trailing update of all sites
+      // as one batched MFMA GEMM (see lu_schur.hip).  Sites ordered by the size of their always-block so that the
+      // sites still active at step j0 are a prefix of the descriptor array.
+      constexpr i64 WB = 64;
+      std::vector<i64> order(ns);
+      std::iota(order.begin(), order.end(), 0);
+      std::stable_sort(order.begin(), order.end(), [&](i64 a, i64 b) { return ka[a] > ka[b]; });
+      i64 piv_tot = 0, t_tot = 0;
+      for (i64 j = 0; j < ns; ++j) piv_tot += ka[j], t_tot += ka[j] > 0 ? WB * mk[j] : 0;
+      void* d_piv;
+      u64 d_T;
+      TMF_TRY(dalloc(piv_tot, 4, &d_piv));
+      TMF_TRY(alloc_el(t_tot, &d_T));
+      std::vector<tmf_lublock_desc> ld(ns);
+      i64 po = 0, to = 0;
+      for (i64 r = 0; r < ns; ++r) {
+        const i64 j = order[r];
+        tmf_lublock_desc& q = ld[r];
+        q.W = Wp[j], q.det = detp[j], q.piv = (u64)d_piv + (u64)(po * 4), q.T = d_T + (u64)(to * el);
+        q.mb = (int32_t)mb[j], q.mk = (int32_t)mk[j], q.k = (int32_t)ka[j], q.ldw = (int32_t)std::max<i64>(mb[j], 1);
+        po += ka[j], to += ka[j] > 0 ? WB * mk[j] : 0;
+      }
+      u64 t_ld;
+      TMF_TRY(up_vec(ld, &t_ld));
+      const i64 kmax = ns > 0 ? ka[order[0]] : 0;
+      for (i64 j0 = 0; j0 < std::max<i64>(kmax, 1); j0 += WB) {
+        i64 nact = 0, act_mb = 0, max_cols = 0;
+        while (nact < ns && ka[order[nact]] > j0) {
+          const i64 j = order[nact], cend = std::min(ka[j], j0 + WB);
+          act_mb = std::max(act_mb, mb[j]), max_cols = std::max(max_cols, mk[j] - cend);
+          ++nact;
+        }
+        // (j0 = 0 runs over all sites: a site without always-block gets det = 1)
+        TMF_TRY(tmf_lu_block_batched(c.dtype, (const tmf_lublock_desc*)t_ld, (int)(j0 == 0 ? ns : nact), (int)j0, (int)WB,
+                                     (int)(j0 == 0 ? maxmb : act_mb), c.s_main));
+        if (nact == 0) break;
+        TMF_TRY(tmf_lu_trsm_batched(c.dtype, (const tmf_lublock_desc*)t_ld, (int)nact, (int)j0, (int)WB, (int)max_cols, c.s_main));
+        Gemm g;
+        for (i64 r = 0; r < nact; ++r) {
+          const i64 j = order[r], cend = std::min(ka[j], j0 + WB), ldw = std::max<i64>(mb[j], 1);
+          g.add(Wp[j] + (u64)((cend + j0 * ldw) * el), ld[r].T, Wp[j] + (u64)((cend + cend * ldw) * el), mb[j] - cend, mk[j] - cend,
+                cend - j0, ldw, WB, ldw);
+        }
+        TMF_TRY(gemm(0, -1.0, 1.0, g));
+      }
+    }
     tick(ST_SCHUR, t0);
 
     // ---- S4: all minors ----
@@ -1353,6 +1425,8 @@ struct Sweep {
         c.n_det += pairs;
       }
     }
+    HIP_TRY(hipEventRecord(c.set_done[c.cur], c.s_main));  // every kernel of this sweep is enqueued
+    c.set_used[c.cur] = true;
     tick(ST_DET, t0);
     return TMF_OK;
   }
@@ -1367,7 +1441,7 @@ struct Sweep {
     TMF_TRY(overlap_stage());
     TMF_TRY(host_phase());  // integer work on host threads while the GPU runs the filled-basis launches
     TMF_TRY(site_stage());
-    c.have_sites = true;
+    c.have_sites = c.have_out = true;
     dims->ncut = c.ncut, dims->cap = c.cap, dims->ns = c.ns, dims->sec_tot = c.sc_tot, dims->bra_tot = c.br_tot;
     dims->e_tot = (i64)c.e_pool.size() - 1, dims->out_elems = c.out_tot, dims->elem_bytes = c.el;
     return TMF_OK;
@@ -1416,17 +1490,19 @@ struct Sweep {
     TMF_TRY(new_event(&ev));
     HIP_TRY(hipEventRecord(ev, c.s_main));
     HIP_TRY(hipStreamWaitEvent(c.s_down, ev, 0));
+    s->n_checks = c.n_checks;
+    if (c.n_checks > 0) HIP_TRY(hipMemcpyAsync(s->checks.p, c.d_chk, (size_t)c.n_checks * 8, hipMemcpyDeviceToHost, c.s_down));
     if (q->det) HIP_TRY(hipMemcpyAsync(q->det, c.d_det, (size_t)ns * c.el, hipMemcpyDeviceToHost, c.s_down));
     if (want_tensors && q->out) {
       const size_t total = (size_t)c.out_tot * c.el, chunk = (size_t)64 << 20;
       for (size_t o = 0; o < total; o += chunk)  // in pieces: small copies of other streams get a turn
         HIP_TRY(hipMemcpyAsync((char*)q->out + o, c.d_out + o, std::min(chunk, total - o), hipMemcpyDeviceToHost, c.s_down));
     }
-    s->n_checks = c.n_checks;
-    if (c.n_checks > 0)
-      HIP_TRY(hipMemcpyAsync(s->checks.p, c.d_chk, (size_t)c.n_checks * 8, hipMemcpyDeviceToHost, c.s_down));
     HIP_TRY(hipEventRecord(s->done, c.s_down));
     s->busy = true;
+    s->reserved = false;
+    c.slot = nullptr;
+    c.have_sites = false;  // one download per sweep
     s->ticket = c.next_ticket++;
     *ticket = s->ticket;
     tick(ST_DOWNLOAD, t0);
@@ -1452,6 +1528,8 @@ extern "C" int tmf_ctx_create(int device, tmf_ctx** out) {
   int st = check_hip(hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking), "hipStreamCreate");
   if (st == TMF_OK) st = check_hip(hipStreamCreateWithFlags(&c->s_down, hipStreamNonBlocking), "hipStreamCreate");
   if (st == TMF_OK) st = check_hip(hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking), "hipStreamCreate");
+  for (int i = 0; i < 2 && st == TMF_OK; ++i)
+    st = check_hip(hipEventCreateWithFlags(&c->set_done[i], hipEventDisableTiming), "hipEventCreate");
   if (st != TMF_OK) {
     delete c;
     return st;
@@ -1467,12 +1545,16 @@ extern "C" void tmf_ctx_destroy(tmf_ctx* c) {
   (void)hipDeviceSynchronize();
   for (auto& s : c->slots) {
     if (s.d) (void)hipFree(s.d);
+    if (s.d_chk) (void)hipFree(s.d_chk);
     if (s.done) (void)hipEventDestroy(s.done);
     s.checks.release();
   }
-  for (auto e : c->event_pool) (void)hipEventDestroy(e);
-  c->dev.release();
-  c->stage.release();
+  for (int i = 0; i < 2; ++i) {
+    for (auto e : c->event_pool_set[i]) (void)hipEventDestroy(e);
+    if (c->set_done[i]) (void)hipEventDestroy(c->set_done[i]);
+    c->dev_set[i].release();
+    c->stage_set[i].release();
+  }
   c->fetch.release(), c->pool_pin.release(), c->c_pin.release();
   if (c->s_main) (void)hipStreamDestroy(c->s_main);
   if (c->s_down) (void)hipStreamDestroy(c->s_down);
@@ -1547,7 +1629,7 @@ extern "C" int tmf_sweep_wait(tmf_ctx* ctx, int64_t ticket, double* checks, int3
 extern "C" const char* tmf_sweep_stage_name(int i) { return (i >= 0 && i < N_STAGES) ? kStageNames[i] : ""; }
 
 extern "C" int tmf_sweep_device_out(tmf_ctx* ctx, uint64_t* d_out, int64_t* elems) {
-  if (!ctx || !ctx->have_sites) {
+  if (!ctx || !ctx->have_out) {
     set_error("tmf_sweep_device_out: no finished sweep");
     return TMF_E_ARG;
   }
@@ -1563,7 +1645,7 @@ extern "C" int tmf_sweep_info_get(tmf_ctx* ctx, tmf_sweep_info* o) {
   memset(o, 0, sizeof(*o));
   memcpy(o->stage_ms, ctx->stage_ms, sizeof(double) * N_STAGES);
   o->range_width = ctx->P, o->range_iterations = ctx->range_iterations, o->range_floor = ctx->range_floor;
-  o->n_fermion = ctx->n_fermion, o->device_bytes = (int64_t)ctx->dev.total;
+  o->n_fermion = ctx->n_fermion, o->device_bytes = (int64_t)(ctx->dev_set[0].total + ctx->dev_set[1].total);
   o->n_det = ctx->n_det;
   const int64_t n_det_all = ctx->n_det;
   (void)n_det_all;

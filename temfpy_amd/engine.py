@@ -110,41 +110,6 @@ def _drive(gen):
         return stop.value
 
 
-def run_pipelined(engines, C, trunc, ortho_center, unit_cell_width, ranges, download=True, threads=None):
-    """One conversion split into site ranges that are swept concurrently by cooperative scheduling:
-    every range is a generator (``Engine.run_gen``) that yields where it would otherwise block (GPU
-    results coming down, the host enumeration thread), and the scheduler resumes whichever range can
-    continue.  The launches of all ranges go to the same HIP stream, so the GPU executes the entangled
-    stage of range B while the host classifies and enumerates range A, and so on: the host round
-    trips of one range hide behind the kernels of the other (single Python thread, no GIL contest;
-    the native host phases run in their own threads).  Returns the per-range MPSData objects."""
-    torch = engines[0].torch
-    dev = engines[0].device
-    torch.cuda.current_stream(dev).synchronize()
-    if isinstance(C, torch.Tensor):
-        Ld = int(round(C.numel() ** 0.5))
-        diag = torch.real(C.reshape(-1)[:: Ld + 1]).cpu().numpy().astype(np.float64)
-    else:
-        diag = np.real(np.diagonal(np.asarray(C))).astype(np.float64)
-    gens = [e.run_gen(C, trunc, ortho_center, unit_cell_width, threads=threads, download=download, site_range=r,
-                      diag=diag, presynced=True) for e, r in zip(engines, ranges)]
-    waits, out = [None] * len(gens), [None] * len(gens)
-    live = list(range(len(gens)))
-    while live:
-        progressed = False
-        for j in list(live):
-            if waits[j] is None or waits[j].ready():
-                try:
-                    waits[j] = next(gens[j])
-                except StopIteration as stop:
-                    out[j] = stop.value
-                    live.remove(j)
-                progressed = True
-        if not progressed:
-            waits[live[0]].block()
-    return out
-
-
 class Engine:
     def __init__(self, device="cuda:0", profile=None):
         import torch
@@ -535,6 +500,7 @@ class Engine:
     filled_cholqr = os.environ.get("TMF_FILLED_CHOLQR", "1") == "1"   # panel method of the filled-basis QR
     det_method = os.environ.get("TMF_DET_METHOD", "ppt")              # "ppt" | "reduced" (A/B switch)
     filled_passes = int(os.environ.get("TMF_FILLED_PASSES", "1"))     # projection passes of the filled-basis QR
+    lu_method = os.environ.get("TMF_LU", "blocked")                    # "blocked" (multi-launch, MFMA update) | "single"
 
     def _fetch_async(self, tensors):
         """Asynchronous device -> pinned host copies of small result tensors; returns (wait handle, NumPy
@@ -766,6 +732,7 @@ class Engine:
         flags |= (nat.SWEEP_CHECKS if self.checks else 0) | (nat.SWEEP_TIME_KERNELS if self.time_gemm else 0)
         flags |= (nat.SWEEP_RANGE_BCGS if self.range_qr != "house" else 0) | (0 if self.filled_cholqr else nat.SWEEP_NO_CHOLQR)
         flags |= nat.SWEEP_TWO_PASSES if self.filled_passes >= 2 else 0
+        flags |= nat.SWEEP_LU_SINGLE if self.lu_method == "single" else 0
         flags |= nat.SWEEP_DET_DIRECT if self.force_direct_det else (nat.SWEEP_DET_REDUCED if self.det_method != "ppt" else 0)
         par = nat.SweepParams(L=L, chi_max=int(trunc.chi_max or 0), svd_min=float(trunc.svd_min),
                               degeneracy_tol=float(trunc.degeneracy_tol), sectors=None if sec is None else sec.ctypes.data,
@@ -773,7 +740,6 @@ class Engine:
                               n_sectors=0 if sec is None else int(sec.size), is_complex=int(cplx),
                               host_threads=int(threads or min(16, os.cpu_count() or 1)), flags=flags)
         nat.check(lib.tmf_sweep_begin(ctx, c_ptr, ctypes.byref(par)), "tmf_sweep_begin")
-        del keep_c
 
         # ---- entangled stage with the narrowest adequate range finder (see entangled_stage_adaptive_gen): adequacy is
         # CHECKED, the decisions are taken on the maximum over all ranks ----
@@ -808,6 +774,7 @@ class Engine:
             raise NotImplementedError(f"entanglement rank beyond the widest range finder ({self.range_ladder[-1]} "
                                       f"columns): {reason}")
 
+        del keep_c      # (a device-resident C has been read by now: the entangled stage synchronised the launch stream)
         dims = nat.SweepDims()
         nat.check(lib.tmf_sweep_sites(ctx, ctypes.byref(dims)), "tmf_sweep_sites")
         want_out = download is not False

@@ -244,6 +244,61 @@ def test_lu_schur(eng, cplx):
 
 
 @pytest.mark.parametrize("cplx", [True, False])
+def test_lu_blocked_over_launches(eng, cplx):
+    """tmf_lu_block_batched + tmf_lu_trsm_batched + the MFMA GEMM (the multi-launch form of tmf_lu_schur_batched the
+    sweep uses): det(A) and the Schur complement D - C A^-1 B against NumPy (slater.py:1077-1090), for always-blocks
+    from 0 to 4 outer steps, ragged last blocks, k = mb and k = mk."""
+    setup(eng, cplx)
+    nat = eng.nat
+    rng = np.random.default_rng(16)
+    cases = [(5, 4, 0), (1, 3, 1), (20, 23, 7), (70, 66, 40), (300, 290, 257), (33, 33, 33), (48, 50, 16), (130, 140, 64),
+             (131, 139, 65), (200, 210, 128), (90, 64, 64)]
+    cases.sort(key=lambda c: -c[2])          # the driver's order: largest always-block first
+    Ws = [rnd(rng, (mb, mk), cplx) for mb, mk, k in cases]
+    dW = [dev(eng, W) for W in Ws]
+    ddet = eng._alloc(len(cases))
+    d_piv = torch.zeros(sum(c[2] for c in cases) + 1, dtype=torch.int32, device="cuda")
+    d_T = eng._alloc(sum(64 * c[1] for c in cases) + 1)
+    ld = np.zeros(len(cases), nat.lublock_desc)
+    ld["W"] = [d[1] for d in dW]
+    ld["det"] = ddet.data_ptr() + np.arange(len(cases)) * eng.elem
+    ks = np.array([c[2] for c in cases])
+    ld["piv"] = d_piv.data_ptr() + 4 * (np.cumsum(ks) - ks)
+    tk = np.array([64 * c[1] for c in cases])
+    ld["T"] = d_T.data_ptr() + eng.elem * (np.cumsum(tk) - tk)
+    ld["mb"], ld["mk"], ld["k"] = [c[0] for c in cases], [c[1] for c in cases], ks
+    ld["ldw"] = ld["mb"]
+    t = eng._up(ld)
+    mb, mk = ld["mb"].astype(np.int64), ld["mk"].astype(np.int64)
+    for j0 in range(0, max(int(ks.max()), 1), 64):
+        nact = int((ks > j0).sum())
+        nat.check(eng.lib.tmf_lu_block_batched(eng.dtype, t.data_ptr(), len(cases) if j0 == 0 else nact, j0, 64,
+                                               int(mb.max() if j0 == 0 else mb[:nact].max()), eng.stream), "lu_block")
+        if nact == 0:
+            break
+        cend = np.minimum(ks[:nact], j0 + 64)
+        nat.check(eng.lib.tmf_lu_trsm_batched(eng.dtype, t.data_ptr(), nact, j0, 64, int((mk[:nact] - cend).max()), eng.stream),
+                  "lu_trsm")
+        el = eng.elem
+        eng.gemm(0, -1.0, 1.0, ld["W"][:nact] + ((cend + j0 * mb[:nact]) * el).astype(np.uint64), ld["T"][:nact],
+                 ld["W"][:nact] + ((cend + cend * mb[:nact]) * el).astype(np.uint64), mb[:nact] - cend, mk[:nact] - cend,
+                 cend - j0, mb[:nact], np.full(nact, 64), mb[:nact])
+    torch.cuda.synchronize()
+    det = ddet.cpu().numpy()
+    for i, ((mb_, mk_, k), W) in enumerate(zip(cases, Ws)):
+        if k:
+            dref = np.linalg.det(W[:k, :k])
+            Sref = W[k:, k:] - W[k:, :k] @ np.linalg.solve(W[:k, :k], W[:k, k:])
+        else:
+            dref, Sref = 1.0, W
+        np.testing.assert_allclose(det[i], dref, rtol=1e-10)
+        if mb_ > k and mk_ > k:
+            Wd = back(dW[i][0], (mb_, mk_))
+            scale = max(1.0, np.abs(Sref).max())
+            np.testing.assert_allclose(Wd[k:, k:], Sref, rtol=0, atol=1e-10 * scale)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
 @pytest.mark.parametrize("n,cls", [(0, 0), (1, 1), (2, 2), (5, 5), (8, 8), (9, 9), (12, 12), (13, 13), (16, 16), (17, 17), (19, 19), (25, 25), (32, 32), (40, 64)])
 def test_det_gather(eng, cplx, n, cls):
     setup(eng, cplx)

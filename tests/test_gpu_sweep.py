@@ -190,7 +190,7 @@ def test_site_sharding_reproduces_unsharded_result_bitwise():
     from tests_inputs import random_hopping
     from temfpy_amd.engine import Engine
     from temfpy_amd.schmidt_utils import to_stopping_condition
-    import bench
+    from temfpy_amd.multi_gpu import shard_sites
 
     L, chi = 48, 32
     C, _ = orc.correlation_matrix(random_hopping(L, 5))
@@ -198,7 +198,7 @@ def test_site_sharding_reproduces_unsharded_result_bitwise():
     eng = Engine("cuda:0")
     full = eng.run(C, tr, L // 2, L)
     for world in (2, 3, 4):
-        ranges = bench.shard_sites(L, L // 2, world)
+        ranges = shard_sites(L, L // 2, world)
         assert ranges[0][0] == 0 and ranges[-1][1] == L
         assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
         for (lo, hi) in ranges:
@@ -211,15 +211,6 @@ def test_site_sharding_reproduces_unsharded_result_bitwise():
             for b in range(lo, hi + 1):
                 assert np.array_equal(part.bonds[b].lam, full.bonds[b].lam)
                 assert np.array_equal(part.bonds[b].masks, full.bonds[b].masks)
-    # the same ranges interleaved on one stream by cooperative scheduling (engine.run_pipelined)
-    from temfpy_amd.engine import run_pipelined
-
-    ranges = bench.shard_sites(L, L // 2, 3)
-    parts = run_pipelined([Engine("cuda:0") for _ in ranges], C, tr, L // 2, L, ranges)
-    for (lo, hi), part in zip(ranges, parts):
-        for i in range(lo, hi):
-            for bp, bf in zip(part.sites[i].blocks, full.sites[i].blocks):
-                assert bp[:5] == bf[:5] and np.array_equal(bp[5], bf[5])
 
 
 def test_real_dtype_path_matches_complex_path():

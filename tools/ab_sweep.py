@@ -55,6 +55,8 @@ def compare(a, b, tag):
 def main():
     py, cpp = Engine("cuda:0"), Engine("cuda:0")
     py.sweep_impl, cpp.sweep_impl = "python", "cpp"
+    cpp.lu_method = "single"       # the Python orchestration uses the one-workgroup-per-site LU kernel
+    blk = Engine("cuda:0")         # default C++ path: blocked LU over several launches
     cases = [("rand L=16 chi=32", slater.correlation_matrix(random_hopping(16, 0))[0], dict(chi_max=32), {}),
              ("rand L=48 chi=32 oc=7", slater.correlation_matrix(random_hopping(48, 5))[0], dict(chi_max=32), dict(oc=7)),
              ("chain real L=40 chi=64", slater.correlation_matrix(uniform_chain(40) + np.diag(0.3 * np.cos(1.7 * np.arange(40))))[0], dict(chi_max=64), {}),
@@ -85,13 +87,27 @@ def main():
             ok = False
             continue
         ok &= compare(a, b, tag)
+        try:
+            d = blk.run(C, tr, oc, L, site_range=kw.get("rng"))
+            worst = 0.0
+            for i in range(L):
+                if b.sites[i] is None:
+                    continue
+                for u, v in zip(b.sites[i].blocks, d.sites[i].blocks):
+                    assert u[:5] == v[:5]
+                    worst = max(worst, np.abs(u[5] - v[5]).max() / max(np.abs(u[5]).max(), 1e-300))
+            print(f"   blocked LU vs single-kernel LU: max relative block deviation {worst:.2e}", flush=True)
+        except Exception as exc:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            ok = False
         if a.info["checks"] != b.info["checks"]:
             print("   checks differ:", a.info["checks"], b.info["checks"])
     # timing at full size
     import torch
     C = cases[-1][1]
     tr = to_stopping_condition({"chi_max": 512})
-    for name, eng in (("python", py), ("cpp", cpp)):
+    for name, eng in (("python", py), ("cpp single-kernel LU", cpp), ("cpp blocked LU", blk)):
         for _ in range(3):
             eng.run(C, tr, 512, 1024)
         torch.cuda.synchronize()
