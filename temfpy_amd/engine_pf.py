@@ -114,6 +114,46 @@ class PfMPSData:
     def dense_tensors(self):
         return [s.dense() for s in self.sites]
 
+    def to_tenpy(self, verify=True):
+        """Assemble ``tenpy.networks.mps.MPS`` like pfaffian.py:1485-1489, :1628-1658, :1750-1778, :1916-1919:
+        parity legs offset by the reference parity to the left of each bond, the physical leg merged into the bra leg
+        by an unsorted, unbunched ``LegPipe`` (p more major), rows addressed through ``leg_idx_bra``.
+
+        TeNPy is not installed in the build environment, so - as for the Slater path (``MPSData.to_tenpy``) - the
+        assembly checks itself at run time: every assembled tensor (16 sampled sites on long chains) is read back
+        with ``to_ndarray()`` and must equal this object's own dense tensor, else RuntimeError."""
+        import tenpy.linalg.np_conserved as npc
+        from tenpy import networks
+
+        site = networks.site.FermionSite(conserve="parity")
+        leg_p, chinfo = site.leg, site.leg.chinfo
+
+        def legcharge(bond, qconj):      # pfaffian.py:1485-1489 with idx_parity as {parity: slice}
+            idx = {(par + bond.pL) % 2: slice(a, b) for par, (a, b) in bond.idx_parity.items()}
+            return npc.LegCharge.from_qdict(chinfo, idx, qconj=qconj)
+
+        check = set(range(self.L)) if self.L <= 64 else set(np.linspace(0, self.L - 1, 16).astype(int).tolist())
+        tensors = []
+        for i, s in enumerate(self.sites):
+            left = s.mode == "left"
+            bra, ket = (self.bonds[i], self.bonds[i + 1]) if left else (self.bonds[i + 1], self.bonds[i])
+            qconj = (+1, -1) if left else (-1, +1)
+            names = ("vL", "vR") if left else ("vR", "vL")
+            leg_bra = legcharge(bra, qconj[0])
+            pipe = npc.LegPipe([leg_p, leg_bra], qconj=leg_bra.qconj, sort=False, bunch=False)
+            B = npc.zeros([pipe, legcharge(ket, qconj[1])], labels=[f"(p.{names[0]})", names[1]], qtotal=(s.qtotal,),
+                          dtype=complex)
+            for (r0, r1, c0, c1, blk) in s.blocks.values():
+                B[s.leg_idx_bra[r0:r1], slice(c0, c1)] = blk
+            B = B.split_legs()
+            if verify and i in check:
+                got = B.to_ndarray()
+                want = s.dense() if left else s.dense().transpose(0, 2, 1)
+                if got.shape != want.shape or not np.array_equal(got, want):
+                    raise RuntimeError(f"TeNPy assembly self-check failed at site {i} (Pfaffian path); use as_tenpy=False")
+            tensors.append(B)
+        return networks.mps.MPS([site] * self.L, tensors, self.lam, form=self.form, unit_cell_width=self.unit_cell_width)
+
 
 class PfEngine(Engine):
     range_floor_tol = 3e-15  # see Engine.entangled_stage_adaptive

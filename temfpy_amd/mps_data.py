@@ -248,6 +248,21 @@ class MPSData:
         res.shards = list(shards)
         return res
 
+    def schmidt_modes(self, bond: int):
+        """``temfpy.slater.SchmidtModes`` view of one cut (slater.py:42; orbital matrices not downloaded)."""
+        from .views import SchmidtModes
+        return SchmidtModes.from_bond(self.bonds[bond], self.L)
+
+    def schmidt_vectors(self, bond: int):
+        """``temfpy.slater.SchmidtVectors`` view of one cut (slater.py:495)."""
+        from .views import SchmidtVectors
+        return SchmidtVectors.from_bond(self.bonds[bond], self.L)
+
+    def tensor_data(self, site: int):
+        """``temfpy.slater.MPSTensorData`` view of one site (slater.py:873; Schur complement not downloaded)."""
+        from .views import MPSTensorData
+        return MPSTensorData.from_site(self, site)
+
     def wait(self):
         """Blocks until the tensors of an asynchronous download have landed in host memory."""
         for s in self.shards:

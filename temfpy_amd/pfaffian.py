@@ -2,8 +2,9 @@
 
 Same names, arguments and defaults as the reference for the converter entry points
 (pfaffian.py:1785-1793, :2094-2102, :302-304) and the basis-change helpers (pfaffian.py:75-184).
-Returns a :class:`temfpy_amd.engine_pf.PfMPSData` (parity-graded blocks, Schmidt values, vacuum
-parities); assembling a TeNPy ``MPS`` needs TeNPy's parity ``LegPipe`` and is not wired up yet.
+Returns a ``tenpy.networks.mps.MPS`` when TeNPy is importable and ``as_tenpy`` is not False (assembly
+as pfaffian.py:1750-1778, self-checked at run time: :meth:`PfMPSData.to_tenpy`), else a
+:class:`temfpy_amd.engine_pf.PfMPSData` (parity-graded blocks, Schmidt values, vacuum parities).
 """
 from __future__ import annotations
 
@@ -145,7 +146,8 @@ def parity(V: np.ndarray, *, tol: float = 1e-12, device: str = "cuda:0") -> int:
 
 
 def C_to_MPS(C: np.ndarray, trunc_par: dict | StoppingCondition, *, basis: str, diag_tol: float = _DIAG_TOL,
-             ortho_center: int = None, unit_cell_width: int | None = None, device: str = "cuda:0"):
+             ortho_center: int = None, unit_cell_width: int | None = None, device: str = "cuda:0",
+             as_tenpy: bool | None = None):
     """MPS of a BCS / Pfaffian state from its Nambu correlation matrix (pfaffian.py:1785-1921)."""
     from .engine_pf import PfEngine
 
@@ -169,15 +171,25 @@ def C_to_MPS(C: np.ndarray, trunc_par: dict | StoppingCondition, *, basis: str, 
     eng.checks = testing.TEST_ACTION != "pass"
     mps = eng.run(C, trunc_par, ortho_center, unit_cell_width)
     testing.report_schmidt_checks(mps.info["checks"], diag_tol)  # pfaffian.py:919
-    return mps
+    # as_tenpy as in slater.C_to_MPS: True -> tenpy.networks.mps.MPS (ImportError without TeNPy), False -> PfMPSData,
+    # None -> the TeNPy object if TeNPy is importable (pfaffian.py:1916-1919)
+    if as_tenpy is False:
+        return mps
+    try:
+        return mps.to_tenpy()
+    except ImportError:
+        if as_tenpy:
+            raise
+        return mps
 
 
 def H_to_MPS(H: np.ndarray, trunc_par: dict | StoppingCondition, *, basis: str, diag_tol: float = _DIAG_TOL,
-             ortho_center: int = None, unit_cell_width: int | None = None, device: str = "cuda:0"):
+             ortho_center: int = None, unit_cell_width: int | None = None, device: str = "cuda:0",
+             as_tenpy: bool | None = None):
     """pfaffian.py:2094-2148."""
     C = correlation_matrix(H, f"{basis}->M")
     return C_to_MPS(C, trunc_par, basis="M", diag_tol=diag_tol, ortho_center=ortho_center,
-                    unit_cell_width=unit_cell_width, device=device)
+                    unit_cell_width=unit_cell_width, device=device, as_tenpy=as_tenpy)
 
 
 def C_to_iMPS(C_short: np.ndarray, C_long: np.ndarray, trunc_par: dict | StoppingCondition, sites_per_cell: int,
@@ -200,8 +212,8 @@ def C_to_iMPS(C_short: np.ndarray, C_long: np.ndarray, trunc_par: dict | Stoppin
     L_short, L_long = len(C_short) // 2, len(C_long) // 2
     assert L_short + sites_per_cell == L_long, (
         "The given two MPS must differ by one unit cell, got " f"{L_long} - {L_short} != {sites_per_cell}")
-    mps_s = C_to_MPS(C_short, trunc_par, basis=basis, diag_tol=diag_tol, ortho_center=cut, device=device)
-    mps_l = C_to_MPS(C_long, trunc_par, basis=basis, diag_tol=diag_tol, ortho_center=cut, device=device)
+    mps_s = C_to_MPS(C_short, trunc_par, basis=basis, diag_tol=diag_tol, ortho_center=cut, device=device, as_tenpy=False)
+    mps_l = C_to_MPS(C_long, trunc_par, basis=basis, diag_tol=diag_tol, ortho_center=cut, device=device, as_tenpy=False)
     res, err = iMPS.MPS_to_iMPS(mps_s, mps_l, sites_per_cell, cut, unitary_tol=unitary_tol, schmidt_tol=schmidt_tol,
                                 offset=0, unit_cell_width=sites_per_cell, device=device)
     res.unit_cell_width = unit_cell_width

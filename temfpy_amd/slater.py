@@ -17,6 +17,7 @@ from . import testing
 from .testing import _DIAG_TOL
 from .utils import HT
 from .mps_data import MPSData
+from .views import MPSTensorData, SchmidtModes, SchmidtVectors  # noqa: F401  (names of the reference's public classes)
 
 logger = logging.getLogger(__name__)
 

@@ -16,7 +16,7 @@ def pytest_configure(config):
 
 def golden_names():
     """Slater fixtures (the Pfaffian ones, pf_*.npz, are used by tests/test_oracle_pfaffian.py)."""
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith("pf_"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith(("pf_", "views_")))
 
 
 @pytest.fixture(scope="session")

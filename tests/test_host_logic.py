@@ -209,3 +209,48 @@ def test_jacobi_sweep_cap_means_not_converged():
     nat.check_jacobi_sweeps(np.zeros(0, np.int32))
     with pytest.raises(np.linalg.LinAlgError, match="did not converge in 60 sweeps"):
         nat.check_jacobi_sweeps(np.array([3, 60, 5], np.int32))
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_merged_leg_order_against_the_reference_fixtures(name):
+    """The one thing `MPSData.to_tenpy` depends on that is checkable without TeNPy: the rows of the merged (p, bra) leg
+    are enumerated in the order slater.py:943-952 documents (ascending left charge; inside a charge first the p = 0 rows
+    of bra sector Q, then the p = 1 rows of sector Q - 1, each in the bra's own order).  For every site of every fixture
+    the occupation pattern of merged row r over the sometimes-occupied orbitals - rebuilt from (bra_p[r], bra_alpha[r]),
+    the bra's patterns and the native row selection - must equal row r of the REFERENCE's `new_sets_bra`; likewise the
+    ket patterns against `new_sets_ket`."""
+    g = load(name)
+    L, oc = int(g["L"]), int(g["ortho_center"])
+
+    def cut(b):
+        sets = g[f"b{b}_sets"]
+        m = np.zeros((len(sets), 2), np.uint64)
+        for i in range(sets.shape[1]):
+            m[:, i // 64] |= sets[:, i].astype(np.uint64) << np.uint64(i % 64)
+        nfl, nfr = (int(x) for x in g[f"b{b}_nfilled"])
+        return dict(sets=sets, masks=m, k=sets.shape[1], nfl=nfl, nfr=nfr, q=nfl + sets.sum(axis=1))
+
+    for i in range(L):
+        mode = 0 if i < oc else 1
+        bra, ket = (cut(i), cut(i + 1)) if mode == 0 else (cut(i + 1), cut(i))
+        nfb, nfk = (bra["nfl"], ket["nfl"]) if mode == 0 else (bra["nfr"], ket["nfr"])
+        r = nat.site_prepare(mode, bra["k"], nfb, bra["masks"], bra["q"], ket["k"], nfk, ket["masks"], ket["q"])
+
+        def occupied(side, orb, alpha, p):
+            """occupation of orbital `orb` (numbering [entangled | filled], -1 = physical) in Schmidt vector alpha"""
+            if orb < 0:
+                return bool(p)
+            if orb >= side["k"]:
+                return True                                   # a filled orbital
+            if mode == 0:
+                return bool(side["sets"][alpha, orb])
+            return not side["sets"][alpha, side["k"] - 1 - orb]   # slater.py:465
+
+        ka, ref_bra, ref_ket = r["k"], g[f"s{i}_sets_bra"], g[f"s{i}_sets_ket"]
+        assert ref_bra.shape == (2 * len(bra["sets"]), r["sb"]) and ref_ket.shape == (len(ket["sets"]), r["sk"])
+        for row in range(len(ref_bra)):
+            mine = [occupied(bra, int(o), int(r["bra_alpha"][row]), int(r["bra_p"][row])) for o in r["row_sel"][ka:]]
+            assert mine == ref_bra[row].tolist(), (name, i, row)
+        for col in range(len(ref_ket)):
+            mine = [occupied(ket, int(o), col, 0) for o in r["col_sel"][ka:]]
+            assert mine == ref_ket[col].tolist(), (name, i, col)
