@@ -500,6 +500,7 @@ class Engine:
     filled_cholqr = os.environ.get("TMF_FILLED_CHOLQR", "1") == "1"   # panel method of the filled-basis QR
     det_method = os.environ.get("TMF_DET_METHOD", "ppt")              # "ppt" | "reduced" (A/B switch)
     filled_passes = int(os.environ.get("TMF_FILLED_PASSES", "1"))     # projection passes of the filled-basis QR
+    host_threads = int(os.environ.get("TMF_HOST_THREADS", min(32, os.cpu_count() or 1)))   # enumeration / site preparation
     lu_method = os.environ.get("TMF_LU", "blocked")                    # "blocked" (multi-launch, MFMA update) | "single"
 
     def _fetch_async(self, tensors):
@@ -738,7 +739,7 @@ class Engine:
                               degeneracy_tol=float(trunc.degeneracy_tol), sectors=None if sec is None else sec.ctypes.data,
                               ortho_center=int(ortho_center), site_lo=int(s_lo), site_hi=int(s_hi),
                               n_sectors=0 if sec is None else int(sec.size), is_complex=int(cplx),
-                              host_threads=int(threads or min(16, os.cpu_count() or 1)), flags=flags)
+                              host_threads=int(threads or self.host_threads), flags=flags)
         nat.check(lib.tmf_sweep_begin(ctx, c_ptr, ctypes.byref(par)), "tmf_sweep_begin")
 
         # ---- entangled stage with the narrowest adequate range finder (see entangled_stage_adaptive_gen): adequacy is

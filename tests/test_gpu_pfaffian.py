@@ -145,3 +145,105 @@ def test_pfaffian_correlation_matrix_on_device(basis):
     C0 = pfaffian.correlation_matrix(H, basis)
     C1 = pfaffian.correlation_matrix(H, basis, device="cuda:0")
     np.testing.assert_allclose(C1, C0, rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("kind", ["kitaev", "random"])
+def test_config4_full_size(kind):
+    """BASELINE config 4 at FULL size (L = 512, chi_max = 256; pfaffian.py:1785-1921): the Majorana chain of
+    src/examples/iMPS_pfaffian.py:7-11 and a random BdG chain (slowly decaying spectrum: the range finder takes its
+    subspace-iteration branch, and the sub-Pfaffians reach their largest orders).  The oracle needs minutes per site at
+    this size, so: properties of EVERY bond and site (normalisation, ordering, parity bookkeeping, isometry where the
+    bond dimension is not truncated) and three sites spread over the chain recomputed with the pinned oracle
+    (patterns and parities exact, eigenvalues 1e-13, Schmidt values 1e-10, |entries| 1e-6 max)."""
+    import sys
+    import time
+    sys.path.insert(0, GOLDEN)
+    from make_golden_pfaffian import kitaev_majorana_H, random_majorana_H
+    from temfpy_amd import pfaffian
+
+    L, chi = 512, 256
+    H = kitaev_majorana_H(L, 1.5j, 1j) if kind == "kitaev" else random_majorana_H(L, 0)
+    C = pfaffian.correlation_matrix(H, "M->M")
+    pfaffian.C_to_MPS(C, {"chi_max": chi}, basis="M", as_tenpy=False)       # warm-up
+    t0 = time.perf_counter()
+    mps = pfaffian.C_to_MPS(C, {"chi_max": chi}, basis="M", as_tenpy=False)
+    dt = time.perf_counter() - t0
+    oc = L // 2
+    assert mps.L == L and max(mps.chi) <= chi and mps.chi[0] == 1 and mps.chi[-1] == 1
+    if kind == "random":
+        assert max(mps.chi) == chi
+        assert mps.info["range_finder_iterations"] == 1      # the branch config 4 is there to exercise
+    parity = mps.bonds[oc].parity()
+    for b in range(L + 1):
+        bd = mps.bonds[b]
+        assert abs((bd.lam**2).sum() - 1) < 1e-12 and np.all(bd.lam_raw > 0)
+        assert bd.parity() == parity, b                                   # pL + pR is the state's parity at every cut
+        exc = bd.sets.sum(axis=1)
+        key = (exc % 2) * 1000 + exc                                      # sorted by (parity, number), pfaffian.py:1009-1100
+        assert np.all(np.diff(key) >= 0), b
+        for par, (a_, b_) in bd.idx_parity.items():
+            assert np.all(exc[a_:b_] % 2 == par)
+    # Isometry of the tensors at both ends of the chain, where chi_max does not truncate.  svd_min still does, and not in
+    # a nested way: a Schmidt vector kept at one bond with lam ~ 1e-6 may consist mostly of vectors discarded at the
+    # neighbouring bond, so its column has norm < 1 (measured: 2e-3 off) - but it enters the state with weight lam.
+    # The lam-weighted deviation is the one that bounds the state.
+    T = mps.dense_tensors()
+    checked = 0
+    for i in list(range(0, 10)) + list(range(L - 10, L)):
+        if max(mps.chi[i], mps.chi[i + 1]) >= chi:
+            continue
+        A = T[i]                                                           # (p, vL, vR)
+        if i < oc:
+            G, lam = np.einsum("pab,pac->bc", A.conj(), A), mps.bonds[i + 1].lam
+        else:
+            G, lam = np.einsum("pab,pcb->ac", A.conj(), A), mps.bonds[i].lam
+        dev = np.abs(G - np.eye(len(G))) * np.outer(lam, lam)
+        assert dev.max() < 1e-10, (i, dev.max())
+        checked += 1
+    assert checked >= 6
+    # three sites against the oracle
+    trunc = porc.as_trunc({"chi_max": chi})
+    centre = porc.cut_vectors(C, oc, trunc, "LR")
+    assert centre.parity() == parity
+    worst_frob = 0.0
+    for i in (3, oc - 1, L - 60):
+        if i >= oc:
+            bra = porc.cut_vectors(C, i + 1, trunc, "R", parity)
+            ket = centre if i == oc else porc.cut_vectors(C, i, trunc, "R", parity)
+            ref = porc.site_tensor(bra, ket, "right")
+        else:
+            bra = porc.cut_vectors(C, i, trunc, "L", parity)
+            ket = centre if i + 1 == oc else porc.cut_vectors(C, i + 1, trunc, "L", parity)
+            ref = porc.site_tensor(bra, ket, "left")
+        for c in (bra, ket):
+            bd = mps.bonds[c.x]
+            np.testing.assert_allclose(bd.e, c.e, rtol=0, atol=1e-13)
+            assert bd.parity() == c.parity()
+            if kind == "kitaev":
+                # the dimerised chain has an exactly degenerate entanglement spectrum: the order (and the basis) inside a
+                # multiplet is decided by rounding, in the reference too - gauge-invariant comparison only
+                np.testing.assert_allclose(np.sort(bd.lam), np.sort(c.lam), rtol=0, atol=1e-10)
+                continue
+            np.testing.assert_array_equal(bd.sets, c.sets)
+            np.testing.assert_allclose(bd.lam, c.lam, rtol=0, atol=1e-10)
+            if c.pL is not None:
+                assert bd.pL == c.pL
+        s = mps.sites[i]
+        assert abs(s.norm - abs(ref.norm)) < 1e-8 * max(1.0, abs(ref.norm)) and sorted(s.blocks) == sorted(ref.blocks)
+        if kind == "kitaev":
+            continue
+        np.testing.assert_array_equal(s.leg_idx_bra, ref.leg_idx_bra)
+        num = den = 0.0
+        for key_, (r0, r1, c0, c1, blk) in s.blocks.items():
+            rb = ref.blocks[key_][4]
+            # as at the full Slater size (tests/test_gpu_fullsize.py): entries that involve modes within a decade of the
+            # 1e-12 cutoff move at second order in an eigenvector mixing of eps / gap that LAPACK has as well (measured
+            # here: 5e-5 on 0.6 % of the entries); the Frobenius bound is the sharp one
+            np.testing.assert_allclose(np.abs(blk), np.abs(rb), rtol=0, atol=3e-4 * max(1.0, np.abs(rb).max()))
+            num += ((np.abs(blk) - np.abs(rb)) ** 2).sum()
+            den += (np.abs(rb) ** 2).sum()
+        worst_frob = max(worst_frob, float(np.sqrt(num / den)))
+        assert np.sqrt(num / den) < 2e-5, (i, np.sqrt(num / den))
+    print(f"config 4 ({kind}): L={L} chi={chi} {dt * 1e3:.1f} ms -> {L / dt:.0f} sites/s, S(centre)="
+          f"{mps.entanglement_entropy(all_bonds=True)[oc]:.9f}, max k={max(b.k for b in mps.bonds)}, "
+          f"sampled sites vs oracle: relative Frobenius deviation of |entries| {worst_frob:.1e}")
