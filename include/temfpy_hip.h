@@ -94,7 +94,8 @@ typedef struct {
 int64_t tmf_bcgs_work_bytes(const tmf_bcgs_desc* h_desc, int nprob);
 int tmf_bcgs_batched(int dtype, const tmf_bcgs_desc* d_desc, const tmf_bcgs_desc* h_desc, int nprob, int passes,
                      int flags /* bit 0: Cholesky-QR (twice) inside the panels instead of the LDS Gram-Schmidt panel
-                                  kernel - for well-conditioned slabs (filled-orbital bases) only */,
+                                  kernel - for well-conditioned slabs (filled-orbital bases) only;
+                                  bit 1: outer blocks of 64 instead of 16 columns (scratch: c_end x 64 per slab) */,
                      void* d_work, int64_t work_bytes, void* stream);
 
 /* One-sided (Hestenes) Jacobi on a p x p matrix X held in LDS: X V = U diag(s).
@@ -510,6 +511,7 @@ void tmf_ctx_destroy(tmf_ctx* ctx);
 #define TMF_SWEEP_DET_DIRECT 32u   /* ... through tmf_det_gather_batched                                  */
 #define TMF_SWEEP_C_ON_DEVICE 64u  /* C is a device pointer (row-major) instead of host memory            */
 #define TMF_SWEEP_TWO_PASSES 128u  /* two projection passes in the filled-basis Gram-Schmidt              */
+#define TMF_SWEEP_NARROW_BCGS 512u /* 16- instead of 64-column outer blocks in the filled-basis Gram-Schmidt (A/B) */
 #define TMF_SWEEP_LU_SINGLE 256u   /* Schur complements by tmf_lu_schur_batched (one workgroup per site; A/B)  */
 
 typedef struct {

@@ -17,7 +17,8 @@ namespace tmf {
 // [from, c_begin + t) with from = 0 (t0 < 0: everything before the block) or from = c_begin + t0
 // (the earlier panels of the same 16-column block).
 __global__ __launch_bounds__(256) void bcgs_prepare_kernel(const tmf_bcgs_desc* __restrict__ desc, int nprob, int t,
-                                                           int w, int t0, size_t elem, tmf_gemm_desc* __restrict__ g_coef,
+                                                           int w, int t0, int coef_rows, size_t elem,
+                                                           tmf_gemm_desc* __restrict__ g_coef,
                                                            tmf_gemm_desc* __restrict__ g_upd,
                                                            tmf_panel_desc* __restrict__ pd, int32_t* __restrict__ tiles_coef,
                                                            int32_t* __restrict__ tiles_upd, tmf_gemm_desc* __restrict__ g_gram,
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void bcgs_prepare_kernel(const tmf_bcgs_desc* 
       g_gram[i] = g;
       tiles_gram[4 * i] = i, tiles_gram[4 * i + 1] = 0, tiles_gram[4 * i + 2] = 0, tiles_gram[4 * i + 3] = 0;
     }
-    nc += (c.M > 0 && c.N > 0) ? (c.M + 15) / 16 : 0;   // tall kernel: 16 x 16 output tiles
+    nc += (c.M > 0 && c.N > 0) ? (c.M + coef_rows - 1) / coef_rows : 0;   // tall kernel: 16 x 16 output tiles; wide blocks: 64 x 64
     nu += (u.M > 0 && u.N > 0) ? (u.M + 63) / 64 : 0;
   }
   scan_c[tid + 1] = nc, scan_u[tid + 1] = nu;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void bcgs_prepare_kernel(const tmf_bcgs_desc* 
   for (int i = i0; i < i1; ++i) {
     const tmf_gemm_desc c = g_coef[i], u = g_upd[i];
     if (c.M > 0 && c.N > 0)
-      for (int m = 0; m < (c.M + 15) / 16; ++m, ++oc) {
+      for (int m = 0; m < (c.M + coef_rows - 1) / coef_rows; ++m, ++oc) {
         tiles_coef[4 * oc] = i, tiles_coef[4 * oc + 1] = m, tiles_coef[4 * oc + 2] = 0, tiles_coef[4 * oc + 3] = 0;
       }
     if (u.M > 0 && u.N > 0)
@@ -191,6 +192,12 @@ extern "C" int tmf_bcgs_batched(int dtype, const tmf_bcgs_desc* d_desc, const tm
     cap_c += (h_desc[i].c_end + 15) / 16;
   }
   const bool cholqr = (flags & 1) != 0;   // Cholesky-QR panels (no LDS panel: always 16 wide)
+  // flags & 2: outer blocks of 64 columns.  The projection of a block against everything before it streams those
+  // columns twice (coefficients, update) and is bound by that traffic (PMC: 22 GB per conversion for the filled
+  // bases with 16-column blocks, 4 TB/s); 64-column blocks read them a quarter as often.  The coefficient and update
+  // products of such a block are ordinary 64-wide MFMA GEMMs; inside it the 16-column panels are projected against
+  // the earlier panels of the block only.  Needs c_end x 64 elements of scratch per slab.
+  const bool wide = (flags & 2) != 0;
   int w = 16;  // widest panel that fits the LDS of orth_panel_kernel
   while (!cholqr && (size_t)max_rows * w * elem + 1024 > 150 * 1024 && w > 1) w >>= 1;
   char* wk = static_cast<char*>(d_work);
@@ -220,24 +227,30 @@ extern "C" int tmf_bcgs_batched(int dtype, const tmf_bcgs_desc* d_desc, const tm
   // bound by streaming those columns, so fewer, wider projections = less traffic); tall slabs whose
   // LDS panel is narrower (w < 16) then orthonormalise the block panel by panel, projecting each
   // later panel only against the earlier panels of its own block.
-  const int wo = 16;
+  const int wo = wide ? 64 : 16;
   auto project = [&](int t, int wb, int t0) -> int {
+    const int crow = wb > 16 ? 64 : 16;   // rows of a coefficient tile: MFMA GEMM kernel / tall-skinny kernel
     int64_t nc = 0, nu = 0;
     for (int i = 0; i < nprob; ++i) {
       const tmf_bcgs_desc& d = h_desc[i];
       if (d.c_end - d.c_begin <= t || d.rows <= 0) continue;
       const int j = d.c_begin + t - (t0 < 0 ? 0 : d.c_begin + t0);
       if (j > 0) {
-        nc += (j + 15) / 16;
+        nc += (j + crow - 1) / crow;
         nu += (d.rows + 63) / 64;
       }
     }
-    hipLaunchKernelGGL(bcgs_prepare_kernel, dim3(1), dim3(256), 0, s, d_desc, nprob, t, wb, t0, elem, g_coef, g_upd, pd,
+    hipLaunchKernelGGL(bcgs_prepare_kernel, dim3(1), dim3(256), 0, s, d_desc, nprob, t, wb, t0, crow, elem, g_coef, g_upd, pd,
                        tiles_coef, tiles_upd, cholqr ? g_gram : (tmf_gemm_desc*)nullptr, tiles_gram);
     int st = check_hip(hipGetLastError(), "tmf_bcgs_batched prepare");
     for (int p = 0; p < passes && nc > 0 && !st; ++p) {
-      st = tmf_gemm_tall_batched(dtype, 1.0, 0.0, g_coef, tiles_coef, (int)nc, stream);
-      if (!st) st = tmf_gemm_batched(dtype, 0, -1.0, 1.0, g_upd, tiles_upd, (int)nu, 16, stream);
+      if (wb > 16) {
+        st = tmf_gemm_batched(dtype, 1, 1.0, 0.0, g_coef, tiles_coef, (int)nc, 64, stream);
+        if (!st) st = tmf_gemm_batched(dtype, 0, -1.0, 1.0, g_upd, tiles_upd, (int)nu, 64, stream);
+      } else {
+        st = tmf_gemm_tall_batched(dtype, 1.0, 0.0, g_coef, tiles_coef, (int)nc, stream);
+        if (!st) st = tmf_gemm_batched(dtype, 0, -1.0, 1.0, g_upd, tiles_upd, (int)nu, 16, stream);
+      }
     }
     return st;
   };

@@ -363,7 +363,7 @@ struct Sweep {
     u64 scratch;
   };
   // blocked classical Gram-Schmidt with re-orthogonalisation (tmf_bcgs_batched)
-  int bcgs(std::vector<Slab> s, int passes, bool cholqr) {
+  int bcgs(std::vector<Slab> s, int passes, bool cholqr, bool wide = false) {
     s.erase(std::remove_if(s.begin(), s.end(), [](const Slab& x) { return !(x.rows > 0 && x.c1 > x.c0); }), s.end());
     if (s.empty()) return TMF_OK;
     std::stable_sort(s.begin(), s.end(), [](const Slab& a, const Slab& b) { return a.rows > b.rows; });
@@ -390,7 +390,7 @@ struct Sweep {
     const i64 wb = tmf_bcgs_work_bytes(bd.data(), (int)bd.size());
     void* d_work;
     TMF_TRY(dalloc(wb, 1, &d_work));
-    return tmf_bcgs_batched(c.dtype, (const tmf_bcgs_desc*)t_bd, bd.data(), (int)bd.size(), passes, cholqr ? 1 : 0, d_work, wb,
+    return tmf_bcgs_batched(c.dtype, (const tmf_bcgs_desc*)t_bd, bd.data(), (int)bd.size(), passes, (cholqr ? 1 : 0) | (wide ? 2 : 0), d_work, wb,
                             c.s_main);
   }
 
@@ -1025,12 +1025,15 @@ struct Sweep {
       // one multiplication by A: the filled space has eigenvalue >= 1 - 1e-12, everything that is not projected off
       // with U_E below has eigenvalue <= 1e-12 (the reference's own cutoff)
       TMF_TRY(nested('A', d_OmF, L, Vf, c.nf));
-      const i64 per = (maxcol + 1) * PANEL_W;
+      // 64-column outer blocks in the Gram-Schmidt (a quarter of the re-reads of the earlier columns): the coefficient
+      // scratch of a slab is (columns) x 64
+      const bool wide = !(c.par.flags & TMF_SWEEP_NARROW_BCGS);
+      const i64 per = (maxcol + 1) * (wide ? 64 : PANEL_W);
       TMF_TRY(alloc_el(per * ncs, &d_scr2));
       std::vector<Slab> s;
       for (i64 i = 0; i < ncs; ++i)
         if (c.nf[i] > 0) s.push_back(Slab{Vp[i], c.n[i], c.ld1[i], c.k[i], ncolV[i], d_scr2 + (u64)(i * per * el)});
-      TMF_TRY(bcgs(s, (c.par.flags & TMF_SWEEP_TWO_PASSES) ? 2 : 1, !(c.par.flags & TMF_SWEEP_NO_CHOLQR)));
+      TMF_TRY(bcgs(s, (c.par.flags & TMF_SWEEP_TWO_PASSES) ? 2 : 1, !(c.par.flags & TMF_SWEEP_NO_CHOLQR), wide));
     }
     // self-check of the centre cut (testing.py:131-177; slater.py:419-420 runs it only there)
     c.n_checks = 0;

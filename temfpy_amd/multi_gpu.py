@@ -245,6 +245,7 @@ class ShardGroup:
         self.reader = _Reader(tag) if self.rank == 0 else None
         self.host_threads = max(2, min(16, len(os.sched_getaffinity(0)) // max(self.world, 1)))
         self.last_busy_ms = None
+        self._c_pin = None
 
     def convert_local(self, C, trunc, ortho_center=None, unit_cell_width=None):
         """Steps every rank takes: shape + C from rank 0, this rank's site range into its segment.  Returns
@@ -262,15 +263,22 @@ class ShardGroup:
         L, cplx, oc, ucw = (int(x) for x in hdr)
         tdt = torch.complex128 if cplx else torch.float64
         if self.data_nccl:
-            d_C = (torch.from_numpy(C.reshape(-1)).to(self.device) if self.rank == 0
-                   else torch.empty(L * L, dtype=tdt, device=self.device))
-            if self.world > 1:
-                dist.broadcast(d_C, 0)                      # RCCL over xGMI
+            if self.rank == 0:
+                # through a persistent page-locked buffer: a pageable .to(device) runs at ~6 GB/s (2.7 ms for the
+                # 16 MiB every other rank waits for), a memcpy + asynchronous DMA at ~1 ms
+                if self._c_pin is None or self._c_pin.numel() < L * L or self._c_pin.dtype != tdt:
+                    self._c_pin = torch.empty(L * L, dtype=tdt, pin_memory=True)
+                np.copyto(self._c_pin[: L * L].numpy(), C.reshape(-1))
+                d_C = self._c_pin[: L * L].to(self.device, non_blocking=True)
+            else:
+                d_C = torch.empty(L * L, dtype=tdt, device=self.device)
+            if self.world > 1:                              # RCCL over xGMI (complex data travels as pairs of doubles)
+                dist.broadcast(torch.view_as_real(d_C) if cplx else d_C, 0)
             mat = d_C
         else:
             h_C = torch.from_numpy(C.reshape(-1)) if self.rank == 0 else torch.empty(L * L, dtype=tdt)
             if self.world > 1:
-                dist.broadcast(h_C, 0)
+                dist.broadcast(torch.view_as_real(h_C) if cplx else h_C, 0)
             mat = h_C.numpy().reshape(L, L)
         rng = shard_sites(L, oc, self.world)[self.rank]
         mps = self.eng.run(mat, trunc, oc, ucw, threads=self.host_threads, download=True, site_range=rng, sink=self.sink)

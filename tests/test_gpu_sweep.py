@@ -280,6 +280,32 @@ def test_spinful_ph_chain_block_decoupled_spectra(L, chi):
     assert abs(1 - overlap(cuts, sites, mps, L)) < 1e-3
 
 
+@pytest.mark.parametrize("L,ph", [(10, True), (12, False)])
+def test_spinful_chain_without_chi_limit_matches_oracle_tightly(L, ph):
+    """The same block-decoupled, exactly degenerate input with `chi_max=None`: the list is then cut by the svd_min
+    threshold alone, which a multiplet straddles only if the threshold falls inside its 1e-7-wide noise band, so - unlike
+    with a chi_max that cuts multiplets - the kept SET of patterns is determined and the comparison is sharp: chi equal,
+    sorted Schmidt values 1e-10, entropies 1e-10, state overlap 1 - 1e-9 (config 5's Slater stage at oracle sizes)."""
+    from tests_inputs import uniform_chain
+    from temfpy_amd import slater
+
+    C, _ = orc.correlation_matrix(uniform_chain(L) + 0.2 * np.diag(np.cos(0.9 * np.arange(L))))
+    kind = "PH" if ph else "simple"
+    mps = slater.C_to_MPS(C, {"chi_max": None}, as_tenpy=False, spinful=kind)
+    cuts, sites = orc.c_to_mps(C, {"chi_max": None}, spinful=kind)
+    assert mps.L == 2 * L
+    for b in range(2 * L + 1):
+        c, m = cuts[b], mps.bonds[b]
+        assert (c.k, c.n_filled("L"), c.n_filled("R")) == (len(m.e), m.n_filled_left, m.n_filled_right)
+        np.testing.assert_allclose(m.e, c.e, rtol=0, atol=1e-12)
+        assert m.chi == len(c.lam), (b, m.chi, len(c.lam))
+        np.testing.assert_allclose(np.sort(m.lam), np.sort(c.lam), rtol=0, atol=1e-10)
+        assert sorted(map(bytes, np.packbits(m.sets, axis=1))) == sorted(map(bytes, np.packbits(c.sets, axis=1)))
+    dS = np.abs(orc.entropies(cuts) - mps.entanglement_entropy(all_bonds=True)).max()
+    assert dS < 1e-10, dS
+    assert abs(1 - overlap(cuts, sites, mps, L)) < 1e-9
+
+
 def test_schmidt_decomposition_self_check_on_device():
     """testing.check_schmidt_decomposition (testing.py:131-177) evaluated by tmf_recon_error_batched:
     deviations of the centre cut far below diag_tol for a proper Slater determinant, reported as
