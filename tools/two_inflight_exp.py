@@ -11,7 +11,7 @@ from temfpy_amd.schmidt_utils import to_stopping_condition
 import torch
 C, _ = slater.correlation_matrix(random_hopping(1024, 0))
 tr = to_stopping_condition({"chi_max": 512})
-K = 20
+K = 40
 for mode in ("async", False):
     for nthr, ht in ((1, 32), (2, 16), (2, 32)):
         engs = [Engine("cuda:0") for _ in range(nthr)]
@@ -26,7 +26,7 @@ for mode in ("async", False):
             for r in res:
                 r.wait()
         for e in engs:
-            work(e, 3)
+            work(e, 10)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         th = [threading.Thread(target=work, args=(e, K // nthr)) for e in engs]
