@@ -11,9 +11,9 @@ from temfpy_amd.schmidt_utils import to_stopping_condition
 import torch
 C, _ = slater.correlation_matrix(random_hopping(1024, 0))
 tr = to_stopping_condition({"chi_max": 512})
-K = 40
-for mode in ("async", False):
-    for nthr, ht in ((1, 32), (2, 16), (2, 32)):
+K = 24
+for mode in (("async",) if os.environ.get("EXP_ASYNC_ONLY") else ("async", False)):
+    for nthr, ht in (((1, 32), (2, 16)) if os.environ.get("EXP_ASYNC_ONLY") else ((1, 32), (2, 16), (2, 32))):
         engs = [Engine("cuda:0") for _ in range(nthr)]
         last = {}
         def work(e, n, ht=ht):
