@@ -158,7 +158,7 @@ def self_spawn(a):
         if r != 0 and p.stdout is not None:
             p.stdout.close()
     if out0:
-        sys.stdout.write(out0)
+        sys.stdout.write("".join(ln + "\n" for ln in out0.splitlines() if ln.startswith("{")))
         sys.stdout.flush()
     sys.exit(rc)
 
@@ -179,6 +179,16 @@ def main():
 
     dry = os.environ.get("TMF_DRY_ENGINE") == "1"
     same_dev = os.environ.get("TMF_BENCH_SAME_DEVICE") == "1"
+    # The contract is ONE JSON line on stdout.  Libraries underneath write to the C-level stdout (gloo announces its
+    # peers there), so file descriptor 1 points to stderr for the rest of the run and the line goes to a saved copy.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    def emit(obj):
+        real_stdout.write(json.dumps(obj) + "\n")
+        real_stdout.flush()
+
     import torch
     import torch.distributed as dist
     from temfpy_amd import multi_gpu
@@ -281,7 +291,7 @@ def main():
                 ref = np.load(REF_SUMMARY)
                 out["max_abs_dS_vs_reference"] = float(np.abs(mps.entanglement_entropy(all_bonds=True) - ref["S"]).max())
                 out["sites_assembled"] = int(sum(mps.sites[i] is not None for i in range(0, L, 37)))
-            print(json.dumps(out), flush=True)
+            emit(out)
         del mps
         barrier()
         dist.destroy_process_group()
@@ -416,7 +426,7 @@ def main():
         cb, S_ref = cpu_baseline(C0, chi, L, oc, a.cpu_sample)
         out["cpu_baseline"] = cb
         out["max_abs_dS_vs_oracle"] = float(max(abs(S_hip[b] - s) for b, s in S_ref.items()))
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 if __name__ == "__main__":
