@@ -511,6 +511,7 @@ void tmf_ctx_destroy(tmf_ctx* ctx);
 #define TMF_SWEEP_DET_DIRECT 32u   /* ... through tmf_det_gather_batched                                  */
 #define TMF_SWEEP_C_ON_DEVICE 64u  /* C is a device pointer (row-major) instead of host memory            */
 #define TMF_SWEEP_TWO_PASSES 128u  /* two projection passes in the filled-basis Gram-Schmidt              */
+#define TMF_SWEEP_ONE_STREAM 1024u  /* filled-basis Gram-Schmidt of the left and right blocks on one stream (A/B)   */
 #define TMF_SWEEP_NARROW_BCGS 512u /* 16- instead of 64-column outer blocks in the filled-basis Gram-Schmidt (A/B) */
 #define TMF_SWEEP_LU_SINGLE 256u   /* Schur complements by tmf_lu_schur_batched (one workgroup per site; A/B)  */
 

@@ -99,7 +99,8 @@ SYMBOLS = [
 
 # ---- sweep-level structs (include/temfpy_hip.h, "Sweep level") ---------------------------------------------
 SWEEP_CHECKS, SWEEP_TIME_KERNELS, SWEEP_RANGE_BCGS, SWEEP_NO_CHOLQR = 1, 2, 4, 8
-SWEEP_DET_REDUCED, SWEEP_DET_DIRECT, SWEEP_C_ON_DEVICE, SWEEP_TWO_PASSES, SWEEP_LU_SINGLE, SWEEP_NARROW_BCGS = 16, 32, 64, 128, 256, 512
+SWEEP_DET_REDUCED, SWEEP_DET_DIRECT, SWEEP_C_ON_DEVICE, SWEEP_TWO_PASSES, SWEEP_LU_SINGLE, SWEEP_NARROW_BCGS, SWEEP_ONE_STREAM = (
+    16, 32, 64, 128, 256, 512, 1024)
 
 
 class SweepParams(C.Structure):

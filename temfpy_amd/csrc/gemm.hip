@@ -25,7 +25,7 @@ constexpr int KT = 16;
 constexpr int LDT = KT + 1;  // padded k-stride of the LDS tiles (doubles)
 
 template <typename T, int OPA, int TN>
-__global__ __launch_bounds__(256) void gemm_kernel(const tmf_gemm_desc* __restrict__ desc,
+__global__ __launch_bounds__(256, 3) void gemm_kernel(const tmf_gemm_desc* __restrict__ desc,
                                                    const int32_t* __restrict__ tiles, double alpha, double beta) {
   constexpr int CP = sc<T>::cplx;
   constexpr int NP = CP ? 2 : 1;               // planes (re, im)

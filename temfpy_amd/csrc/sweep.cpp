@@ -363,7 +363,10 @@ struct Sweep {
     u64 scratch;
   };
   // blocked classical Gram-Schmidt with re-orthogonalisation (tmf_bcgs_batched)
-  int bcgs(std::vector<Slab> s, int passes, bool cholqr, bool wide = false) {
+  // `on`: the stream the kernels run on.  Descriptors (and the zeroing of the norms) always go through the launch
+  // stream; another stream waits for them by event.
+  int bcgs(std::vector<Slab> s, int passes, bool cholqr, bool wide = false, hipStream_t on = nullptr) {
+    if (on == nullptr) on = c.s_main;
     s.erase(std::remove_if(s.begin(), s.end(), [](const Slab& x) { return !(x.rows > 0 && x.c1 > x.c0); }), s.end());
     if (s.empty()) return TMF_OK;
     std::stable_sort(s.begin(), s.end(), [](const Slab& a, const Slab& b) { return a.rows > b.rows; });
@@ -385,13 +388,19 @@ struct Sweep {
     }
     u64 t_nd, t_bd;
     TMF_TRY(up_vec(nd, &t_nd));
-    TMF_TRY(tmf_column_norms_batched(c.dtype, (const tmf_norms_desc*)t_nd, (int)s.size(), c.s_main));
     TMF_TRY(up_vec(bd, &t_bd));
     const i64 wb = tmf_bcgs_work_bytes(bd.data(), (int)bd.size());
     void* d_work;
     TMF_TRY(dalloc(wb, 1, &d_work));
+    if (on != c.s_main) {
+      hipEvent_t ev;
+      TMF_TRY(new_event(&ev));
+      HIP_TRY(hipEventRecord(ev, c.s_main));
+      HIP_TRY(hipStreamWaitEvent(on, ev, 0));
+    }
+    TMF_TRY(tmf_column_norms_batched(c.dtype, (const tmf_norms_desc*)t_nd, (int)s.size(), on));
     return tmf_bcgs_batched(c.dtype, (const tmf_bcgs_desc*)t_bd, bd.data(), (int)bd.size(), passes, (cholqr ? 1 : 0) | (wide ? 2 : 0), d_work, wb,
-                            c.s_main);
+                            on);
   }
 
   struct HSlab {
@@ -1030,10 +1039,27 @@ struct Sweep {
       const bool wide = !(c.par.flags & TMF_SWEEP_NARROW_BCGS);
       const i64 per = (maxcol + 1) * (wide ? 64 : PANEL_W);
       TMF_TRY(alloc_el(per * ncs, &d_scr2));
-      std::vector<Slab> s;
+      // The Gram-Schmidt of the filled bases is a chain of ~110 short dependent launches (per 16-column panel: descriptors,
+      // coefficients, update, two Gram / Cholesky rounds; 20 - 35 us each, every one over all slabs) - bound by the latency
+      // of one launch, not by the GPU.  The slabs of the left and of the right blocks are independent: their two chains run
+      // on two streams at once (the upload stream is idle until the index lists go up).
+      std::vector<Slab> s[2];
       for (i64 i = 0; i < ncs; ++i)
-        if (c.nf[i] > 0) s.push_back(Slab{Vp[i], c.n[i], c.ld1[i], c.k[i], ncolV[i], d_scr2 + (u64)(i * per * el)});
-      TMF_TRY(bcgs(s, (c.par.flags & TMF_SWEEP_TWO_PASSES) ? 2 : 1, !(c.par.flags & TMF_SWEEP_NO_CHOLQR), wide));
+        if (c.nf[i] > 0) s[c.cs_side[i]].push_back(Slab{Vp[i], c.n[i], c.ld1[i], c.k[i], ncolV[i], d_scr2 + (u64)(i * per * el)});
+      const int passes = (c.par.flags & TMF_SWEEP_TWO_PASSES) ? 2 : 1;
+      const bool cholqr = !(c.par.flags & TMF_SWEEP_NO_CHOLQR);
+      const bool two_streams = !s[0].empty() && !s[1].empty() && !(c.par.flags & TMF_SWEEP_ONE_STREAM);
+      if (two_streams) {
+        TMF_TRY(bcgs(s[1], passes, cholqr, wide, c.s_up));
+        TMF_TRY(bcgs(s[0], passes, cholqr, wide));
+        hipEvent_t ev;
+        TMF_TRY(new_event(&ev));
+        HIP_TRY(hipEventRecord(ev, c.s_up));
+        HIP_TRY(hipStreamWaitEvent(c.s_main, ev, 0));
+      } else {
+        s[0].insert(s[0].end(), s[1].begin(), s[1].end());
+        TMF_TRY(bcgs(s[0], passes, cholqr, wide));
+      }
     }
     // self-check of the centre cut (testing.py:131-177; slater.py:419-420 runs it only there)
     c.n_checks = 0;

@@ -502,6 +502,7 @@ class Engine:
     filled_passes = int(os.environ.get("TMF_FILLED_PASSES", "1"))     # projection passes of the filled-basis QR
     host_threads = int(os.environ.get("TMF_HOST_THREADS", min(32, os.cpu_count() or 1)))   # enumeration / site preparation
     filled_blocks = int(os.environ.get("TMF_FILLED_BLOCKS", "64"))     # outer block width of the filled-basis Gram-Schmidt (64 | 16)
+    one_stream = os.environ.get("TMF_ONE_STREAM", "0") == "1"          # no second stream for the filled-basis chain (A/B)
     lu_method = os.environ.get("TMF_LU", "blocked")                    # "blocked" (multi-launch, MFMA update) | "single"
 
     def _fetch_async(self, tensors):
@@ -736,6 +737,7 @@ class Engine:
         flags |= nat.SWEEP_TWO_PASSES if self.filled_passes >= 2 else 0
         flags |= nat.SWEEP_LU_SINGLE if self.lu_method == "single" else 0
         flags |= nat.SWEEP_NARROW_BCGS if self.filled_blocks == 16 else 0
+        flags |= nat.SWEEP_ONE_STREAM if self.one_stream else 0
         flags |= nat.SWEEP_DET_DIRECT if self.force_direct_det else (nat.SWEEP_DET_REDUCED if self.det_method != "ppt" else 0)
         par = nat.SweepParams(L=L, chi_max=int(trunc.chi_max or 0), svd_min=float(trunc.svd_min),
                               degeneracy_tol=float(trunc.degeneracy_tol), sectors=None if sec is None else sec.ctypes.data,
