@@ -502,7 +502,10 @@ class Engine:
     filled_passes = int(os.environ.get("TMF_FILLED_PASSES", "1"))     # projection passes of the filled-basis QR
     host_threads = int(os.environ.get("TMF_HOST_THREADS", min(32, os.cpu_count() or 1)))   # enumeration / site preparation
     filled_blocks = int(os.environ.get("TMF_FILLED_BLOCKS", "64"))     # outer block width of the filled-basis Gram-Schmidt (64 | 16)
-    one_stream = os.environ.get("TMF_ONE_STREAM", "0") == "1"          # no second stream for the filled-basis chain (A/B)
+    # The two Gram-Schmidt chains of the filled bases (left / right blocks) on two streams: 0.3 ms faster device-resident,
+    # but with a tensor download in flight the second kernel stream ended up behind the 27 ms copy (73 instead of 30 ms
+    # per conversion, measured) - the runtime multiplexes streams onto few hardware queues.  Off unless asked for.
+    one_stream = os.environ.get("TMF_ONE_STREAM", "1") == "1"
     lu_method = os.environ.get("TMF_LU", "blocked")                    # "blocked" (multi-launch, MFMA update) | "single"
 
     def _fetch_async(self, tensors):
