@@ -175,6 +175,26 @@ typedef struct {
 int tmf_lu_block_batched(int dtype, const tmf_lublock_desc* d_desc, int nprob, int j0, int wb, int max_mb, void* stream);
 int tmf_lu_trsm_batched(int dtype, const tmf_lublock_desc* d_desc, int nprob, int j0, int wb, int max_cols, void* stream);
 
+/* The same Schur complement by block Gaussian elimination with the row search confined to the 64 x 64 diagonal block D of
+ * every outer step; everything outside the block is GEMM work with the explicit inverse of D:
+ *   tmf_diag_inverse_batched   D^-1 of W[j0:cend, j0:cend] (Gauss-Jordan with row pivoting, in registers) into `inv` (dense,
+ *                              leading dimension 64), det(A) accumulated in `det`; d_stats[2 p] = smallest |pivot|^2 of
+ *                              matrix p so far, d_stats[2 p + 1] = largest |entry|^2 of D^-1 over the blocks with
+ *                              always-rows below them (reset at step 0): the caller repeats the LU with
+ *                              tmf_lu_block_batched when it exceeds its threshold
+ *   tmf_gemm_batched           X = D^-1 W[j0:cend, cend:]
+ *   tmf_gemm_batched           W[cend:, cend:] -= W[cend:, j0:cend] X
+ * Outer step s works on columns [j0, cend) of the k always-columns, counted from the end: block 0 = [0, (k-1) % 64 + 1),
+ * block s = the next 64.  Valid because the always-occupied orbitals of neighbouring cuts are nearly aligned (same random
+ * block behind every filled basis, tmf_site_prepare pairs them): their overlap matrix is close to block diagonal and
+ * ||D^-1 A12|| stays O(1) (see lu_schur.hip). */
+typedef struct {
+  uint64_t W, det;           /* mb x mk workspace (ldw); one element                                 */
+  uint64_t inv;              /* out: D^-1, 64 x 64 elements (leading dimension 64)                   */
+  int32_t mb, mk, k, ldw;
+} tmf_diaginv_desc;          /* 40 bytes */
+int tmf_diag_inverse_batched(int dtype, const tmf_diaginv_desc* d_desc, int nprob, int step, void* d_stats, void* stream);
+
 /* The hot kernel: batched gathered determinants (slater.py:828-869, `_tensor_block`,
  * 90 % of the reference's wall time).  For every tile, for every pair (a, b) of a bra
  * row and a ket row of one charge sector, out[a, b] = scale * det(S[rows(a)][:, cols(b)]).
@@ -514,6 +534,9 @@ void tmf_ctx_destroy(tmf_ctx* ctx);
 #define TMF_SWEEP_ONE_STREAM 1024u  /* filled-basis Gram-Schmidt of the left and right blocks on one stream (A/B)   */
 #define TMF_SWEEP_NARROW_BCGS 512u /* 16- instead of 64-column outer blocks in the filled-basis Gram-Schmidt (A/B) */
 #define TMF_SWEEP_LU_SINGLE 256u   /* Schur complements by tmf_lu_schur_batched (one workgroup per site; A/B)  */
+#define TMF_SWEEP_LU_PIVOTED 2048u /* ... by the fully pivoted blocked LU (tmf_lu_block_batched; A/B).  Default: pivoting inside the
+                                    * 64 x 64 diagonal blocks (tmf_diag_inverse_batched), fully pivoted only when a block inverse grows */
+#define TMF_SWEEP_LU_FORCE_FALLBACK 4096u /* tests: treat every pivot as too small, i.e. run the default and then the fallback */
 
 typedef struct {
   int64_t L;                 /* C is L x L, row-major, real (double) or complex (re, im doubles)          */
@@ -550,6 +573,9 @@ typedef struct {
   int32_t range_width, range_iterations;
   double range_floor;
   int64_t n_fermion, device_bytes;
+  double lu_min_pivot;       /* smallest |pivot| of the block-local elimination of the last sweep (0: method not used) */
+  double lu_max_inverse;     /* its largest |entry| of a diagonal-block inverse (fallback above the cap)               */
+  int64_t lu_fallbacks;      /* sweeps of this context that had to repeat the LU fully pivoted                */
 } tmf_sweep_info;
 
 int tmf_sweep_begin(tmf_ctx* ctx, const void* C, const tmf_sweep_params* par);

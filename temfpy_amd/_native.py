@@ -40,6 +40,8 @@ schur_desc = np.dtype([("W", "<u8"), ("S", "<u8"), ("det", "<u8"), ("mb", "<i4")
 lublock_desc = np.dtype([("W", "<u8"), ("det", "<u8"), ("piv", "<u8"), ("T", "<u8"), ("mb", "<i4"), ("mk", "<i4"),
                          ("k", "<i4"), ("ldw", "<i4")])
 assert lublock_desc.itemsize == 48
+diaginv_desc = np.dtype([("W", "<u8"), ("det", "<u8"), ("inv", "<u8"), ("mb", "<i4"), ("mk", "<i4"), ("k", "<i4"), ("ldw", "<i4")])
+assert diaginv_desc.itemsize == 40
 det_desc = np.dtype([("S", "<u8"), ("scale", "<u8"), ("bra_idx", "<u8"), ("ket_idx", "<u8"), ("out", "<u8"),
                      ("sb", "<i4"), ("sk", "<i4"), ("lds", "<i4"), ("n", "<i4"), ("nsb", "<i4"), ("nsk", "<i4"),
                      ("a0", "<i4"), ("a1", "<i4")])
@@ -90,7 +92,7 @@ SYMBOLS = [
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_column_norms_batched", "tmf_cut_vectors",
     "tmf_site_prepare", "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_det_tiles_build", "tmf_pf_gather_batched",
     "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched", "tmf_copy_blocks_batched", "tmf_house_qr_batched", "tmf_jacobi_compact_batched", "tmf_house_slab_batched",
-    "tmf_host_register", "tmf_host_unregister", "tmf_memcpy_async", "tmf_lu_block_batched", "tmf_lu_trsm_batched",
+    "tmf_host_register", "tmf_host_unregister", "tmf_memcpy_async", "tmf_lu_block_batched", "tmf_lu_trsm_batched", "tmf_diag_inverse_batched",
     "tmf_ctx_create", "tmf_ctx_destroy", "tmf_sweep_begin", "tmf_sweep_entangled", "tmf_sweep_sites", "tmf_sweep_download",
     "tmf_sweep_query", "tmf_sweep_wait", "tmf_sweep_info_get", "tmf_sweep_stage_name", "tmf_sweep_device_out",
     "tmf_slater_sweep", "tmf_result_dims", "tmf_result_bond", "tmf_result_site", "tmf_result_block", "tmf_result_checks",
@@ -101,6 +103,7 @@ SYMBOLS = [
 SWEEP_CHECKS, SWEEP_TIME_KERNELS, SWEEP_RANGE_BCGS, SWEEP_NO_CHOLQR = 1, 2, 4, 8
 SWEEP_DET_REDUCED, SWEEP_DET_DIRECT, SWEEP_C_ON_DEVICE, SWEEP_TWO_PASSES, SWEEP_LU_SINGLE, SWEEP_NARROW_BCGS, SWEEP_ONE_STREAM = (
     16, 32, 64, 128, 256, 512, 1024)
+SWEEP_LU_PIVOTED, SWEEP_LU_FORCE_FALLBACK = 2048, 4096
 
 
 class SweepParams(C.Structure):
@@ -125,7 +128,8 @@ class SweepInfo(C.Structure):
     _fields_ = [("stage_ms", C.c_double * 16), ("gemm_ms", C.c_double), ("gemm_flops", C.c_double), ("det_ms", C.c_double),
                 ("det_flops", C.c_double), ("det_all_ms", C.c_double), ("n_det", C.c_int64), ("n_gemm_launches", C.c_int64),
                 ("det_kind", C.c_int32), ("det_order", C.c_int32), ("range_width", C.c_int32), ("range_iterations", C.c_int32),
-                ("range_floor", C.c_double), ("n_fermion", C.c_int64), ("device_bytes", C.c_int64)]
+                ("range_floor", C.c_double), ("n_fermion", C.c_int64), ("device_bytes", C.c_int64),
+                ("lu_min_pivot", C.c_double), ("lu_max_inverse", C.c_double), ("lu_fallbacks", C.c_int64)]
 
 
 class BondView(C.Structure):
@@ -219,6 +223,7 @@ def load():
     _set_host_argtypes(lib)
     lib.tmf_lu_block_batched.argtypes = [i32, vp, i32, i32, i32, i32, vp]
     lib.tmf_lu_trsm_batched.argtypes = [i32, vp, i32, i32, i32, i32, vp]
+    lib.tmf_diag_inverse_batched.argtypes = [i32, vp, i32, i32, vp, vp]
     lib.tmf_ctx_create.argtypes = [i32, C.POINTER(vp)]
     lib.tmf_ctx_destroy.argtypes = [vp]
     lib.tmf_ctx_destroy.restype = None

@@ -326,6 +326,40 @@ extern "C" int tmf_site_prepare(const tmf_site_in* in, const uint64_t* sets_b, c
   };
   assemble(ab, sb_, rows, srows);
   assemble(ak, sk_, cols, scols);
+  // Order inside the always block (free: the Schur complement does not depend on it, det(A) only through the parity,
+  // which goes into the sign of the first row).  Filled orbital f of either side is column f of the same random block
+  // pushed through the side's projector and orthonormalised in column order, so <filled_b f | filled_k f> is the
+  // dominant entry of its row and column.  Those pairs go on the diagonal of the leading part; the orbitals without a
+  // partner (always-occupied entangled ones, surplus filled ones) come last: they repair the rank the paired part
+  // lacks when the two sides have different numbers of filled orbitals, which only shows in its last pivots.  The
+  // block-local pivoting of tmf_lu_diag_batched relies on this (lu_schur.hip); the fully pivoted kernels do not care.
+  {
+    auto filled_index = [&](const Orb& o, int k_side) { return (o.ent < 0 && o.src >= 0) ? o.src - k_side : -1; };
+    const int nf_max = std::max(B.nf, K.nf);
+    std::vector<char> in_rows((size_t)nf_max + 1, 0), paired((size_t)nf_max + 1, 0);
+    for (int i = 0; i < k; ++i) {
+      const int f = filled_index(rows[i], B.k);
+      if (f >= 0) in_rows[(size_t)f] = 1;
+    }
+    for (int i = 0; i < k; ++i) {
+      const int f = filled_index(cols[i], K.k);
+      if (f >= 0 && f <= nf_max && in_rows[(size_t)f]) paired[(size_t)f] = 1;
+    }
+    auto reorder = [&](std::vector<Orb>& v, int k_side) -> int {   // returns the parity of the permutation
+      std::vector<Orb> rest, pairs;   // filled orbitals appear in ascending f on both sides
+      long inversions = 0;
+      for (int i = 0; i < k; ++i) {
+        const int f = filled_index(v[i], k_side);
+        if (f >= 0 && paired[(size_t)f]) pairs.push_back(v[i]), inversions += (long)rest.size();
+        else rest.push_back(v[i]);
+      }
+      for (size_t i = 0; i < pairs.size(); ++i) v[i] = pairs[i];
+      for (size_t i = 0; i < rest.size(); ++i) v[pairs.size() + i] = rest[i];
+      return (int)(inversions & 1);
+    };
+    const int parity = reorder(rows, B.k) ^ reorder(cols, K.k);
+    if (parity && k > 0) rows[0].sign = -rows[0].sign;
+  }
   const int mb = (int)rows.size(), mk = (int)cols.size();
   const int sb = mb - k, sk = mk - k;
   if (sb > 255 || sk > 255) {

@@ -396,6 +396,168 @@ __global__ __launch_bounds__(256) void lu_trsm_kernel(const tmf_lublock_desc* __
   }
 }
 
+
+// -------------------------------------------------------------------------------------------
+// Block-local pivoting (tmf_diag_inverse_batched): the filled-orbital bases of neighbouring cuts are built from the SAME
+// random block (column f of Omega_f -> column f of the basis, Gram-Schmidt in column order), so the overlap of the
+// always-occupied orbitals of a site is close to a (block-)diagonal matrix once tmf_site_prepare has put the paired
+// filled orbitals on the diagonal.  Block Gaussian elimination is stable for such matrices as long as ||D^-1 A12|| stays
+// bounded (Demmel, Higham, Schreiber 1995), so the row search is confined to the 64 x 64 diagonal block D of each outer
+// step and everything else is MFMA GEMM work:
+//     D^-1 (this kernel)        X = D^-1 A12        A22 -= A21 X        det(A) = prod det(D)
+// The diagonal blocks are counted from the END of the always-block (block 0 has (k - 1) % 64 + 1 columns, the others 64):
+// the orbitals without a partner come last (tmf_site_prepare), and the loss of rank of the paired part that they repair
+// only shows in its last pivots - both must sit in the same diagonal block for the local search to find them.
+// Reported per matrix: the smallest pivot magnitude and the largest |entry| of D^-1 over the blocks that have always-rows
+// below them (where a search over all rows could have done better).  The caller repeats the factorisation fully pivoted
+// (tmf_lu_block_batched) when that entry is large, so robustness does not rest on the structure assumed here.
+//
+// The kernel: in-place Gauss-Jordan inversion with (implicit) row pivoting, entirely in registers.  One 256-thread
+// workgroup per matrix; thread (lane r, wave w) holds row r of the 16 columns c = w (mod 4).  Per elimination step the
+// wave that owns column j finds the pivot row (DPP max over the unused rows), publishes the multipliers through LDS
+// (one barrier per step), every wave reads the pivot row of its own columns with v_readlane (the pivot row index is
+// wave-uniform) and updates its 16 columns: 64 readlanes + 64 FMAs per step and wave, no LDS traffic for the matrix.
+// Rows are never moved: row p_j (the pivot row of column j) of the result is row j of (P D)^-1, un-permuted on output.
+// -------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ inline double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double readlane_d(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ inline double readlane_t(double v, int l) { return readlane_d(v, l); }
+__device__ inline cd readlane_t(cd v, int l) { return make_cd(readlane_d(v.x, l), readlane_d(v.y, l)); }
+// maximum over the 64 lanes (non-NaN input), the same value in every lane
+__device__ inline double wave_max64(double v) {
+  v = fmax(v, dpp_mov<0x111>(v));   // row_shr:1   inclusive scan inside every row of 16 lanes ...
+  v = fmax(v, dpp_mov<0x112>(v));   // row_shr:2
+  v = fmax(v, dpp_mov<0x114>(v));   // row_shr:4
+  v = fmax(v, dpp_mov<0x118>(v));   // row_shr:8   ... lane 15 of a row holds the row maximum
+  v = fmax(v, dpp_mov<0x142>(v));   // row_bcast:15: lane 15 of a row into the next row
+  v = fmax(v, dpp_mov<0x143>(v));   // row_bcast:31: lane 31 into rows 2, 3   -> lane 63 holds the maximum
+  return readlane_d(v, 63);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void diag_inverse_kernel(const tmf_diaginv_desc* __restrict__ desc, const int step, double* __restrict__ stats) {
+  constexpr int WB = 64;
+  __shared__ T colbuf[2][WB];
+  __shared__ T pvbuf[2];
+  __shared__ int pivbuf[2];
+  __shared__ int perm[WB], pos[WB];
+  __shared__ T wdet[4];
+  __shared__ double wmin[4], wmax[4];
+  const tmf_diaginv_desc d = desc[blockIdx.x];
+  const int k = d.k, ldw = d.ldw;
+  const int tid = threadIdx.x, r = tid & 63, cg = tid >> 6;
+  // blocks counted from the END of the always-block: a ragged first block, full ones after it
+  const int nb0 = k > 0 ? (k - 1) % WB + 1 : 0;
+  const int j0 = step == 0 ? 0 : nb0 + (step - 1) * WB;
+  if (j0 >= k) {
+    if (j0 == 0 && tid == 0) *reinterpret_cast<T*>(d.det) = sc<T>::one(), stats[2 * blockIdx.x] = 1e300, stats[2 * blockIdx.x + 1] = 0.0;
+    return;
+  }
+  const int cend = step == 0 ? nb0 : j0 + WB, nb = cend - j0;
+  const T* __restrict__ W = reinterpret_cast<const T*>(d.W);
+  // the block, padded with the identity to 64 x 64 (the padding pivots on itself with pivot 1)
+  T x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = cg + 4 * i;
+    x[i] = (r < nb && c < nb) ? W[(size_t)(j0 + r) + (size_t)(j0 + c) * ldw] : (r == c ? sc<T>::one() : sc<T>::zero());
+  }
+  bool used = false;
+  T det = sc<T>::one();        // product of the pivots of the columns this wave owns
+  double minp = 1e300;
+#pragma unroll 1
+  for (int jj = 0; jj < 16; ++jj) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int j = 4 * jj + b, buf = b & 1;
+      if (cg == b) {            // this wave owns column j: it sits in x[0] (the registers rotate once per jj)
+        const T v = x[0];
+        const double a2 = used ? -1.0 : sc<T>::abs2(v);
+        const double mx = wave_max64(a2);
+        const int piv = __builtin_ctzll(__ballot(a2 == mx));
+        const T pv = readlane_t(v, piv);
+        const T pvinv = mx > 0.0 ? sc<T>::inv(pv) : sc<T>::zero();     // singular block: det = 0, finite garbage
+        colbuf[buf][r] = (r == piv) ? sc<T>::sub(sc<T>::one(), pvinv) : sc<T>::mul(v, pvinv);
+        if (r == 0) pivbuf[buf] = piv, pvbuf[buf] = pvinv, perm[j] = piv;
+        det = sc<T>::mul(det, pv);
+        if (j < nb) minp = fmin(minp, mx);
+      }
+      __syncthreads();
+      // unified update  x[r][c] -= g[r] x[p][c]:  g[r] = x[r][j] / pv for the other rows, g[p] = 1 - 1 / pv turns row p
+      // into x[p][c] / pv; column j itself becomes the column of the inverse: -g[r], and 1 / pv in row p
+      const T g = colbuf[buf][r];
+      const int piv = __builtin_amdgcn_readfirstlane(pivbuf[buf]);
+      if (r == piv) used = true;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) x[i] = sc<T>::fms(x[i], g, readlane_t(x[i], piv));
+      if (cg == b) x[0] = (r == piv) ? pvbuf[buf] : sc<T>::neg(g);
+    }
+    const T t = x[0];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) x[i] = x[i + 1];
+    x[15] = t;
+  }
+  // ---- bookkeeping: det(D) = prod pivots * sign(perm); statistics; un-permuted output -------------------------
+  double big = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const double a = sc<T>::abs2(x[i]);
+    big = (a > big || a != a) ? a : big;
+  }
+  {
+    // NaN-aware maximum over the wave (wave_max64 would drop a NaN)
+    for (int o = 32; o > 0; o >>= 1) {
+      const double a = __shfl_xor(big, o);
+      big = (a > big || a != a) ? a : big;
+    }
+  }
+  const double wm = minp;      // wave-uniform already
+  // every wave owns pivots: combine the four partial products / minima
+  if (r == 0) wdet[cg] = det, wmin[cg] = wm, wmax[cg] = big;
+  __syncthreads();
+  if (tid < WB) pos[tid] = WB;          // (a NaN block can leave perm short of a permutation: such rows are not written)
+  __syncthreads();
+  if (tid < WB) pos[perm[tid]] = tid;
+  if (tid == 0) {
+    T dd = sc<T>::mul(sc<T>::mul(wdet[0], wdet[1]), sc<T>::mul(wdet[2], wdet[3]));
+    unsigned long long seen = 0;
+    int transpositions = 0;
+    for (int i = 0; i < WB; ++i) {          // parity from the cycle lengths
+      if (seen >> i & 1) continue;
+      int len = 0;
+      for (int q = i; !(seen >> q & 1); q = perm[q]) seen |= 1ull << q, ++len;
+      transpositions += len - 1;
+    }
+    if (transpositions & 1) dd = sc<T>::neg(dd);
+    const T prev = (step == 0) ? sc<T>::one() : *reinterpret_cast<const T*>(d.det);
+    *reinterpret_cast<T*>(d.det) = sc<T>::mul(prev, dd);
+    const double m = fmin(fmin(wmin[0], wmin[1]), fmin(wmin[2], wmin[3]));
+    double g = wmax[0];
+    for (int w = 1; w < 4; ++w) g = (wmax[w] > g || wmax[w] != wmax[w]) ? wmax[w] : g;
+    const double m0 = (step == 0) ? 1e300 : stats[2 * blockIdx.x];
+    const double g0 = (step == 0) ? 0.0 : stats[2 * blockIdx.x + 1];
+    stats[2 * blockIdx.x] = fmin(m, m0);
+    stats[2 * blockIdx.x + 1] = (cend < k) ? ((g > g0 || g != g) ? g : g0) : g0;   // only blocks with always-rows below them
+  }
+  __syncthreads();
+  // (P D)^-1 = D^-1 P^T: storage row p_i is row i of it, its column j belongs to column p_j of D^-1
+  T* __restrict__ inv = reinterpret_cast<T*>(d.inv);
+  const int row = pos[r];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int col = perm[cg + 4 * i];
+    if ((unsigned)row < (unsigned)nb && (unsigned)col < (unsigned)nb) inv[(size_t)col * WB + row] = x[i];
+  }
+}
+
 }  // namespace tmf
 
 extern "C" int tmf_lu_schur_batched(int dtype, const tmf_schur_desc* d_desc, int nprob, int max_mb, void* stream) {
@@ -494,4 +656,23 @@ extern "C" int tmf_lu_trsm_batched(int dtype, const tmf_lublock_desc* d_desc, in
     return TMF_E_ARG;
   }
   return check_hip(hipGetLastError(), "tmf_lu_trsm_batched launch");
+}
+
+extern "C" int tmf_diag_inverse_batched(int dtype, const tmf_diaginv_desc* d_desc, int nprob, int step, void* d_stats, void* stream) {
+  using namespace tmf;
+  if (nprob <= 0) return TMF_OK;
+  if (step < 0) {
+    set_error("tmf_diag_inverse_batched: outer step %d", step);
+    return TMF_E_ARG;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == TMF_C128)
+    hipLaunchKernelGGL(diag_inverse_kernel<cd>, dim3(nprob), dim3(256), 0, s, d_desc, step, (double*)d_stats);
+  else if (dtype == TMF_F64)
+    hipLaunchKernelGGL(diag_inverse_kernel<double>, dim3(nprob), dim3(256), 0, s, d_desc, step, (double*)d_stats);
+  else {
+    set_error("tmf_diag_inverse_batched: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+  return check_hip(hipGetLastError(), "tmf_diag_inverse_batched launch");
 }

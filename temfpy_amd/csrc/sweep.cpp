@@ -255,6 +255,8 @@ struct tmf_ctx {
   int n_checks = 0;
   std::vector<int32_t*> sweep_counters;  // device arrays of Jacobi sweep counts
   std::vector<i64> sweep_counts_n;
+  double lu_min_pivot = 0.0, lu_max_inverse = 0.0, lu_inverse_cap = 100.0;
+  i64 lu_fallbacks = 0;
   // timings
   double stage_ms[N_STAGES] = {0};
   double t_begin = 0;
@@ -1250,17 +1252,16 @@ struct Sweep {
     u64 t_gd, t_sd = 0;
     TMF_TRY(up_vec(gd, &t_gd));
     TMF_TRY(tmf_gather_signed_batched(c.dtype, (const tmf_gather_desc*)t_gd, (int)ns, c.s_main));
-    if (c.par.flags & TMF_SWEEP_LU_SINGLE) {  // A/B switch: the one-workgroup-per-site kernel
-      TMF_TRY(up_vec(sd, &t_sd));
-      TMF_TRY(tmf_lu_schur_batched(c.dtype, (const tmf_schur_desc*)t_sd, (int)ns, (int)maxmb, c.s_main));
-    } else {
-      // Blocked LU over several launches: 64 always-columns per outer step, the rank-64 trailing update of all sites
-      // as one batched MFMA GEMM (see lu_schur.hip).  Sites ordered by the size of their always-block so that the
-      // sites still active at step j0 are a prefix of the descriptor array.
-      constexpr i64 WB = 64;
-      std::vector<i64> order(ns);
-      std::iota(order.begin(), order.end(), 0);
-      std::stable_sort(order.begin(), order.end(), [&](i64 a, i64 b) { return ka[a] > ka[b]; });
+    // Sites ordered by the size of their always-block so that the sites still active at outer step j0 are a prefix of
+    // the descriptor arrays of the blocked methods.
+    constexpr i64 WB = 64;
+    std::vector<i64> order(ns);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](i64 a, i64 b) { return ka[a] > ka[b]; });
+    const i64 kmax = ns > 0 ? ka[order[0]] : 0;
+    // Fully pivoted blocked LU over several launches: 64 always-columns per outer step, the rank-64 trailing update of
+    // all sites as one batched MFMA GEMM (see lu_schur.hip).
+    auto lu_pivoted = [&]() -> int {
       i64 piv_tot = 0, t_tot = 0;
       for (i64 j = 0; j < ns; ++j) piv_tot += ka[j], t_tot += ka[j] > 0 ? WB * mk[j] : 0;
       void* d_piv;
@@ -1278,7 +1279,6 @@ struct Sweep {
       }
       u64 t_ld;
       TMF_TRY(up_vec(ld, &t_ld));
-      const i64 kmax = ns > 0 ? ka[order[0]] : 0;
       for (i64 j0 = 0; j0 < std::max<i64>(kmax, 1); j0 += WB) {
         i64 nact = 0, act_mb = 0, max_cols = 0;
         while (nact < ns && ka[order[nact]] > j0) {
@@ -1299,6 +1299,90 @@ struct Sweep {
         }
         TMF_TRY(gemm(0, -1.0, 1.0, g));
       }
+      return TMF_OK;
+    };
+    // Block-local pivoting: row search inside the 64 x 64 diagonal block only, everything else GEMMs with the explicit
+    // inverse of the block (lu_schur.hip).  The statistics come back with the event ev_lu; lu_verify() falls back to the
+    // fully pivoted method when a block inverse has grown.
+    hipEvent_t ev_lu = nullptr;
+    double* h_minp = nullptr;
+    auto lu_local = [&]() -> int {
+      i64 n_blk = 0, t_tot = 0;
+      for (i64 j = 0; j < ns; ++j)
+        if (ka[j] > 0) ++n_blk, t_tot += WB * mk[j];
+      u64 d_inv, d_X;
+      TMF_TRY(alloc_el(n_blk * WB * WB, &d_inv));
+      TMF_TRY(alloc_el(t_tot, &d_X));
+      std::vector<tmf_diaginv_desc> ld(ns);
+      std::vector<u64> Xp(ns);
+      i64 io = 0, to = 0;
+      for (i64 r = 0; r < ns; ++r) {
+        const i64 j = order[r];
+        tmf_diaginv_desc& q = ld[r];
+        q.W = Wp[j], q.det = detp[j], q.inv = d_inv + (u64)(io * el);
+        Xp[r] = d_X + (u64)(to * el);
+        q.mb = (int32_t)mb[j], q.mk = (int32_t)mk[j], q.k = (int32_t)ka[j], q.ldw = (int32_t)std::max<i64>(mb[j], 1);
+        if (ka[j] > 0) io += WB * WB, to += WB * mk[j];
+      }
+      u64 t_ld;
+      void* t_minp;
+      TMF_TRY(up_vec(ld, &t_ld));
+      TMF_TRY(dalloc(2 * ns + 2, 8, &t_minp));
+      for (i64 step = 0; step * WB < std::max<i64>(kmax, 1); ++step) {
+        i64 nact = 0;
+        while (nact < ns && ka[order[nact]] > step * WB) ++nact;   // cdiv(k, 64) blocks whichever end they are counted from
+        TMF_TRY(tmf_diag_inverse_batched(c.dtype, (const tmf_diaginv_desc*)t_ld, (int)(step == 0 ? ns : nact), (int)step, t_minp, c.s_main));
+        if (nact == 0) break;
+        Gemm g1, g2;
+        for (i64 r = 0; r < nact; ++r) {
+          const i64 j = order[r], nb0 = (ka[j] - 1) % WB + 1;
+          const i64 j0 = step == 0 ? 0 : nb0 + (step - 1) * WB, cend = step == 0 ? nb0 : j0 + WB, nb = cend - j0;
+          const i64 ldw = std::max<i64>(mb[j], 1), rows2 = mb[j] - cend, cols2 = mk[j] - cend;
+          if (rows2 <= 0 || cols2 <= 0) continue;   // nothing behind the block
+          g1.add(ld[r].inv, Wp[j] + (u64)((j0 + cend * ldw) * el), Xp[r], nb, cols2, nb, WB, ldw, WB);          // X = D^-1 A12
+          g2.add(Wp[j] + (u64)((cend + j0 * ldw) * el), Xp[r], Wp[j] + (u64)((cend + cend * ldw) * el), rows2, cols2, nb, ldw, WB, ldw);
+        }
+        TMF_TRY(gemm(0, 1.0, 0.0, g1));
+        TMF_TRY(gemm(0, -1.0, 1.0, g2));
+      }
+      TMF_TRY(c.fetch.ensure((size_t)(2 * ns + 2) * 8));
+      h_minp = (double*)c.fetch.p;
+      HIP_TRY(hipMemcpyAsync(h_minp, t_minp, (size_t)ns * 16, hipMemcpyDeviceToHost, c.s_main));
+      TMF_TRY(new_event(&ev_lu));
+      HIP_TRY(hipEventRecord(ev_lu, c.s_main));
+      return TMF_OK;
+    };
+    auto lu_verify = [&]() -> int {   // before the first determinant launch
+      if (!ev_lu) return TMF_OK;
+      HIP_TRY(hipEventSynchronize(ev_lu));
+      ev_lu = nullptr;
+      double m2 = 1e300, g2 = 0.0;
+      bool nan = false;
+      for (i64 r = 0; r < ns; ++r) {
+        m2 = std::min(m2, h_minp[2 * r]);
+        nan = nan || !(h_minp[2 * r + 1] == h_minp[2 * r + 1]);
+        g2 = std::max(g2, h_minp[2 * r + 1]);
+      }
+      c.lu_min_pivot = std::sqrt(m2), c.lu_max_inverse = nan ? INFINITY : std::sqrt(g2);
+      if (getenv("TMF_LU_DEBUG"))
+        for (i64 r = 0; r < ns; ++r)
+          if (h_minp[2 * r] < 1e-4 || !(h_minp[2 * r + 1] < 16.0))
+            fprintf(stderr, "lu site %lld mode %d: k %lld mb %lld mk %lld nf_b %d nf_k %d min pivot %.3e max |D^-1| %.3e\n",
+                    (long long)order[r], (int)c.jobs[order[r]].mode, (long long)ka[order[r]], (long long)mb[order[r]],
+                    (long long)mk[order[r]], (int)c.jobs[order[r]].nf_b, (int)c.jobs[order[r]].nf_k, std::sqrt(h_minp[2 * r]),
+                    std::sqrt(h_minp[2 * r + 1]));
+      if (c.lu_max_inverse <= c.lu_inverse_cap && !(c.par.flags & TMF_SWEEP_LU_FORCE_FALLBACK)) return TMF_OK;
+      c.lu_fallbacks += 1;
+      TMF_TRY(tmf_gather_signed_batched(c.dtype, (const tmf_gather_desc*)t_gd, (int)ns, c.s_main));
+      return lu_pivoted();
+    };
+    if (c.par.flags & TMF_SWEEP_LU_SINGLE) {  // A/B switch: the one-workgroup-per-site kernel
+      TMF_TRY(up_vec(sd, &t_sd));
+      TMF_TRY(tmf_lu_schur_batched(c.dtype, (const tmf_schur_desc*)t_sd, (int)ns, (int)maxmb, c.s_main));
+    } else if (c.par.flags & TMF_SWEEP_LU_PIVOTED) {
+      TMF_TRY(lu_pivoted());
+    } else {
+      TMF_TRY(lu_local());
     }
     tick(ST_SCHUR, t0);
 
@@ -1328,6 +1412,7 @@ struct Sweep {
                                rest_keys.data(), (i64)rest_keys.size(), &n_rest, &lds_max, &fl3, &npairs);
       rest_keys.resize((size_t)n_rest);
       have_rest_keys = true;
+      TMF_TRY(lu_verify());
       if (nt > 0) {
         u64 t_dd;
         TMF_TRY(up(tiles.data(), (size_t)nt * sizeof(tmf_det_desc), &t_dd));
@@ -1357,6 +1442,7 @@ struct Sweep {
     } else {
       for (i64 key : rest_keys) rs.push_back(Rest{key >> 32, key & 0xFFFFFFFF});
     }
+    TMF_TRY(lu_verify());
     if (!rs.empty()) {
       struct TileX {
         tmf_det_desc d;
@@ -1676,6 +1762,7 @@ extern "C" int tmf_sweep_info_get(tmf_ctx* ctx, tmf_sweep_info* o) {
   o->range_width = ctx->P, o->range_iterations = ctx->range_iterations, o->range_floor = ctx->range_floor;
   o->n_fermion = ctx->n_fermion, o->device_bytes = (int64_t)(ctx->dev_set[0].total + ctx->dev_set[1].total);
   o->n_det = ctx->n_det;
+  o->lu_min_pivot = ctx->lu_min_pivot, o->lu_max_inverse = ctx->lu_max_inverse, o->lu_fallbacks = ctx->lu_fallbacks;
   const int64_t n_det_all = ctx->n_det;
   (void)n_det_all;
   if (!ctx->gemm_events.empty() || !ctx->det_events.empty()) {

@@ -506,7 +506,10 @@ class Engine:
     # but with a tensor download in flight the second kernel stream ended up behind the 27 ms copy (73 instead of 30 ms
     # per conversion, measured) - the runtime multiplexes streams onto few hardware queues.  Off unless asked for.
     one_stream = os.environ.get("TMF_ONE_STREAM", "1") == "1"
-    lu_method = os.environ.get("TMF_LU", "blocked")                    # "blocked" (multi-launch, MFMA update) | "single"
+    # "local": pivoting inside the 64 x 64 diagonal blocks, everything else MFMA GEMMs, fully pivoted fallback when a pivot
+    # is small | "blocked": fully pivoted, multi-launch | "single": one workgroup per site | "fallback": local, then
+    # always the fallback (tests)
+    lu_method = os.environ.get("TMF_LU", "local")
 
     def _fetch_async(self, tensors):
         """Asynchronous device -> pinned host copies of small result tensors; returns (wait handle, NumPy
@@ -738,7 +741,10 @@ class Engine:
         flags |= (nat.SWEEP_CHECKS if self.checks else 0) | (nat.SWEEP_TIME_KERNELS if self.time_gemm else 0)
         flags |= (nat.SWEEP_RANGE_BCGS if self.range_qr != "house" else 0) | (0 if self.filled_cholqr else nat.SWEEP_NO_CHOLQR)
         flags |= nat.SWEEP_TWO_PASSES if self.filled_passes >= 2 else 0
-        flags |= nat.SWEEP_LU_SINGLE if self.lu_method == "single" else 0
+        if self.lu_method not in ("local", "blocked", "single", "fallback"):
+            raise ValueError(f"lu_method {self.lu_method!r}: expected 'local', 'blocked', 'single' or 'fallback'")
+        flags |= {"single": nat.SWEEP_LU_SINGLE, "blocked": nat.SWEEP_LU_PIVOTED, "fallback": nat.SWEEP_LU_FORCE_FALLBACK}.get(
+            self.lu_method, 0)
         flags |= nat.SWEEP_NARROW_BCGS if self.filled_blocks == 16 else 0
         flags |= nat.SWEEP_ONE_STREAM if self.one_stream else 0
         flags |= nat.SWEEP_DET_DIRECT if self.force_direct_det else (nat.SWEEP_DET_REDUCED if self.det_method != "ppt" else 0)

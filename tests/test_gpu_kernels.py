@@ -299,6 +299,92 @@ def test_lu_blocked_over_launches(eng, cplx):
 
 
 @pytest.mark.parametrize("cplx", [True, False])
+def test_block_local_elimination(eng, cplx):
+    """tmf_diag_inverse_batched + two MFMA GEMM launches per outer step (the sweep's default Schur-complement path): det(A),
+    the Schur complement D - C A^-1 B (slater.py:1077-1090) and the reported statistics, on matrices whose always-block
+    is block-diagonally dominant with arbitrary (pivoting needed) diagonal blocks; a matrix whose diagonal block is
+    singular must report a zero pivot."""
+    setup(eng, cplx)
+    nat = eng.nat
+    rng = np.random.default_rng(21)
+    cases = [(5, 4, 0), (1, 3, 1), (20, 23, 7), (70, 66, 40), (300, 290, 257), (33, 33, 33), (48, 50, 16), (130, 140, 64),
+             (131, 139, 65), (200, 210, 128), (90, 64, 64), (150, 160, 100)]
+    cases.sort(key=lambda c: -c[2])
+    Ws = []
+    for mb, mk, k in cases:
+        W = 0.05 * rnd(rng, (mb, mk), cplx)
+        b0 = 0
+        while b0 < k:                                                  # the kernel's blocks: (k - 1) % 64 + 1 columns, then 64 each
+            b1 = b0 + ((k - 1) % 64 + 1 if b0 == 0 else 64)
+            W[b0:b1, b0:b1] = rnd(rng, (b1 - b0, b1 - b0), cplx)       # no structure inside a block: pivoting is needed there
+            b0 = b1
+        Ws.append(W)
+    singular = cases.index((20, 23, 7))     # second round: its only diagonal block made rank deficient
+    for bad in (False, True):
+        if bad:
+            Ws[singular][:7, :7] = 0.0
+            Ws[singular][:7, :7][0, 0] = 1.0
+        dW = [dev(eng, W) for W in Ws]
+        n = len(cases)
+        ddet = eng._alloc(n)
+        d_inv = eng._alloc(64 * 64 * n)
+        tk = np.array([64 * c[1] for c in cases])
+        d_X = eng._alloc(int(tk.sum()) + 1)
+        d_stats = torch.zeros(2 * n, dtype=torch.float64, device="cuda")   # per matrix: min |pivot|^2, max |D^-1 entry|^2
+        ld = np.zeros(n, nat.diaginv_desc)
+        el = eng.elem
+        ld["W"] = [d[1] for d in dW]
+        ld["det"] = ddet.data_ptr() + np.arange(n) * el
+        ld["inv"] = d_inv.data_ptr() + el * 64 * 64 * np.arange(n)
+        X = d_X.data_ptr() + el * (np.cumsum(tk) - tk)
+        ks = np.array([c[2] for c in cases])
+        ld["mb"], ld["mk"], ld["k"] = [c[0] for c in cases], [c[1] for c in cases], ks
+        ld["ldw"] = ld["mb"]
+        t = eng._up(ld)
+        mb, mk = ld["mb"].astype(np.int64), ld["mk"].astype(np.int64)
+        for step in range(max(-(-int(ks.max()) // 64), 1)):
+            nact = int((ks > 64 * step).sum())
+            nat.check(eng.lib.tmf_diag_inverse_batched(eng.dtype, t.data_ptr(), n if step == 0 else nact, step, d_stats.data_ptr(),
+                                                       eng.stream), "diag_inverse")
+            if nact == 0:
+                break
+            nb0 = (ks[:nact] - 1) % 64 + 1                  # blocks counted from the end: a ragged first one
+            j0 = np.zeros(nact, np.int64) if step == 0 else nb0 + 64 * (step - 1)
+            cend = nb0 if step == 0 else j0 + 64
+            nb, rows2, cols2 = cend - j0, mb[:nact] - cend, mk[:nact] - cend
+            use = (rows2 > 0) & (cols2 > 0)
+            if not use.any():
+                continue
+            u64 = np.uint64
+            A12 = ld["W"][:nact] + ((j0 + cend * mb[:nact]) * el).astype(u64)
+            A21 = ld["W"][:nact] + ((cend + j0 * mb[:nact]) * el).astype(u64)
+            W22 = ld["W"][:nact] + ((cend + cend * mb[:nact]) * el).astype(u64)
+            w64 = np.full(int(use.sum()), 64)
+            eng.gemm(0, 1.0, 0.0, ld["inv"][:nact][use], A12[use], X[:nact][use], nb[use], cols2[use], nb[use], w64, mb[:nact][use], w64)
+            eng.gemm(0, -1.0, 1.0, A21[use], X[:nact][use], W22[use], rows2[use], cols2[use], nb[use], mb[:nact][use], w64, mb[:nact][use])
+        torch.cuda.synchronize()
+        det = ddet.cpu().numpy()
+        stats = np.sqrt(d_stats.cpu().numpy().reshape(n, 2))
+        if bad:
+            assert stats[singular, 0] == 0.0
+            continue
+        assert 1e-3 < stats[ks > 0, 0].min() and stats[ks > 0, 0].max() < 3.0, stats
+        # the inverse statistic only covers blocks with always-rows below them
+        assert np.all(stats[ks <= 64, 1] == 0.0) and 0.0 < stats[ks > 64, 1].min() and stats[:, 1].max() < 100.0, stats
+        for i, ((mb_, mk_, k), W) in enumerate(zip(cases, Ws)):
+            if k:
+                dref = np.linalg.det(W[:k, :k])
+                Sref = W[k:, k:] - W[k:, :k] @ np.linalg.solve(W[:k, :k], W[:k, k:])
+            else:
+                dref, Sref = 1.0, W
+            np.testing.assert_allclose(det[i], dref, rtol=1e-9)
+            if mb_ > k and mk_ > k:
+                Wd = back(dW[i][0], (mb_, mk_))
+                scale = max(1.0, np.abs(Sref).max())
+                np.testing.assert_allclose(Wd[k:, k:], Sref, rtol=0, atol=1e-9 * scale)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
 @pytest.mark.parametrize("n,cls", [(0, 0), (1, 1), (2, 2), (5, 5), (8, 8), (9, 9), (12, 12), (13, 13), (16, 16), (17, 17), (19, 19), (25, 25), (32, 32), (40, 64)])
 def test_det_gather(eng, cplx, n, cls):
     setup(eng, cplx)

@@ -213,6 +213,40 @@ def test_site_sharding_reproduces_unsharded_result_bitwise():
                 assert np.array_equal(part.bonds[b].masks, full.bonds[b].masks)
 
 
+def test_block_local_elimination_against_fully_pivoted_lu():
+    """Default Schur-complement path (row search inside the 64 x 64 diagonal blocks, tmf_diag_inverse_batched) against the
+    fully pivoted blocked LU on a chain whose always-blocks span several diagonal blocks; the forced fallback (statistics
+    read back, gather repeated, fully pivoted LU) must reproduce the pivoted path bit for bit.  The block inverses stay
+    O(1): that is the structure the local search relies on (the filled orbitals of neighbouring cuts pair up)."""
+    from tests_inputs import random_hopping
+    from temfpy_amd.engine import Engine
+    from temfpy_amd.schmidt_utils import to_stopping_condition
+
+    L, chi = 448, 160
+    C, _ = orc.correlation_matrix(random_hopping(L, 2))
+    tr = to_stopping_condition({"chi_max": chi})
+    res = {}
+    for method in ("local", "blocked", "fallback"):
+        eng = Engine("cuda:0")
+        eng.lu_method = method
+        res[method] = eng.run(C, tr, L // 2, L)
+        eng._stage_timings()
+        res[method + "_info"] = (eng.kernel_info.lu_min_pivot, eng.kernel_info.lu_max_inverse, eng.kernel_info.lu_fallbacks)
+    assert max(b.n_filled_left for b in res["local"].bonds) > 64      # always-blocks of several diagonal blocks
+    min_pivot, max_inv, fallbacks = res["local_info"]
+    assert fallbacks == 0 and 0 < max_inv < 10 and min_pivot > 0, res["local_info"]
+    assert res["fallback_info"][2] == 1 and res["blocked_info"][1] == 0.0
+    worst = 0.0
+    for a, b, c in zip(res["local"].sites, res["blocked"].sites, res["fallback"].sites):
+        assert b.det_always == c.det_always
+        worst = max(worst, abs(a.det_always - b.det_always) / abs(b.det_always))
+        for u, v, w in zip(a.blocks, b.blocks, c.blocks):
+            assert u[:5] == v[:5] == w[:5]
+            assert np.array_equal(v[5], w[5])
+            worst = max(worst, np.abs(u[5] - v[5]).max() / max(np.abs(v[5]).max(), 1e-300))
+    assert worst < 1e-11, worst
+
+
 def test_real_dtype_path_matches_complex_path():
     """A real correlation matrix takes the float64 kernels; promoted to complex it must give the
     same Schmidt data and the same state."""

@@ -57,7 +57,11 @@ def main():
     py.sweep_impl, cpp.sweep_impl = "python", "cpp"
     cpp.lu_method = "single"       # the Python orchestration uses the one-workgroup-per-site LU kernel
     cpp.filled_blocks = 16         # ... and 16-column outer blocks in the filled-basis Gram-Schmidt
-    blk = Engine("cuda:0")         # default C++ path: blocked LU over several launches
+    blk = Engine("cuda:0")         # C++ path with the fully pivoted blocked LU over several launches
+    blk.lu_method = "blocked"
+    loc = Engine("cuda:0")         # default: pivoting inside the diagonal blocks
+    fb = Engine("cuda:0")          # ... followed by the forced fallback (must equal the pivoted path bit for bit)
+    fb.lu_method = "fallback"
     cases = [("rand L=16 chi=32", slater.correlation_matrix(random_hopping(16, 0))[0], dict(chi_max=32), {}),
              ("rand L=48 chi=32 oc=7", slater.correlation_matrix(random_hopping(48, 5))[0], dict(chi_max=32), dict(oc=7)),
              ("chain real L=40 chi=64", slater.correlation_matrix(uniform_chain(40) + np.diag(0.3 * np.cos(1.7 * np.arange(40))))[0], dict(chi_max=64), {}),
@@ -97,7 +101,27 @@ def main():
                 for u, v in zip(b.sites[i].blocks, d.sites[i].blocks):
                     assert u[:5] == v[:5]
                     worst = max(worst, np.abs(u[5] - v[5]).max() / max(np.abs(u[5]).max(), 1e-300))
-            print(f"   default C++ path (blocked LU, 64-column Gram-Schmidt blocks) vs the above: max relative block deviation {worst:.2e}", flush=True)
+            print(f"   pivoted blocked LU, 64-column Gram-Schmidt blocks vs the above: max relative block deviation {worst:.2e}", flush=True)
+            e = loc.run(C, tr, oc, L, site_range=kw.get("rng"))
+            loc._stage_timings()
+            minp = loc.kernel_info.lu_min_pivot
+            worst = 0.0
+            for i in range(L):
+                if d.sites[i] is None:
+                    continue
+                worst = max(worst, abs(d.sites[i].det_always - e.sites[i].det_always) / abs(d.sites[i].det_always))
+                for u, v in zip(d.sites[i].blocks, e.sites[i].blocks):
+                    assert u[:5] == v[:5]
+                    worst = max(worst, np.abs(u[5] - v[5]).max() / max(np.abs(u[5]).max(), 1e-300))
+            print(f"   block-local pivoting vs fully pivoted: max relative deviation {worst:.2e}; smallest pivot {minp:.3e}, largest "
+                  f"|D^-1| {loc.kernel_info.lu_max_inverse:.3e}; fallbacks {loc.kernel_info.lu_fallbacks}", flush=True)
+            ok &= worst < 1e-9
+            f = fb.run(C, tr, oc, L, site_range=kw.get("rng"))
+            fb._stage_timings()
+            same = all(d.sites[i] is None or (d.sites[i].det_always == f.sites[i].det_always and all(
+                np.array_equal(u[5], v[5]) for u, v in zip(d.sites[i].blocks, f.sites[i].blocks))) for i in range(L))
+            print(f"   forced fallback vs fully pivoted: {'IDENTICAL' if same else 'DIFFERS'} (fallbacks {fb.kernel_info.lu_fallbacks})", flush=True)
+            ok &= same
         except Exception as exc:  # noqa: BLE001
             import traceback
             traceback.print_exc()
