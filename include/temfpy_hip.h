@@ -194,6 +194,14 @@ typedef struct {
   int32_t mb, mk, k, ldw;
 } tmf_diaginv_desc;          /* 40 bytes */
 int tmf_diag_inverse_batched(int dtype, const tmf_diaginv_desc* d_desc, int nprob, int step, void* d_stats, void* stream);
+/* *d_flag = 1 when any of the nprob matrices has a block-inverse entry above `cap` (or a NaN) or when `force` is set, else 0;
+ * summary[0..2] = smallest |pivot|, largest |D^-1 entry|, flag (device memory or page-locked host memory). */
+int tmf_diag_inverse_verdict(const void* d_stats, int nprob, double cap, int force, int32_t* d_flag, double* summary, void* stream);
+/* Conditional-launch scope of the calling thread: while d_flag != NULL, the kernels launched by tmf_gather_signed_batched,
+ * tmf_lu_block_batched, tmf_lu_trsm_batched and tmf_gemm_batched return at once on the device when *d_flag == 0 (read when
+ * the kernel runs, not when it is enqueued).  The fallback of the block-local elimination is enqueued this way, so the
+ * host never waits for the verdict.  tmf_launch_condition(NULL) ends the scope. */
+void tmf_launch_condition(const int32_t* d_flag);
 
 /* The hot kernel: batched gathered determinants (slater.py:828-869, `_tensor_block`,
  * 90 % of the reference's wall time).  For every tile, for every pair (a, b) of a bra
@@ -288,6 +296,9 @@ int tmf_pf_matrix_batched(const tmf_pf_matrix_desc* d_desc, int nprob, void* str
  * the rank assembling the MPS maps too: every GPU of a node then writes its site shard through
  * its own PCIe link, no collective - slater.py:1301-1346, independent sites).
  * tmf_memcpy_async: to_host = 1 device -> host, 0 host -> device; only enqueues.          */
+/* bytes (a multiple of 4) from device memory into page-locked host memory by a kernel instead of the copy engine: small
+ * results needed by the host in the middle of a conversion do not wait behind a tensor download in flight */
+int tmf_export_words(void* host_mapped_dst, const void* d_src, int64_t bytes, void* stream);
 int tmf_host_register(void* ptr, int64_t bytes);
 int tmf_host_unregister(void* ptr);
 int tmf_memcpy_async(void* dst, const void* src, int64_t bytes, int to_host, void* stream);

@@ -92,7 +92,7 @@ SYMBOLS = [
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_column_norms_batched", "tmf_cut_vectors",
     "tmf_site_prepare", "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_det_tiles_build", "tmf_pf_gather_batched",
     "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched", "tmf_copy_blocks_batched", "tmf_house_qr_batched", "tmf_jacobi_compact_batched", "tmf_house_slab_batched",
-    "tmf_host_register", "tmf_host_unregister", "tmf_memcpy_async", "tmf_lu_block_batched", "tmf_lu_trsm_batched", "tmf_diag_inverse_batched",
+    "tmf_host_register", "tmf_host_unregister", "tmf_memcpy_async", "tmf_lu_block_batched", "tmf_lu_trsm_batched", "tmf_diag_inverse_batched", "tmf_diag_inverse_verdict", "tmf_launch_condition", "tmf_export_words",
     "tmf_ctx_create", "tmf_ctx_destroy", "tmf_sweep_begin", "tmf_sweep_entangled", "tmf_sweep_sites", "tmf_sweep_download",
     "tmf_sweep_query", "tmf_sweep_wait", "tmf_sweep_info_get", "tmf_sweep_stage_name", "tmf_sweep_device_out",
     "tmf_slater_sweep", "tmf_result_dims", "tmf_result_bond", "tmf_result_site", "tmf_result_block", "tmf_result_checks",
@@ -224,6 +224,10 @@ def load():
     lib.tmf_lu_block_batched.argtypes = [i32, vp, i32, i32, i32, i32, vp]
     lib.tmf_lu_trsm_batched.argtypes = [i32, vp, i32, i32, i32, i32, vp]
     lib.tmf_diag_inverse_batched.argtypes = [i32, vp, i32, i32, vp, vp]
+    lib.tmf_diag_inverse_verdict.argtypes = [vp, i32, C.c_double, i32, vp, vp, vp]
+    lib.tmf_launch_condition.argtypes = [vp]
+    lib.tmf_export_words.argtypes = [vp, vp, i64, vp]
+    lib.tmf_launch_condition.restype = None
     lib.tmf_ctx_create.argtypes = [i32, C.POINTER(vp)]
     lib.tmf_ctx_destroy.argtypes = [vp]
     lib.tmf_ctx_destroy.restype = None

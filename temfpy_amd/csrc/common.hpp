@@ -121,5 +121,7 @@ __device__ inline cd shfl_xor_t<cd>(cd v, int mask, int width) {
 // error plumbing (host)
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
+// device flag of the calling thread's conditional-launch scope (tmf_launch_condition), or nullptr
+const int32_t* launch_condition();
 
 }  // namespace tmf

@@ -26,7 +26,9 @@ constexpr int LDT = KT + 1;  // padded k-stride of the LDS tiles (doubles)
 
 template <typename T, int OPA, int TN>
 __global__ __launch_bounds__(256, 3) void gemm_kernel(const tmf_gemm_desc* __restrict__ desc,
-                                                   const int32_t* __restrict__ tiles, double alpha, double beta) {
+                                                   const int32_t* __restrict__ tiles, double alpha, double beta,
+                                                   const int32_t* __restrict__ run_if) {
+  if (run_if != nullptr && *run_if == 0) return;   // conditional-launch scope (tmf_launch_condition)
   constexpr int CP = sc<T>::cplx;
   constexpr int NP = CP ? 2 : 1;               // planes (re, im)
   constexpr int WM = (TN == 64) ? 32 : 16;     // rows of C per wave
@@ -296,11 +298,11 @@ static int launch(int opA, double alpha, double beta, const tmf_gemm_desc* d, co
                   hipStream_t s) {
   dim3 g(nt), b(256);
   if (tile_n == 64) {
-    if (opA) hipLaunchKernelGGL((gemm_kernel<T, 1, 64>), g, b, 0, s, d, t, alpha, beta);
-    else hipLaunchKernelGGL((gemm_kernel<T, 0, 64>), g, b, 0, s, d, t, alpha, beta);
+    if (opA) hipLaunchKernelGGL((gemm_kernel<T, 1, 64>), g, b, 0, s, d, t, alpha, beta, launch_condition());
+    else hipLaunchKernelGGL((gemm_kernel<T, 0, 64>), g, b, 0, s, d, t, alpha, beta, launch_condition());
   } else {
-    if (opA) hipLaunchKernelGGL((gemm_kernel<T, 1, 16>), g, b, 0, s, d, t, alpha, beta);
-    else hipLaunchKernelGGL((gemm_kernel<T, 0, 16>), g, b, 0, s, d, t, alpha, beta);
+    if (opA) hipLaunchKernelGGL((gemm_kernel<T, 1, 16>), g, b, 0, s, d, t, alpha, beta, launch_condition());
+    else hipLaunchKernelGGL((gemm_kernel<T, 0, 16>), g, b, 0, s, d, t, alpha, beta, launch_condition());
   }
   return check_hip(hipGetLastError(), "tmf_gemm_batched launch");
 }

@@ -181,9 +181,10 @@ __global__ __launch_bounds__(256) void lu_schur_kernel(const tmf_schur_desc* __r
 // launch: the trailing matrix is read and written k / 64 times, by every CU.
 // -------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void lu_block_kernel(const tmf_lublock_desc* __restrict__ desc, const int j0, const int WB,
+__global__ __launch_bounds__(256) void lu_block_kernel(const int32_t* __restrict__ run_if, const tmf_lublock_desc* __restrict__ desc, const int j0, const int WB,
                                                        const int NB) {
   extern __shared__ __align__(16) unsigned char smem[];
+  if (run_if != nullptr && *run_if == 0) return;   // conditional-launch scope (tmf_launch_condition)
   const tmf_lublock_desc d = desc[blockIdx.x];
   const int mb = d.mb, k = d.k, ldw = d.ldw;
   T* __restrict__ W = reinterpret_cast<T*>(d.W);
@@ -340,8 +341,9 @@ __global__ __launch_bounds__(256) void lu_block_kernel(const tmf_lublock_desc* _
 // scratch T (nbk x ncols, leading dimension WB): one thread per column, L11 (unit lower) in LDS, 16 rows at a time
 // in registers.  (Composing the interchanges into one permutation with gathered loads measured slower: 207 vs 183 us.)
 template <typename T>
-__global__ __launch_bounds__(256) void lu_trsm_kernel(const tmf_lublock_desc* __restrict__ desc, const int j0, const int WB) {
+__global__ __launch_bounds__(256) void lu_trsm_kernel(const int32_t* __restrict__ run_if, const tmf_lublock_desc* __restrict__ desc, const int j0, const int WB) {
   extern __shared__ __align__(16) unsigned char smem[];
+  if (run_if != nullptr && *run_if == 0) return;
   const tmf_lublock_desc d = desc[blockIdx.x];
   const int k = d.k, ldw = d.ldw;
   if (j0 >= k) return;
@@ -558,6 +560,33 @@ __global__ __launch_bounds__(256) void diag_inverse_kernel(const tmf_diaginv_des
   }
 }
 
+
+// Verdict on the block-local elimination of a whole launch series: *flag = 1 when any block inverse has an entry above
+// cap (or a NaN), or when forced; summary (page-locked host memory mapped into the device, or device memory) receives
+// {smallest |pivot|, largest |D^-1 entry|, flag}.  The fully pivoted kernels that follow run under
+// tmf_launch_condition(flag): the decision stays on the device, the host never waits for it.
+__global__ __launch_bounds__(256) void diag_verdict_kernel(const double* __restrict__ stats, const int n, const double cap2, const int force,
+                                                           int32_t* __restrict__ flag, double* __restrict__ summary) {
+  __shared__ double smin[256], smax[256];
+  double mn = 1e300, mx = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    mn = fmin(mn, stats[2 * i]);
+    const double a = stats[2 * i + 1];
+    mx = (a > mx || a != a) ? a : mx;
+  }
+  smin[threadIdx.x] = mn, smax[threadIdx.x] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 256; ++i) {
+      mn = fmin(mn, smin[i]);
+      mx = (smax[i] > mx || smax[i] != smax[i]) ? smax[i] : mx;
+    }
+    const int f = (force || !(mx <= cap2)) ? 1 : 0;
+    *flag = f;
+    summary[0] = sqrt(mn), summary[1] = sqrt(mx), summary[2] = (double)f;
+  }
+}
+
 }  // namespace tmf
 
 extern "C" int tmf_lu_schur_batched(int dtype, const tmf_schur_desc* d_desc, int nprob, int max_mb, void* stream) {
@@ -620,9 +649,9 @@ extern "C" int tmf_lu_block_batched(int dtype, const tmf_lublock_desc* d_desc, i
     attr_done = true;
   }
   if (dtype == TMF_C128)
-    hipLaunchKernelGGL(lu_block_kernel<cd>, dim3(nprob), dim3(256), lds, s, d_desc, j0, wb, nb);
+    hipLaunchKernelGGL(lu_block_kernel<cd>, dim3(nprob), dim3(256), lds, s, launch_condition(), d_desc, j0, wb, nb);
   else if (dtype == TMF_F64)
-    hipLaunchKernelGGL(lu_block_kernel<double>, dim3(nprob), dim3(256), lds, s, d_desc, j0, wb, nb);
+    hipLaunchKernelGGL(lu_block_kernel<double>, dim3(nprob), dim3(256), lds, s, launch_condition(), d_desc, j0, wb, nb);
   else {
     set_error("tmf_lu_block_batched: bad dtype %d", dtype);
     return TMF_E_ARG;
@@ -648,9 +677,9 @@ extern "C" int tmf_lu_trsm_batched(int dtype, const tmf_lublock_desc* d_desc, in
   }
   const dim3 grid(nprob, (max_cols + 255) / 256);
   if (dtype == TMF_C128)
-    hipLaunchKernelGGL(lu_trsm_kernel<cd>, grid, dim3(256), lds, s, d_desc, j0, wb);
+    hipLaunchKernelGGL(lu_trsm_kernel<cd>, grid, dim3(256), lds, s, launch_condition(), d_desc, j0, wb);
   else if (dtype == TMF_F64)
-    hipLaunchKernelGGL(lu_trsm_kernel<double>, grid, dim3(256), lds, s, d_desc, j0, wb);
+    hipLaunchKernelGGL(lu_trsm_kernel<double>, grid, dim3(256), lds, s, launch_condition(), d_desc, j0, wb);
   else {
     set_error("tmf_lu_trsm_batched: bad dtype %d", dtype);
     return TMF_E_ARG;
@@ -675,4 +704,12 @@ extern "C" int tmf_diag_inverse_batched(int dtype, const tmf_diaginv_desc* d_des
     return TMF_E_ARG;
   }
   return check_hip(hipGetLastError(), "tmf_diag_inverse_batched launch");
+}
+
+extern "C" int tmf_diag_inverse_verdict(const void* d_stats, int nprob, double cap, int force, int32_t* d_flag, double* summary,
+                                        void* stream) {
+  using namespace tmf;
+  hipLaunchKernelGGL(diag_verdict_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), (const double*)d_stats, nprob, cap * cap,
+                     force, d_flag, summary);
+  return check_hip(hipGetLastError(), "tmf_diag_inverse_verdict launch");
 }

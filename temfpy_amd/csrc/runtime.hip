@@ -2,11 +2,15 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace tmf {
 
 static thread_local char g_err[512] = "";
+static thread_local const int32_t* g_run_if = nullptr;
+const int32_t* launch_condition() { return g_run_if; }
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -65,7 +69,8 @@ __global__ __launch_bounds__(256) void fill_normal_kernel(double* __restrict__ o
 
 // ---- signed gather: dst[r,c] = sr[r]*sc[c]*src[row_sel[r], col_sel[c]] -----------------
 template <typename T>
-__global__ __launch_bounds__(256) void gather_kernel(const tmf_gather_desc* __restrict__ desc) {
+__global__ __launch_bounds__(256) void gather_kernel(const tmf_gather_desc* __restrict__ desc, const int32_t* __restrict__ run_if) {
+  if (run_if != nullptr && *run_if == 0) return;
   const tmf_gather_desc d = desc[blockIdx.x];
   const T* __restrict__ src = reinterpret_cast<const T*>(d.src);
   const T* __restrict__ phys = reinterpret_cast<const T*>(d.phys);
@@ -176,6 +181,8 @@ using namespace tmf;
 extern "C" const char* tmf_last_error(void) { return tmf::g_err; }
 extern "C" int tmf_version(void) { return 100; }
 
+extern "C" void tmf_launch_condition(const int32_t* d_flag) { tmf::g_run_if = d_flag; }
+
 extern "C" int tmf_device_count(void) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -216,9 +223,9 @@ extern "C" int tmf_gather_signed_batched(int dtype, const tmf_gather_desc* d_des
   if (nprob <= 0) return TMF_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == TMF_C128)
-    hipLaunchKernelGGL(gather_kernel<cd>, dim3(nprob), dim3(256), 0, s, d_desc);
+    hipLaunchKernelGGL(gather_kernel<cd>, dim3(nprob), dim3(256), 0, s, d_desc, tmf::launch_condition());
   else if (dtype == TMF_F64)
-    hipLaunchKernelGGL(gather_kernel<double>, dim3(nprob), dim3(256), 0, s, d_desc);
+    hipLaunchKernelGGL(gather_kernel<double>, dim3(nprob), dim3(256), 0, s, d_desc, tmf::launch_condition());
   else {
     set_error("tmf_gather_signed_batched: bad dtype %d", dtype);
     return TMF_E_ARG;
@@ -274,6 +281,24 @@ extern "C" int tmf_copy_blocks_batched(int dtype, const tmf_copy_desc* d_desc, i
 // the caller registered (a POSIX shared-memory segment that rank 0 maps as well, so that
 // every GPU of a node writes its shard through its own PCIe link into one host-visible
 // result) or ordinary pinned allocations.
+// Small results into page-locked host memory by a kernel (the buffer is mapped into the device's address space): unlike a
+// DMA copy it does not queue behind the tensor download of the previous conversion on the copy engine.
+__global__ __launch_bounds__(256) void export_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, const int64_t words) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+extern "C" int tmf_export_words(void* host_mapped_dst, const void* d_src, int64_t bytes, void* stream) {
+  if (bytes <= 0) return TMF_OK;
+  if (bytes % 4 != 0) {
+    tmf::set_error("tmf_export_words: %lld bytes is not a multiple of 4", (long long)bytes);
+    return TMF_E_ARG;
+  }
+  const int64_t words = bytes / 4;
+  const int grid = (int)std::min<int64_t>((words + 255) / 256, 256);
+  hipLaunchKernelGGL(export_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), (uint32_t*)host_mapped_dst, (const uint32_t*)d_src, words);
+  return tmf::check_hip(hipGetLastError(), "tmf_export_words");
+}
+
 extern "C" int tmf_host_register(void* ptr, int64_t bytes) {
   if (ptr == nullptr || bytes <= 0) {
     set_error("tmf_host_register: empty range");

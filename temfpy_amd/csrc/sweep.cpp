@@ -202,6 +202,7 @@ struct tmf_ctx {
   std::vector<OutSlot> slots;
   i64 next_ticket = 1;
   PinnedBuf fetch;     // eigenvalues / counts coming down
+  PinnedBuf lu_stats;  // verdict of the block-local elimination, written by the kernel itself: 2 x {min pivot, max inverse, flag}
   PinnedBuf pool_pin;  // index lists going up
   PinnedBuf c_pin;     // C going up
   size_t events_used = 0;
@@ -257,6 +258,8 @@ struct tmf_ctx {
   std::vector<i64> sweep_counts_n;
   double lu_min_pivot = 0.0, lu_max_inverse = 0.0, lu_inverse_cap = 100.0;
   i64 lu_fallbacks = 0;
+  bool conditional = false;      // inside a tmf_launch_condition scope
+  bool lu_pending[2] = {false, false};   // verdict of the sweep on memory set i not yet folded into the numbers above
   // timings
   double stage_ms[N_STAGES] = {0};
   double t_begin = 0;
@@ -266,6 +269,16 @@ struct tmf_ctx {
 
 namespace tmf {
 namespace {
+
+// Summary of the block-local elimination of the sweep that ran on memory set `set` (written by diag_verdict_kernel into
+// page-locked memory; valid once that sweep has finished on the device).
+static void fold_lu_verdict(tmf_ctx& c, int set) {
+  if (!c.lu_pending[set] || c.lu_stats.p == nullptr) return;
+  const double* v = (const double*)c.lu_stats.p + 3 * set;
+  c.lu_min_pivot = v[0], c.lu_max_inverse = v[1];
+  if (v[2] != 0.0) c.lu_fallbacks += 1;
+  c.lu_pending[set] = false;
+}
 
 struct Sweep {
   tmf_ctx& c;
@@ -342,14 +355,15 @@ struct Sweep {
     TMF_TRY(up(g.d.data(), np * sizeof(tmf_gemm_desc), &dd));
     TMF_TRY(up(tiles.data(), tiles.size() * sizeof(Tile), &dt));
     KernelEvent ev{};
-    if (timing()) {
+    const bool timed = timing() && !c.conditional;   // launches of a conditional scope may return at once: not GEMM work
+    if (timed) {
       TMF_TRY(new_event(&ev.e0));
       TMF_TRY(new_event(&ev.e1));
       HIP_TRY(hipEventRecord(ev.e0, c.s_main));
     }
     TMF_TRY(tmf_gemm_batched(c.dtype, opA, alpha, beta, (const tmf_gemm_desc*)dd, (const int32_t*)dt, (int)tiles.size(), tn,
                              c.s_main));
-    if (timing()) {
+    if (timed) {
       HIP_TRY(hipEventRecord(ev.e1, c.s_main));
       double fl = 0;
       for (auto& x : g.d) fl += (double)x.M * x.N * x.K;
@@ -549,6 +563,7 @@ struct Sweep {
     // the other memory set: free once the sweep before the previous one has finished on the GPU
     c.cur ^= 1;
     if (c.set_used[c.cur]) HIP_TRY(hipEventSynchronize(c.set_done[c.cur]));
+    fold_lu_verdict(c, c.cur);
     c.dev_set[c.cur].reset();
     c.stage_set[c.cur].reset();
     c.events_used = 0;
@@ -772,12 +787,14 @@ struct Sweep {
     const size_t b_sig = (size_t)std::max<i64>(tS, 1) * 8, b_cnt = (size_t)ncs * 4;
     TMF_TRY(c.fetch.ensure(2 * b_sig + b_cnt + nsw * 4 + 64));
     char* h = c.fetch.p;
-    HIP_TRY(hipMemcpyAsync(h, d_sig, b_sig, hipMemcpyDeviceToHost, c.s_main));
-    HIP_TRY(hipMemcpyAsync(h + b_sig, d_e, b_sig, hipMemcpyDeviceToHost, c.s_main));
-    HIP_TRY(hipMemcpyAsync(h + 2 * b_sig, d_cnt, b_cnt, hipMemcpyDeviceToHost, c.s_main));
+    // (written by a kernel into the page-locked buffer: a DMA copy here waits for its turn between the 64 MB pieces of the
+    // previous conversion's tensor download, several ms per conversion)
+    TMF_TRY(tmf_export_words(h, (const void*)d_sig, (int64_t)b_sig, c.s_main));
+    TMF_TRY(tmf_export_words(h + b_sig, (const void*)d_e, (int64_t)b_sig, c.s_main));
+    TMF_TRY(tmf_export_words(h + 2 * b_sig, (const void*)d_cnt, (int64_t)b_cnt, c.s_main));
     size_t o = 2 * b_sig + ((b_cnt + 7) & ~(size_t)7);
     for (size_t j = 0; j < c.sweep_counters.size(); ++j) {
-      HIP_TRY(hipMemcpyAsync(h + o, c.sweep_counters[j], (size_t)c.sweep_counts_n[j] * 4, hipMemcpyDeviceToHost, c.s_main));
+      TMF_TRY(tmf_export_words(h + o, c.sweep_counters[j], (int64_t)c.sweep_counts_n[j] * 4, c.s_main));
       o += (size_t)c.sweep_counts_n[j] * 4;
     }
     tick(ST_E, t0);
@@ -1302,10 +1319,11 @@ struct Sweep {
       return TMF_OK;
     };
     // Block-local pivoting: row search inside the 64 x 64 diagonal block only, everything else GEMMs with the explicit
-    // inverse of the block (lu_schur.hip).  The statistics come back with the event ev_lu; lu_verify() falls back to the
-    // fully pivoted method when a block inverse has grown.
-    hipEvent_t ev_lu = nullptr;
-    double* h_minp = nullptr;
+    // inverse of the block (lu_schur.hip).  A one-workgroup kernel turns the per-site statistics into a device flag; the
+    // fully pivoted method is enqueued right behind it under tmf_launch_condition(flag) and returns at once when the
+    // flag is clear.  The host never waits for the verdict (a host synchronisation here serialises the tensor download of
+    // this conversion with the next conversion: 53 instead of 29 ms per step, measured); it reads the summary from
+    // page-locked memory when the memory set is reused or the statistics are asked for.
     auto lu_local = [&]() -> int {
       i64 n_blk = 0, t_tot = 0;
       for (i64 j = 0; j < ns; ++j)
@@ -1325,9 +1343,10 @@ struct Sweep {
         if (ka[j] > 0) io += WB * WB, to += WB * mk[j];
       }
       u64 t_ld;
-      void* t_minp;
+      void *t_minp, *t_flag;
       TMF_TRY(up_vec(ld, &t_ld));
       TMF_TRY(dalloc(2 * ns + 2, 8, &t_minp));
+      TMF_TRY(dalloc(2, 4, &t_flag));
       for (i64 step = 0; step * WB < std::max<i64>(kmax, 1); ++step) {
         i64 nact = 0;
         while (nact < ns && ka[order[nact]] > step * WB) ++nact;   // cdiv(k, 64) blocks whichever end they are counted from
@@ -1345,36 +1364,31 @@ struct Sweep {
         TMF_TRY(gemm(0, 1.0, 0.0, g1));
         TMF_TRY(gemm(0, -1.0, 1.0, g2));
       }
-      TMF_TRY(c.fetch.ensure((size_t)(2 * ns + 2) * 8));
-      h_minp = (double*)c.fetch.p;
-      HIP_TRY(hipMemcpyAsync(h_minp, t_minp, (size_t)ns * 16, hipMemcpyDeviceToHost, c.s_main));
-      TMF_TRY(new_event(&ev_lu));
-      HIP_TRY(hipEventRecord(ev_lu, c.s_main));
-      return TMF_OK;
-    };
-    auto lu_verify = [&]() -> int {   // before the first determinant launch
-      if (!ev_lu) return TMF_OK;
-      HIP_TRY(hipEventSynchronize(ev_lu));
-      ev_lu = nullptr;
-      double m2 = 1e300, g2 = 0.0;
-      bool nan = false;
-      for (i64 r = 0; r < ns; ++r) {
-        m2 = std::min(m2, h_minp[2 * r]);
-        nan = nan || !(h_minp[2 * r + 1] == h_minp[2 * r + 1]);
-        g2 = std::max(g2, h_minp[2 * r + 1]);
-      }
-      c.lu_min_pivot = std::sqrt(m2), c.lu_max_inverse = nan ? INFINITY : std::sqrt(g2);
-      if (getenv("TMF_LU_DEBUG"))
+      // verdict -> device flag + summary in page-locked host memory (written by the kernel: no DMA copy on this stream)
+      TMF_TRY(c.lu_stats.ensure(64));
+      double* summary = (double*)c.lu_stats.p + 3 * c.cur;
+      TMF_TRY(tmf_diag_inverse_verdict(t_minp, (int)ns, c.lu_inverse_cap, (c.par.flags & TMF_SWEEP_LU_FORCE_FALLBACK) ? 1 : 0,
+                                       (int32_t*)t_flag, summary, c.s_main));
+      c.lu_pending[c.cur] = true;
+      if (getenv("TMF_LU_DEBUG")) {   // diagnostic (tools/lu_debug.py): per-site statistics, with a synchronisation
+        std::vector<double> h((size_t)(2 * ns + 2));
+        HIP_TRY(hipMemcpyAsync(h.data(), t_minp, (size_t)ns * 16, hipMemcpyDeviceToHost, c.s_main));
+        HIP_TRY(hipStreamSynchronize(c.s_main));
         for (i64 r = 0; r < ns; ++r)
-          if (h_minp[2 * r] < 1e-4 || !(h_minp[2 * r + 1] < 16.0))
+          if (h[2 * r] < 1e-4 || !(h[2 * r + 1] < 16.0))
             fprintf(stderr, "lu site %lld mode %d: k %lld mb %lld mk %lld nf_b %d nf_k %d min pivot %.3e max |D^-1| %.3e\n",
                     (long long)order[r], (int)c.jobs[order[r]].mode, (long long)ka[order[r]], (long long)mb[order[r]],
-                    (long long)mk[order[r]], (int)c.jobs[order[r]].nf_b, (int)c.jobs[order[r]].nf_k, std::sqrt(h_minp[2 * r]),
-                    std::sqrt(h_minp[2 * r + 1]));
-      if (c.lu_max_inverse <= c.lu_inverse_cap && !(c.par.flags & TMF_SWEEP_LU_FORCE_FALLBACK)) return TMF_OK;
-      c.lu_fallbacks += 1;
-      TMF_TRY(tmf_gather_signed_batched(c.dtype, (const tmf_gather_desc*)t_gd, (int)ns, c.s_main));
-      return lu_pivoted();
+                    (long long)mk[order[r]], (int)c.jobs[order[r]].nf_b, (int)c.jobs[order[r]].nf_k, std::sqrt(h[2 * r]),
+                    std::sqrt(h[2 * r + 1]));
+      }
+      // the fallback: gather again (the elimination has overwritten W), fully pivoted blocked LU - all of it conditional
+      tmf_launch_condition((const int32_t*)t_flag);
+      c.conditional = true;
+      int st = tmf_gather_signed_batched(c.dtype, (const tmf_gather_desc*)t_gd, (int)ns, c.s_main);
+      if (st == TMF_OK) st = lu_pivoted();
+      c.conditional = false;
+      tmf_launch_condition(nullptr);
+      return st;
     };
     if (c.par.flags & TMF_SWEEP_LU_SINGLE) {  // A/B switch: the one-workgroup-per-site kernel
       TMF_TRY(up_vec(sd, &t_sd));
@@ -1412,7 +1426,6 @@ struct Sweep {
                                rest_keys.data(), (i64)rest_keys.size(), &n_rest, &lds_max, &fl3, &npairs);
       rest_keys.resize((size_t)n_rest);
       have_rest_keys = true;
-      TMF_TRY(lu_verify());
       if (nt > 0) {
         u64 t_dd;
         TMF_TRY(up(tiles.data(), (size_t)nt * sizeof(tmf_det_desc), &t_dd));
@@ -1442,7 +1455,6 @@ struct Sweep {
     } else {
       for (i64 key : rest_keys) rs.push_back(Rest{key >> 32, key & 0xFFFFFFFF});
     }
-    TMF_TRY(lu_verify());
     if (!rs.empty()) {
       struct TileX {
         tmf_det_desc d;
@@ -1670,7 +1682,7 @@ extern "C" void tmf_ctx_destroy(tmf_ctx* c) {
     c->dev_set[i].release();
     c->stage_set[i].release();
   }
-  c->fetch.release(), c->pool_pin.release(), c->c_pin.release();
+  c->fetch.release(), c->lu_stats.release(), c->pool_pin.release(), c->c_pin.release();
   if (c->s_main) (void)hipStreamDestroy(c->s_main);
   if (c->s_down) (void)hipStreamDestroy(c->s_down);
   if (c->s_up) (void)hipStreamDestroy(c->s_up);
@@ -1762,6 +1774,11 @@ extern "C" int tmf_sweep_info_get(tmf_ctx* ctx, tmf_sweep_info* o) {
   o->range_width = ctx->P, o->range_iterations = ctx->range_iterations, o->range_floor = ctx->range_floor;
   o->n_fermion = ctx->n_fermion, o->device_bytes = (int64_t)(ctx->dev_set[0].total + ctx->dev_set[1].total);
   o->n_det = ctx->n_det;
+  if (ctx->lu_pending[0] || ctx->lu_pending[1]) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->s_main));
+    fold_lu_verdict(*ctx, 1 - ctx->cur), fold_lu_verdict(*ctx, ctx->cur);   // older sweep first
+  }
   o->lu_min_pivot = ctx->lu_min_pivot, o->lu_max_inverse = ctx->lu_max_inverse, o->lu_fallbacks = ctx->lu_fallbacks;
   const int64_t n_det_all = ctx->n_det;
   (void)n_det_all;
