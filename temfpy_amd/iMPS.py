@@ -411,9 +411,17 @@ def basis_rotation(overlap: BlockMatrix, Schmidt_bra: np.ndarray, Schmidt_ket: n
 
 def MPS_to_iMPS(mps_short, mps_long, sites_per_cell: int, cut: int, unitary_tol: float = _UNITARY_TOL,
                 schmidt_tol: float = _SCHMIDT_TOL, offset: Iterable[int | Literal["auto"]] | int | Literal["auto"] = "auto",
-                unit_cell_width: int | None = None, *, device: str = "cuda:0"):
+                unit_cell_width: int | None = None, *, device: str = "cuda:0", right: str = "rotate"):
     """Constructs an iMPS by comparing two finite MPS that differ by one unit cell (iMPS.py:232-441).
-    Returns (iMPSData, iMPSError)."""
+    Returns (iMPSData, iMPSError).
+
+    right   "rotate" (iMPS.py:403-421): the last tensor is multiplied by the Procrustes rotation D of the right
+            Schmidt-vector overlaps and the right-hand errors are reported.
+            "project" (what ``C_to_iMPS`` does in the reference, slater.py:1508-1518, 1563 / pfaffian.py:2040-2091): the
+            last tensor is expressed in the right Schmidt vectors of the SHORT chain, i.e. multiplied by the overlap
+            matrix itself, and the right-hand errors are reported as zero."""
+    if right not in ("rotate", "project"):
+        raise ValueError(f"`right` must be 'rotate' or 'project', got {right!r}")
     L_short, L_long = mps_short.L, mps_long.L
     if L_short + sites_per_cell != L_long:
         raise ValueError("The given two MPS must differ by one unit cell, got "
@@ -459,8 +467,11 @@ def MPS_to_iMPS(mps_short, mps_long, sites_per_cell: int, cut: int, unitary_tol:
     C, left_unitary, left_schmidt = basis_rotation(C0, S0, cl_.lam[cut], mode="left", unitary_tol=unitary_tol,
                                                    schmidt_tol=schmidt_tol, device=device)
     D0 = _overlap(dev, cs, cut, L_short, cl_, cut + sites_per_cell, L_long, "right")
-    D, right_unitary, right_schmidt = basis_rotation(D0, S0, cl_.lam[cut + sites_per_cell], mode="right",
-                                                     unitary_tol=unitary_tol, schmidt_tol=schmidt_tol, device=device)
+    if right == "rotate":
+        D, right_unitary, right_schmidt = basis_rotation(D0, S0, cl_.lam[cut + sites_per_cell], mode="right",
+                                                         unitary_tol=unitary_tol, schmidt_tol=schmidt_tol, device=device)
+    else:
+        D, right_unitary, right_schmidt = D0, 0.0, 0.0
     # unit cell in right canonical form, gauge unitaries on the first and last tensor (iMPS.py:415-421)
     cell = [cl_.to_form(cut + i, "B") for i in range(sites_per_cell)]
     dq = int(cl_.f.charges[L_long][0]) - int(cs.f.charges[L_short][0])

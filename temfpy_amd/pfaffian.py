@@ -196,12 +196,12 @@ def C_to_iMPS(C_short: np.ndarray, C_long: np.ndarray, trunc_par: dict | Stoppin
               cut: int, *, basis: str, diag_tol: float = _DIAG_TOL, unitary_tol: float = 1e-6,
               schmidt_tol: float = 1e-6, unit_cell_width: int | None = None, device: str = "cuda:0"):
     """iMPS representation of a Nambu mean-field state from the correlation matrices of two chains that differ by
-    one unit cell (pfaffian.py:1924-2091): same arguments, defaults and exceptions.  As in
-    ``temfpy_amd.slater.C_to_iMPS`` the method differs from the reference's, stated rather than hidden: both
-    chains are converted in full with their orthogonality centre at ``cut`` and the unit cell is gauge fixed by
-    :func:`temfpy_amd.iMPS.MPS_to_iMPS` (transfer-matrix overlaps, Procrustes rotations on both sides), whereas
-    the reference uses its Pfaffian overlap formulas without environment tensors and reports zero right-hand
-    errors."""
+    one unit cell (pfaffian.py:1924-2091): same arguments, defaults and exceptions.  As in the reference the last
+    tensor of the unit cell is expressed in the right Schmidt vectors of the SHORT chain (pfaffian.py:2039-2056) and no
+    right-hand errors are reported (pfaffian.py:2090).  Difference in method, stated rather than hidden (as in
+    ``temfpy_amd.slater.C_to_iMPS``): both chains are converted in full with their orthogonality centre at ``cut`` and the
+    Schmidt-vector overlaps come from the transfer matrices of the two MPS (:func:`temfpy_amd.iMPS.MPS_to_iMPS` with
+    ``right="project"``), whereas the reference uses its Pfaffian overlap formulas without environment tensors."""
     from . import iMPS
 
     trunc_par = to_stopping_condition(trunc_par)
@@ -215,7 +215,7 @@ def C_to_iMPS(C_short: np.ndarray, C_long: np.ndarray, trunc_par: dict | Stoppin
     mps_s = C_to_MPS(C_short, trunc_par, basis=basis, diag_tol=diag_tol, ortho_center=cut, device=device, as_tenpy=False)
     mps_l = C_to_MPS(C_long, trunc_par, basis=basis, diag_tol=diag_tol, ortho_center=cut, device=device, as_tenpy=False)
     res, err = iMPS.MPS_to_iMPS(mps_s, mps_l, sites_per_cell, cut, unitary_tol=unitary_tol, schmidt_tol=schmidt_tol,
-                                offset=0, unit_cell_width=sites_per_cell, device=device)
+                                offset=0, unit_cell_width=sites_per_cell, device=device, right="project")
     res.unit_cell_width = unit_cell_width
     return res, err
 

@@ -156,13 +156,14 @@ def C_to_iMPS(
     """iMPS representation of a Slater determinant from the correlation matrices of two chains that differ by
     one unit cell (slater.py:1356-1565): same arguments, defaults, offset rules and exceptions.
 
-    Difference in method, stated rather than hidden: the reference never builds the environment tensors (it
-    gets the Schmidt-vector overlaps from determinant formulas, slater.py:1443-1446) and therefore reports zero
-    right-hand errors; here both chains are converted in full (40 ms each at L = 1024) with their orthogonality
-    centre at ``cut`` and the unit cell is gauge fixed by :func:`temfpy_amd.iMPS.MPS_to_iMPS`, i.e. the overlaps
-    come from transfer matrices and the last tensor is rotated with the Procrustes matrix D instead of being
-    projected on the short chain's right Schmidt vectors.  Both describe the same state up to the reported
-    errors (acceptance check of src/examples/iMPS.py:27-38 in tests/test_gpu_imps.py)."""
+    As in the reference the last tensor of the unit cell is expressed in the right Schmidt vectors of the SHORT chain
+    (slater.py:1508-1518) and no right-hand errors are reported (slater.py:1563); the first tensor carries the Procrustes
+    rotation of the left Schmidt-vector overlaps (slater.py:1538-1553).  Difference in method, stated rather than hidden:
+    the reference gets those overlaps from determinant formulas without environment tensors (slater.py:1443-1446,
+    1023-1024); here both chains are converted in full (30 ms each at L = 1024) with their orthogonality centre at ``cut``
+    and the overlaps come from the transfer matrices of the two MPS (:func:`temfpy_amd.iMPS.MPS_to_iMPS` with
+    ``right="project"``), i.e. they are overlaps of the truncated Schmidt vectors.  Same state up to the truncation
+    (acceptance check of src/examples/iMPS.py:27-38 in tests/test_gpu_imps.py)."""
     from . import iMPS
 
     trunc_par = to_stopping_condition(trunc_par)
@@ -193,7 +194,7 @@ def C_to_iMPS(
                      as_tenpy=False)
     res, err = iMPS.MPS_to_iMPS(mps_s, mps_l, mult * sites_per_cell, mult * cut, unitary_tol=unitary_tol,
                                 schmidt_tol=schmidt_tol, offset=offset, unit_cell_width=mult * sites_per_cell,
-                                device=device)
+                                device=device, right="project")
     res.unit_cell_width = unit_cell_width
     return res, err
 

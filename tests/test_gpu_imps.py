@@ -110,6 +110,7 @@ def test_H_to_iMPS(spinful):
         res, err = slater.H_to_iMPS(ssh(L), ssh(L + 2), {"chi_max": chi}, 2, cut, spinful=spinful)
         mult = 1 if spinful is None else 2
         assert res.L == 2 * mult and res.unit_cell_width == 2 and err.total_error < 1e-3
+        assert err.right_unitary == 0.0 and err.right_schmidt == 0.0     # slater.py:1563
         expect = {None: 6, "simple": 12, "PH": 12}[spinful]          # particles left of the cut at half filling
         q0 = res.charges[0] + expect
         Cs, _ = slater.correlation_matrix(ssh(L))
@@ -161,9 +162,18 @@ def test_pfaffian_H_to_iMPS():
     Ts, ls, fs = sorted_dense(ms)
     Tl, ll, fl = sorted_dense(ml)
     B, S, eo = io.mps_to_imps(Ts, ls, fs, Tl, ll, fl, 1, cut)
-    np.testing.assert_allclose(list(err), eo, rtol=0, atol=1e-9)
-    for t, r, sl in zip(res.dense_tensors(), B, S[:-1]):
+    # C_to_iMPS reports the left-hand errors only (pfaffian.py:2090); the unit cell with both rotations is MPS_to_iMPS
+    np.testing.assert_allclose(list(err)[:2], eo[:2], rtol=0, atol=1e-9)
+    assert err.right_unitary == 0.0 and err.right_schmidt == 0.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rot, err_rot = iMPS.MPS_to_iMPS(ms, ml, 1, cut, offset=0)
+    np.testing.assert_allclose(list(err_rot), eo, rtol=0, atol=1e-9)
+    for t, r, sl in zip(rot.dense_tensors(), B, S[:-1]):
         assert (sl[None, :, None] * np.abs(t - r)).max() < 1e-9
+    # projected on the short chain's right Schmidt vectors instead of rotated: the same tensor up to the reported errors
+    for t, r, sl in zip(res.dense_tensors(), B, S[:-1]):
+        assert (sl[None, :, None] * np.abs(t - r)).max() < 10 * max(err_rot.total_error, 1e-9)
     Tr, lr, fr = io.insert_cells(Ts, ls, fs, res.dense_tensors(), res.lam, cut, n_cell)
     Tv, lv, fv = sorted_dense(mv)
     ov = io.overlap(Tv, lv, fv, Tr, lr, fr)
