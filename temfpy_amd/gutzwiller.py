@@ -12,25 +12,26 @@ Everything numerical runs on the GPU through the C ABI (``include/temfpy_hip.h``
   the charge blocks of both fermion tensors are regrouped by ``tmf_copy_blocks_batched`` and multiplied by ONE
   batched MFMA launch (``tmf_gemm_batched``) over all pairs, physical states and charge sectors;
 * canonical form (TeNPy ``MPS.canonical_form_finite(cutoff=...)``, called at gutzwiller.py:266 / :471).
-  ``method="sequential"`` (default) is TeNPy's algorithm: a sweep to the right with one QR per charge block
-  (``tmf_house_qr_batched``, Householder: the projected tensors are exactly rank deficient, where Gram-Schmidt
-  needs a rank decision and Householder does not), then a sweep back with one SVD per site, N = A X of shape
-  chi_l x (2 chi_r) per charge block: QR of N^H, a second QR of the small factor R^H as preconditioner, one-sided
-  Jacobi WITHOUT accumulator on R3^H (``tmf_jacobi_compact_batched``: its normalised columns are the right
-  singular vectors V3 of R3), B = (Q V3)^H, U S = N (Q V3) pushed to the left.  The result is exactly
-  right-canonical after truncation, like TeNPy's.
-  ``method="parallel"`` removes the SVDs from the sequential part: two QR-only sweeps that do not depend on each
-  other run concurrently on two HIP streams (rightwards ``R_j T_j = A_j R_{j+1}``, leftwards
-  ``T_j L_{j+1} = L_j B_j``), the centre matrix of every bond is ``C_j = R_j L_j / norm``, the SVDs of ALL bonds
-  and charge sectors are ONE Jacobi launch (~2500 workgroups instead of <= 5 at a time) and the Schmidt gauge
-  ``B_j <- V_j^H B_j V_{j+1}`` two batched MFMA launches (3x faster at L = 512, chi = 512).  Same state and
-  Schmidt values; but rows of B that belong to Schmidt values within a few decades of ``cutoff`` are then
-  isometric only up to (cutoff / s)^2, because every bond is truncated independently (exact for cutoff -> 0).
+  ``method="parallel"`` (default): two QR-only sweeps that do not depend on each other run concurrently on two HIP
+  streams (rightwards ``R_j T_j = A_j R_{j+1}``, leftwards ``T_j L_{j+1} = L_j B_j``; ``tmf_house_slab_batched``,
+  Householder: the projected tensors are exactly rank deficient, where Gram-Schmidt needs a rank decision and
+  Householder does not), the centre matrix of every bond is ``C_j = R_j L_j / norm``, the SVDs of ALL bonds and charge
+  sectors are ONE Jacobi launch (~2500 workgroups instead of <= 5 at a time), the Schmidt gauge
+  ``B_j <- V_j^H B_j V_{j+1}`` two batched MFMA launches, and one batched Gram-Schmidt pass over the kept rows of
+  every ``B_j`` makes the tensors exactly right-isometric again (every bond is truncated on its own, which costs a row
+  with Schmidt value s up to (cutoff / s)^2 of its norm; the correction moves the state by less than the truncation).
+  ``method="sequential"`` is TeNPy's algorithm step by step: a sweep to the right with one QR per charge block, then a
+  sweep back with one SVD per site, N = A X of shape chi_l x (2 chi_r) per charge block: QR of N^H, a second QR of the
+  small factor R^H as preconditioner, one-sided Jacobi WITHOUT accumulator on R3^H
+  (``tmf_jacobi_compact_batched``: its normalised columns are the right singular vectors V3 of R3), B = (Q V3)^H,
+  U S = N (Q V3) pushed to the left.  Same state, norm and Schmidt values (1e-12), 3.4x slower at L = 512, chi = 512:
+  every step waits for the previous one and occupies <= 5 of 256 CUs.
   In both methods Schmidt values below ``cutoff`` are zeroed on the device (shapes stay fixed: all descriptors
   are built once, no host round trip inside a sweep) and compacted on the host.
 
-Only finite MPS exist in this package (``C_to_iMPS`` is not built), so the reference's infinite-MPS branches
-(``q_left`` / ``offset`` / ``parity``) reduce to the warnings the reference emits for finite input.
+Finite MPS only: for the infinite-MPS input the reference also accepts (``canonical_form_infinite1``, gutzwiller.py:467-478)
+the entry points raise NotImplementedError; its ``q_left`` / ``offset`` / ``parity`` arguments reduce to the warnings the
+reference emits for finite input.
 """
 from __future__ import annotations
 
@@ -249,8 +250,14 @@ def infer_parities(T, tol=1e-9):
 def _as_fermions(mps):
     from .mps_data import MPSData
 
+    from .iMPS import iMPSData
+
     if isinstance(mps, _Fermions):
         return mps
+    if isinstance(mps, iMPSData):
+        raise NotImplementedError("Gutzwiller projection of an infinite MPS (gutzwiller.py:467-478, TeNPy "
+                                  "canonical_form_infinite1) is not built; project the finite MPS of the two chains "
+                                  "and convert with iMPS.MPS_to_iMPS instead")
     if isinstance(mps, MPSData):
         return _fermions_from_slater(mps)
     if hasattr(mps, "bonds") and hasattr(mps.bonds[0], "parity"):      # PfMPSData
@@ -320,7 +327,7 @@ def _gemm_tiles(d):
 class _Projector:
     """Builds and runs the device pipeline for one projection (see the module docstring)."""
 
-    def __init__(self, fer, pairs, keep_fn, cutoff, device, method="sequential"):
+    def __init__(self, fer, pairs, keep_fn, cutoff, device, method="parallel"):
         import torch
 
         if not torch.cuda.is_available():
@@ -732,6 +739,22 @@ class _Projector:
             gemm(tail[2], s1, opA=1)
             torch.cuda.synchronize(self.device)
             nat.check_jacobi_sweeps(d_sw.cpu().numpy(), "Jacobi SVD of the bond matrices (npc.svd in canonical_form_finite)")
+            # Every bond was truncated on its own, so a row of B_j whose Schmidt value s sits within a few decades of the
+            # cutoff has lost (cutoff / s)^2 of its norm to dropped columns.  One batched Gram-Schmidt pass (Cholesky-QR
+            # twice: the Gram matrices are close to 1) over the kept columns of every B_j^H restores the isometry exactly;
+            # its triangular factor has a positive diagonal, so the basis of bond j moves by <= (cutoff / s)^2 per index
+            # and the state by less than the truncation itself (no compensation in B_{j-1}).
+            h_cnt0 = d_cnt.cpu().numpy()
+            ob, orows, ocend = [], [], []
+            for j in range(Ls):
+                for c, v in Winfo[j].items():
+                    k = int(h_cnt0[cnt_index[(j, c)]])
+                    if k > 0:
+                        ob.append(P(Bho[j][c]))
+                        orows.append(v[1])
+                        ocend.append(k)
+            self._orthonormalise_columns(ob, orows, ocend, s1, keep_alive)
+            torch.cuda.synchronize(self.device)
             self.timings["svd+gauge"] = time.perf_counter() - t3
         # ================= results =================
         t4 = time.perf_counter()
@@ -782,6 +805,34 @@ class _Projector:
         mt = int((_cdiv(recs["rows"].astype(np.int64), 32) * _cdiv(recs["cols"].astype(np.int64), 32)).max())
         nat.check(self.lib.tmf_copy_blocks_batched(self.dt, t.data_ptr(), len(recs), mt, stream), "tmf_copy_blocks_batched")
 
+    def _orthonormalise_columns(self, base, rows, c_end, stream, keep):
+        """Columns [0, c_end) of every matrix base[i] (rows[i] x c_end[i], leading dimension rows[i]) orthonormalised in
+        column order by tmf_bcgs_batched (two passes, Cholesky-QR panels: positive diagonal of the triangular factor)."""
+        base, rows, c_end = (np.asarray(x, np.int64) for x in (base, rows, c_end))
+        if base.size == 0:
+            return
+        order = np.argsort(-rows, kind="stable")
+        base, rows, c_end = base[order], rows[order], c_end[order]
+        torch = self.torch
+        noff = np.concatenate(([0], np.cumsum(c_end)))[:-1]
+        d_nrm = torch.zeros(int(c_end.sum()) + 1, dtype=torch.float64, device=self.device)
+        soff = np.concatenate(([0], np.cumsum(c_end * 16)))[:-1]
+        d_scr = torch.zeros(int((c_end * 16).sum()) + 2, dtype=torch.complex128 if self.cplx else torch.float64, device=self.device)
+        nd = np.zeros(base.size, nat.norms_desc)
+        nd["src"], nd["out"] = base, d_nrm.data_ptr() + 8 * noff
+        nd["n"], nd["c"], nd["lds_"] = rows, c_end, rows
+        t_nd = torch.from_numpy(nd.view(np.uint8).reshape(-1).copy()).to(self.device)
+        nat.check(self.lib.tmf_column_norms_batched(self.dt, t_nd.data_ptr(), base.size, stream), "tmf_column_norms_batched")
+        bd = np.zeros(base.size, nat.bcgs_desc)
+        bd["base"], bd["scratch"], bd["norms"] = base, d_scr.data_ptr() + self.elem * soff, nd["out"]
+        bd["rows"], bd["ld"], bd["c_begin"], bd["c_end"] = rows, rows, 0, c_end
+        t_bd = torch.from_numpy(bd.view(np.uint8).reshape(-1).copy()).to(self.device)
+        wb = int(self.lib.tmf_bcgs_work_bytes(nat._p(bd), base.size))
+        d_work = torch.empty(max(wb, 16), dtype=torch.uint8, device=self.device)
+        keep += [d_nrm, d_scr, t_nd, t_bd, d_work]
+        nat.check(self.lib.tmf_bcgs_batched(self.dt, t_bd.data_ptr(), nat._p(bd), base.size, 2, 1, d_work.data_ptr(), wb, stream),
+                  "tmf_bcgs_batched")
+
     def _gemm_now(self, items, opA, stream, keep):
         if not items:
             return
@@ -826,7 +877,7 @@ def _total_charge(fer):
 
 def abrikosov(mps, *, inplace: bool = False, return_canonical: bool = True, cutoff: float = 1e-12,
               q_left: None | int = None, unit_cell_width: int | None = None, device: str = "cuda:0",
-              method: Literal["sequential", "parallel"] = "sequential"):
+              method: Literal["sequential", "parallel"] = "parallel"):
     """Projection from Abrikosov fermions to a spin-1/2 Hilbert space (gutzwiller.py:95-281): sites 2i, 2i+1
     hold f_up, f_down; single occupation of f_up -> up, of f_down -> down, empty and double occupation dropped.
     No charges survive."""
@@ -857,7 +908,7 @@ def abrikosov(mps, *, inplace: bool = False, return_canonical: bool = True, cuto
 
 def abrikosov_ph(mps, *, inplace: bool = False, return_canonical: bool = True, cutoff: float = 1e-12, offset: int = 0,
                  parity: Literal[0, 1] = 0, unit_cell_width: int | None = None, device: str = "cuda:0",
-                 method: Literal["sequential", "parallel"] = "sequential"):
+                 method: Literal["sequential", "parallel"] = "parallel"):
     """Projection from particle-hole rotated Abrikosov fermions (gutzwiller.py:284-486): sites 2i, 2i+1 hold
     f_up, f_down^dagger; zero occupation -> down, double occupation -> up, single occupation dropped.
     Number-conserving input keeps S^z (2 S^z = number - bond index, :333, :438-441)."""

@@ -171,17 +171,18 @@ def test_exactly_symmetric_chain_rank_deficient_blocks():
 
 @pytest.mark.parametrize("L,perturb", [(16, 0.3), (32, 0.1), (48, 0.0)])
 def test_parallel_method(L, perturb):
-    """method="parallel" (QR-only sweeps on two streams, all SVDs in one launch): same state, norm and Schmidt
-    values as the sequential algorithm / the oracle; isometry exact up to (cutoff / s)^2 per Schmidt index, and to
-    1e-10 outright when the cutoff sits below every Schmidt value that is kept."""
+    """method="parallel" (default: QR-only sweeps on two streams, all SVDs in one launch, one batched Gram-Schmidt pass
+    over the kept rows) against method="sequential" (TeNPy's algorithm step by step) and the oracle: same state, norm
+    and Schmidt values, tensors right-isometric to 1e-10 in both."""
     from temfpy_amd import gutzwiller
 
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         mps = hip_mps(uniform_chain(L) + perturb * np.diag(np.sin(np.arange(float(L)))), 128, "PH")
     res = gutzwiller.abrikosov_ph(mps, method="parallel")
-    check(res, *oracle_inputs(mps), "ph", isometry=None)
-    seq = gutzwiller.abrikosov_ph(mps)
+    check(res, *oracle_inputs(mps), "ph")
+    seq = gutzwiller.abrikosov_ph(mps, method="sequential")
+    check(seq, *oracle_inputs(mps), "ph")
     assert abs(res.norm / seq.norm - 1) < 1e-12
     for a, b in zip(res.lam, seq.lam):
         a, b = np.sort(a)[::-1], np.sort(b)[::-1]

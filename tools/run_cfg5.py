@@ -19,7 +19,7 @@ ap.add_argument("--L", type=int, default=512)
 ap.add_argument("--chi", type=int, default=512)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--checks", action="store_true")
-ap.add_argument("--method", default="sequential")
+ap.add_argument("--method", default="parallel")
 ap.add_argument("--cpu-sample", type=int, default=0,
                 help="also time the CPU oracle (charge-block restatement of TeNPy's canonical_form_finite) on a chain of "
                      "this many fermion sites per species at the same chi_max: the per-site cost is size independent once chi saturates")
