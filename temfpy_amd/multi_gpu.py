@@ -247,9 +247,10 @@ class ShardGroup:
         self.last_busy_ms = None
         self._c_pin = None
 
-    def convert_local(self, C, trunc, ortho_center=None, unit_cell_width=None):
-        """Steps every rank takes: shape + C from rank 0, this rank's site range into its segment.  Returns
-        (generation, bytes, busy ms, checks)."""
+    def convert_begin(self, C, trunc, ortho_center=None, unit_cell_width=None, wait=False):
+        """Steps every rank takes: shape + C from rank 0, this rank's site range enqueued with its tensors on their way
+        into the rank's segment by asynchronous DMA.  Returns a handle for :meth:`convert_end`.  Between the two calls the
+        caller may begin the next conversion: its kernels overlap this one's download (as on one GPU)."""
         torch, dist = self.torch, self.dist
         t0 = time.perf_counter()
         hdr = torch.zeros(4, dtype=torch.int64)
@@ -281,18 +282,23 @@ class ShardGroup:
                 dist.broadcast(torch.view_as_real(h_C) if cplx else h_C, 0)
             mat = h_C.numpy().reshape(L, L)
         rng = shard_sites(L, oc, self.world)[self.rank]
-        mps = self.eng.run(mat, trunc, oc, ucw, threads=self.host_threads, download=True, site_range=rng, sink=self.sink)
+        mps = self.eng.run(mat, trunc, oc, ucw, threads=self.host_threads, download=True if wait else "async", site_range=rng,
+                           sink=self.sink)
         seg = self.sink.last
-        seg.lease = 1
-        self.last_local = mps
-        busy = (time.perf_counter() - t0) * 1e3
-        return seg.gen, seg.size, busy, dict(getattr(mps, "info", {}).get("checks", {}))
+        seg.lease = 1                      # taken: the next conversion gets another segment
+        return dict(mps=mps, seg=seg, L=L, oc=oc, ucw=ucw, busy=(time.perf_counter() - t0) * 1e3, keep=mat)
 
-    def convert(self, C, trunc, ortho_center=None, unit_cell_width=None):
-        """Launcher mode: the assembled ``MPSData`` on rank 0, ``None`` elsewhere."""
+    def convert_end(self, h):
+        """Waits for the tensors of the conversion begun with handle ``h`` and assembles: the ``MPSData`` on rank 0,
+        ``None`` elsewhere."""
         torch, dist = self.torch, self.dist
-        gen, size, busy, checks = self.convert_local(C, trunc, ortho_center, unit_cell_width)
-        mine = torch.tensor([float(gen), float(size), busy], dtype=torch.float64)
+        t0 = time.perf_counter()
+        mps_l, seg = h["mps"], h["seg"]
+        if hasattr(mps_l, "wait"):
+            mps_l.wait()
+        busy = h["busy"] + (time.perf_counter() - t0) * 1e3
+        self.last_local = mps_l
+        mine = torch.tensor([float(seg.gen), float(seg.size), busy], dtype=torch.float64)
         infos = [torch.zeros(3, dtype=torch.float64) for _ in range(self.world)]
         if self.world > 1:
             dist.all_gather(infos, mine, group=self.ctl)     # also orders "segment written" before "segment read"
@@ -301,11 +307,19 @@ class ShardGroup:
         self.last_busy_ms = [float(t[2]) for t in infos]
         if self.rank != 0:
             return None                    # the segment stays leased until rank 0 drops the assembled object
-        L = int(self.last_local.L)
-        mps = assemble(self.reader, [t.tolist() for t in infos], ortho_center or L // 2, unit_cell_width or L,
-                       {"busy_ms_per_rank": self.last_busy_ms})
-        mps.info = dict(getattr(self.last_local, "info", {}))
+        mps = assemble(self.reader, [t.tolist() for t in infos], h["oc"], h["ucw"], {"busy_ms_per_rank": self.last_busy_ms})
+        mps.info = dict(getattr(mps_l, "info", {}))
         return mps
+
+    def convert_local(self, C, trunc, ortho_center=None, unit_cell_width=None):
+        """One conversion of this rank's site range, tensors landed.  Returns (generation, bytes, busy ms, checks)."""
+        h = self.convert_begin(C, trunc, ortho_center, unit_cell_width, wait=True)
+        self.last_local = h["mps"]
+        return h["seg"].gen, h["seg"].size, h["busy"], dict(getattr(h["mps"], "info", {}).get("checks", {}))
+
+    def convert(self, C, trunc, ortho_center=None, unit_cell_width=None):
+        """Launcher mode: the assembled ``MPSData`` on rank 0, ``None`` elsewhere."""
+        return self.convert_end(self.convert_begin(C, trunc, ortho_center, unit_cell_width, wait=True))
 
 
 def init_rank(local=None, gloo=False, dry=False):

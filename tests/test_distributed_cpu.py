@@ -35,6 +35,19 @@ def test_bench_gpus_flag_starts_its_own_ranks():
     assert out["config"]["backend"] == "gloo"
 
 
+def test_bench_under_torch_distributed_run():
+    """The driver's launch: `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` (ranks from the
+    environment, no self-spawn): one JSON line from rank 0, n_gpus = 2."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--L", "24", "--chi", "8",
+                        "--steps", "2", "--warmup", "1", "--cpu-sample", "0"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 2 and out["value"] > 0
+
+
 def test_bench_rank_failure_is_reported():
     """A rank that dies makes the launcher exit non-zero instead of printing a number."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--L", "1", "--chi", "8",
