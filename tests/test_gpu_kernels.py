@@ -1035,6 +1035,55 @@ def test_house_slab_qr(eng, cplx):
         np.testing.assert_allclose(Q @ (Q.conj().T @ A), A, rtol=0, atol=1e-13 * scale * n ** 0.5)   # span(Q) contains A
 
 
+def test_export_words_verdict_and_conditional_launches(eng):
+    """Plumbing of the block-local elimination: tmf_export_words (device -> page-locked host memory by a kernel),
+    tmf_diag_inverse_verdict (statistics -> device flag + summary in host memory) and tmf_launch_condition (GEMM / gather /
+    pivoted-LU launches that return at once while the device flag is clear)."""
+    import ctypes
+
+    setup(eng, True)
+    nat, lib = eng.nat, eng.lib
+    # export
+    src = torch.arange(1000, dtype=torch.float64, device="cuda") * 0.5
+    dst = torch.zeros(1000, dtype=torch.float64).pin_memory()
+    nat.check(lib.tmf_export_words(dst.data_ptr(), src.data_ptr(), 8000, eng.stream), "export")
+    torch.cuda.synchronize()
+    assert np.array_equal(dst.numpy(), np.arange(1000) * 0.5)
+    assert lib.tmf_export_words(dst.data_ptr(), src.data_ptr(), 7, eng.stream) != 0       # not a multiple of 4
+    # verdict: (min pivot^2, max inverse^2) per matrix
+    stats = np.array([[0.25, 4.0], [1e-6, 9.0], [1.0, 0.0]])
+    d_stats = torch.from_numpy(stats.reshape(-1)).cuda()
+    d_flag = torch.full((1,), 7, dtype=torch.int32, device="cuda")
+    summary = torch.zeros(3, dtype=torch.float64).pin_memory()
+    for cap, force, want in ((10.0, 0, 0), (2.5, 0, 1), (10.0, 1, 1)):
+        nat.check(lib.tmf_diag_inverse_verdict(d_stats.data_ptr(), 3, cap, force, d_flag.data_ptr(), summary.data_ptr(), eng.stream), "verdict")
+        torch.cuda.synchronize()
+        assert int(d_flag.item()) == want
+        np.testing.assert_allclose(summary.numpy(), [1e-3, 3.0, want])
+    d_stats[3] = float("nan")
+    nat.check(lib.tmf_diag_inverse_verdict(d_stats.data_ptr(), 3, 10.0, 0, d_flag.data_ptr(), summary.data_ptr(), eng.stream), "verdict")
+    torch.cuda.synchronize()
+    assert int(d_flag.item()) == 1                                                         # a NaN always triggers the fallback
+    # conditional scope around a GEMM: C stays untouched while the flag is 0, is computed when it is 1
+    rng = np.random.default_rng(5)
+    A, B = rnd(rng, (40, 30), True), rnd(rng, (30, 20), True)
+    dA, dB = dev(eng, A), dev(eng, B)
+    dC = eng._alloc(40 * 20, zero=True)
+    for flag in (0, 1):
+        d_flag.fill_(flag)
+        lib.tmf_launch_condition(d_flag.data_ptr())
+        try:
+            eng.gemm(0, 1.0, 0.0, [dA[1]], [dB[1]], [dC.data_ptr()], [40], [20], [30], [40], [30], [40])
+        finally:
+            lib.tmf_launch_condition(None)
+        torch.cuda.synchronize()
+        got = back(dC, (40, 20))
+        np.testing.assert_allclose(got, A @ B if flag else np.zeros((40, 20)), atol=1e-12)
+    eng.gemm(0, 2.0, 0.0, [dA[1]], [dB[1]], [dC.data_ptr()], [40], [20], [30], [40], [30], [40])   # scope ended: runs
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(back(dC, (40, 20)), 2 * (A @ B), atol=1e-12)
+
+
 def test_single_call_sweep_entry_point_and_accessors():
     """tmf_slater_sweep (the one-call form of the staged sweep ABI, include/temfpy_hip.h "Sweep level") through ctypes,
     read back with the tmf_result_* accessors, against the Python entry point that drives the staged calls."""
