@@ -118,6 +118,87 @@ __device__ inline cd shfl_xor_t<cd>(cd v, int mask, int width) {
   return make_cd(__shfl_xor(v.x, mask, width), __shfl_xor(v.y, mask, width));
 }
 
+// ---- full-wave reductions on the DPP path (VALU cross-lane moves; __shfl_xor goes through the LDS crossbar:
+// ds_bpermute_b32, ~60 cycles of latency per 32-bit word and step, 6 dependent steps per reduction) -----------------
+template <int CTRL>
+__device__ inline double dpp_mov_keep(double v) {       // lanes without a source keep their own value
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ inline double dpp_mov_zero(double v) {       // lanes without a source read 0
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double readlane_d(double v, int l) {   // l wave-uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// sum over the 64 lanes, the same value in every lane: inclusive scan inside every row of 16 lanes (row_shr 1, 2, 4, 8),
+// lane 15 of a row into the next row (row_bcast:15), lane 31 into rows 2 and 3 (row_bcast:31): lane 63 holds the total
+__device__ inline double wave_sum64(double v) {
+  v += dpp_mov_zero<0x111>(v);
+  v += dpp_mov_zero<0x112>(v);
+  v += dpp_mov_zero<0x114>(v);
+  v += dpp_mov_zero<0x118>(v);
+  v += dpp_mov_zero<0x142>(v);
+  v += dpp_mov_zero<0x143>(v);
+  return readlane_d(v, 63);
+}
+__device__ inline cd wave_sum64(cd v) { return make_cd(wave_sum64(v.x), wave_sum64(v.y)); }
+// maximum over the 64 lanes (non-NaN input), the same value in every lane
+__device__ inline double wave_max64(double v) {
+  v = fmax(v, dpp_mov_keep<0x111>(v));
+  v = fmax(v, dpp_mov_keep<0x112>(v));
+  v = fmax(v, dpp_mov_keep<0x114>(v));
+  v = fmax(v, dpp_mov_keep<0x118>(v));
+  v = fmax(v, dpp_mov_keep<0x142>(v));
+  v = fmax(v, dpp_mov_keep<0x143>(v));
+  return readlane_d(v, 63);
+}
+
+// sum over aligned groups of W lanes (W = 2 .. 64, a power of two), the group's total in each of its lanes.  Butterfly on
+// DPP: xor 1 and xor 2 as quad permutations, xor 4 as row_half_mirror, xor 8 as row_mirror (after the earlier steps all
+// lanes of a quad / half row hold the same partial sum, so a mirror pairs the right partners); 32 and 64 through
+// row_bcast + readlane.
+template <int W>
+__device__ inline double group_sum(double v) {
+  static_assert(W == 1 || W == 2 || W == 4 || W == 8 || W == 16 || W == 32 || W == 64, "group width");
+  if constexpr (W >= 2) v += dpp_mov_keep<0xB1>(v);     // quad_perm [1,0,3,2]
+  if constexpr (W >= 4) v += dpp_mov_keep<0x4E>(v);     // quad_perm [2,3,0,1]
+  if constexpr (W >= 8) v += dpp_mov_keep<0x141>(v);    // row_half_mirror
+  if constexpr (W >= 16) v += dpp_mov_keep<0x140>(v);   // row_mirror
+  if constexpr (W == 32) {
+    const double w = v + dpp_mov_zero<0x142>(v);        // rows 1 and 3: own row + previous row
+    const double lo = readlane_d(w, 31), hi = readlane_d(w, 63);
+    v = (__lane_id() < 32) ? lo : hi;
+  }
+  if constexpr (W == 64) {
+    double w = v + dpp_mov_zero<0x142>(v);
+    w += dpp_mov_zero<0x143>(w);
+    v = readlane_d(w, 63);
+  }
+  return v;
+}
+template <int W>
+__device__ inline cd group_sum(cd v) { return make_cd(group_sum<W>(v.x), group_sum<W>(v.y)); }
+// the three sums of a Jacobi rotation (two squared norms and the inner product) over groups of `w` lanes, w run-time
+template <typename T>
+__device__ inline void group_sum3(double& al, double& be, T& ga, int w) {
+  switch (w) {
+    case 64: al = group_sum<64>(al), be = group_sum<64>(be), ga = group_sum<64>(ga); break;
+    case 32: al = group_sum<32>(al), be = group_sum<32>(be), ga = group_sum<32>(ga); break;
+    case 16: al = group_sum<16>(al), be = group_sum<16>(be), ga = group_sum<16>(ga); break;
+    case 8: al = group_sum<8>(al), be = group_sum<8>(be), ga = group_sum<8>(ga); break;
+    case 4: al = group_sum<4>(al), be = group_sum<4>(be), ga = group_sum<4>(ga); break;
+    case 2: al = group_sum<2>(al), be = group_sum<2>(be), ga = group_sum<2>(ga); break;
+    default: break;
+  }
+}
+
 // error plumbing (host)
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);

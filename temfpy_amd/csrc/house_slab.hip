@@ -14,7 +14,7 @@
 //            memory, one element per thread, prefetched one reflector ahead), factor the panel, store it;
 //   phase 2, per panel of Q: start from unit columns, apply the reflectors backwards, store to the scratch Q;
 //            finally Q is copied over A.
-// A reflector application is a lane-strided dot product with the LDS vector + 6 shuffles + update in registers.
+// A reflector application is a lane-strided dot product with the LDS vector + a DPP wave reduction + update in registers.
 // (First version with the panel in LDS: 5 LDS accesses per element and reflector, LDS-bandwidth bound at 5.4 ms
 // per launch - no faster than the Gram-Schmidt it replaces.)  HBM traffic: 7 x the slab (PMC: 1.9 GB per launch for
 // 0.27 GB of slabs with Q, the earlier reflectors are re-read by every later panel), 0.8 TB/s: not the bound.
@@ -23,9 +23,8 @@
 namespace tmf {
 
 template <typename T>
-__device__ inline T wsum(T v) {
-  for (int o = 32; o > 0; o >>= 1) v = sc<T>::add(v, shfl_xor_t<T>(v, o, 64));
-  return v;
+__device__ inline T wsum(T v) {      // DPP path: the butterfly through ds_bpermute cost 24 dependent LDS-crossbar hops per complex sum
+  return wave_sum64(v);
 }
 
 constexpr int VB = 8;   // reflectors per LDS block
@@ -105,7 +104,7 @@ void house_slab_kernel(const tmf_slab_desc* __restrict__ desc, int w) {
         if (r > k && r < n) s_ += sc<T>::abs2(col[i]);
         if (r == k) al = col[i];
       }
-      for (int o = 32; o > 0; o >>= 1) s_ += __shfl_xor(s_, o);
+      s_ = wave_sum64(s_);
       const T alpha = wsum<T>(al);
       T tau = sc<T>::zero(), scal = sc<T>::zero(), beta = alpha;
       if (s_ > 0.0 || sc<T>::imag(alpha) != 0.0) {

@@ -102,11 +102,7 @@ __global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __re
             be += sc<T>::abs2(b);
             ga = sc<T>::fmacc(ga, a, b);
           }
-          for (int o = tpp >> 1; o > 0; o >>= 1) {
-            al += __shfl_xor(al, o, tpp);
-            be += __shfl_xor(be, o, tpp);
-            ga = sc<T>::add(ga, shfl_xor_t<T>(ga, o, tpp));
-          }
+          group_sum3<T>(al, be, ga, tpp);      // DPP butterfly (the ds_bpermute one cost ~60 cycles per word and step)
           const double g2 = sc<T>::abs2(ga);
           if (g2 > tol2 * al * be && g2 > 1e-280) {   // (below: rsq / rcp without denormal handling)
             // Rotation parameters with v_rsq_f64 / v_rcp_f64 + Newton steps instead of IEEE sqrt / div
@@ -338,11 +334,7 @@ __global__ __launch_bounds__(512) void jacobi_compact_kernel(const tmf_jacobi_de
             be += sc<T>::abs2(b);
             ga = sc<T>::fmacc(ga, a, b);
           }
-          for (int o = tpp >> 1; o > 0; o >>= 1) {
-            al += __shfl_xor(al, o, tpp);
-            be += __shfl_xor(be, o, tpp);
-            ga = sc<T>::add(ga, shfl_xor_t<T>(ga, o, tpp));
-          }
+          group_sum3<T>(al, be, ga, tpp);      // DPP butterfly (the ds_bpermute one cost ~60 cycles per word and step)
           const double g2 = sc<T>::abs2(ga);
           if (g2 > tol2 * al * be && g2 > 1e-280) {
             const double ginv = rsqrt_fast(g2);
@@ -528,11 +520,7 @@ __global__ __launch_bounds__(512) void jacobi_block_kernel(const tmf_jacobi_desc
                 be += sc<T>::abs2(b);
                 ga = sc<T>::fmacc(ga, a, b);
               }
-              for (int o = tpp >> 1; o > 0; o >>= 1) {
-                al += __shfl_xor(al, o, tpp);
-                be += __shfl_xor(be, o, tpp);
-                ga = sc<T>::add(ga, shfl_xor_t<T>(ga, o, tpp));
-              }
+              group_sum3<T>(al, be, ga, tpp);
               const double g2 = sc<T>::abs2(ga);
               if (g2 > tol2 * al * be && g2 > 0.0) {
                 const double g = sqrt(g2);

@@ -421,28 +421,8 @@ __global__ __launch_bounds__(256) void lu_trsm_kernel(const int32_t* __restrict_
 // wave-uniform) and updates its 16 columns: 64 readlanes + 64 FMAs per step and wave, no LDS traffic for the matrix.
 // Rows are never moved: row p_j (the pivot row of column j) of the result is row j of (P D)^-1, un-permuted on output.
 // -------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ inline double dpp_mov(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ inline double readlane_d(double v, int l) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
 __device__ inline double readlane_t(double v, int l) { return readlane_d(v, l); }
 __device__ inline cd readlane_t(cd v, int l) { return make_cd(readlane_d(v.x, l), readlane_d(v.y, l)); }
-// maximum over the 64 lanes (non-NaN input), the same value in every lane
-__device__ inline double wave_max64(double v) {
-  v = fmax(v, dpp_mov<0x111>(v));   // row_shr:1   inclusive scan inside every row of 16 lanes ...
-  v = fmax(v, dpp_mov<0x112>(v));   // row_shr:2
-  v = fmax(v, dpp_mov<0x114>(v));   // row_shr:4
-  v = fmax(v, dpp_mov<0x118>(v));   // row_shr:8   ... lane 15 of a row holds the row maximum
-  v = fmax(v, dpp_mov<0x142>(v));   // row_bcast:15: lane 15 of a row into the next row
-  v = fmax(v, dpp_mov<0x143>(v));   // row_bcast:31: lane 31 into rows 2, 3   -> lane 63 holds the maximum
-  return readlane_d(v, 63);
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void diag_inverse_kernel(const tmf_diaginv_desc* __restrict__ desc, const int step, double* __restrict__ stats) {

@@ -20,6 +20,8 @@ Everything numerical runs on the GPU through the C ABI (``include/temfpy_hip.h``
   ``B_j <- V_j^H B_j V_{j+1}`` two batched MFMA launches, and one batched Gram-Schmidt pass over the kept rows of
   every ``B_j`` makes the tensors exactly right-isometric again (every bond is truncated on its own, which costs a row
   with Schmidt value s up to (cutoff / s)^2 of its norm; the correction moves the state by less than the truncation).
+  For the same reason Schmidt values within a decade of ``cutoff`` come out up to ~cutoff larger than TeNPy's, which
+  truncates the bonds to the right of a site before it takes that site's SVD; all others agree to 1e-15.
   ``method="sequential"`` is TeNPy's algorithm step by step: a sweep to the right with one QR per charge block, then a
   sweep back with one SVD per site, N = A X of shape chi_l x (2 chi_r) per charge block: QR of N^H, a second QR of the
   small factor R^H as preconditioner, one-sided Jacobi WITHOUT accumulator on R3^H

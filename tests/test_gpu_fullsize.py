@@ -95,9 +95,25 @@ def compare_bonds(mps, ref, e_tol=1e-13, lam_tol=1e-9, S_tol=1e-10, tag="case"):
     events = []
     for b in range(L + 1):
         bd = mps.bonds[b]
-        assert [bd.n_filled_left, bd.n_filled_right] == ref["n_filled"][b].tolist(), b
         e_ref = ref["e"][ref["e_off"][b]: ref["e_off"][b + 1]]
         lam_ref = ref["lam"][ref["lam_off"][b]: ref["lam_off"][b + 1]]
+        nf, nf_ref = [bd.n_filled_left, bd.n_filled_right], ref["n_filled"][b].tolist()
+        if nf != nf_ref:
+            # An orbital is "filled" when min(e, 1 - e) < svd_min^2 = 1e-12 (slater.py:318); eigenvalues carry ~1e-15 of
+            # rounding noise, in LAPACK as here, so an orbital that sits on the cutoff to within that noise is classified
+            # either way.  Accepted only if it is exactly that: one orbital, within E_NOISE of the cutoff, all other
+            # eigenvalues and the Schmidt values unchanged (the orbital contributes a factor 1 - 5e-13 to every pattern).
+            d = [nf[0] - nf_ref[0], nf[1] - nf_ref[1]]
+            assert sorted(abs(x) for x in d) == [0, 1], (b, nf, nf_ref)
+            longer, shorter = (e_ref, bd.e) if sum(d) == 1 else (bd.e, e_ref)
+            assert len(longer) == len(shorter) + 1, b
+            edge = np.abs(np.minimum(longer, 1.0 - longer) - 1e-12)
+            x = int(np.argmin(edge))
+            assert edge[x] <= E_NOISE, f"bond {b}: filled counts {nf} vs {nf_ref}, nearest eigenvalue {edge[x]:.1e} off the cutoff"
+            assert np.abs(np.delete(longer, x) - shorter).max(initial=0.0) <= e_tol, b
+            assert len(bd.lam) == len(lam_ref) and np.abs(bd.lam - lam_ref).max() <= 1e-8, b
+            events.append(b)
+            continue
         assert len(bd.e) == len(e_ref), b
         worst["e"] = max(worst["e"], np.abs(bd.e - e_ref).max(initial=0.0))
         assert abs(np.linalg.norm(bd.lam_raw) / ref["lam_norm"][b] - 1) < 1e-9, b
