@@ -36,11 +36,24 @@ __global__ __launch_bounds__(256) void nested_product_kernel(const tmf_nested_de
 #pragma unroll
   for (int t = 0; t < CPT; ++t) acc[t] = sc<T>::zero();
 
-  auto step = [&](const int j) {
-    const T cj = rv ? C[(size_t)r + (size_t)j * d.ldc] : sc<T>::zero();
+  // The walk over j is a chain of short steps (one coalesced load of C[:, j], CPT wave-uniform loads of Omega[j, :], CPT
+  // FMAs, and the stores of the cut that sits at j).  Loads and stores return in order on this architecture, so a load
+  // issued after the stores of the previous step waits for them: the operands of the NEXT group of G steps are therefore
+  // fetched before the current group computes and stores (software pipeline, two register buffers).
+  constexpr int G = 4;
+  struct Group {
+    T cj[G];
+    T om[G][CPT];
+  };
+  auto fetch = [&](Group& g, const int j0, const int dir, const int jlim) {   // steps j0, j0 + dir, ...; beyond jlim: zeros
 #pragma unroll
-    for (int t = 0; t < CPT; ++t)
-      if (c0 + t < d.maxc) acc[t] = sc<T>::fmac(acc[t], cj, Om[(size_t)j + (size_t)(c0 + t) * d.ldo]);
+    for (int u = 0; u < G; ++u) {
+      const int j = j0 + dir * u;
+      const bool in = dir > 0 ? j < jlim : j >= jlim;
+      g.cj[u] = (in && rv) ? C[(size_t)r + (size_t)j * d.ldc] : sc<T>::zero();
+#pragma unroll
+      for (int t = 0; t < CPT; ++t) g.om[u][t] = (in && c0 + t < d.maxc) ? Om[(size_t)j + (size_t)(c0 + t) * d.ldo] : sc<T>::zero();
+    }
   };
   auto emit = [&](const int x) {
     const uint64_t dp = dest[x];
@@ -54,21 +67,50 @@ __global__ __launch_bounds__(256) void nested_product_kernel(const tmf_nested_de
       if (ok && c0 + t < nc) out[(size_t)lr + (size_t)(c0 + t) * ld] = acc[t];
   };
 
+  Group ga, gb;      // (two named buffers, the loop handles both per trip: an indexed pair would live in scratch memory)
   if (!d.suffix) {  // sums over j < x: cut x is complete after step j = x - 1
     int jend = d.x_hi;
     if (d.rows_ge && rb + 63 < jend) jend = rb + 63;  // rows r >= x: nothing to store once x > r
     if (d.x_lo == 0) emit(0);
-    for (int j = 0; j < jend; ++j) {
-      step(j);
-      if (j + 1 >= d.x_lo) emit(j + 1);
+    auto run = [&](const Group& g, const int j0) {
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int j = j0 + u;
+        if (j < jend) {
+#pragma unroll
+          for (int t = 0; t < CPT; ++t) acc[t] = sc<T>::fmac(acc[t], g.cj[u], g.om[u][t]);
+          if (j + 1 >= d.x_lo) emit(j + 1);
+        }
+      }
+    };
+    fetch(ga, 0, 1, jend);
+    for (int j0 = 0; j0 < jend; j0 += 2 * G) {
+      fetch(gb, j0 + G, 1, jend);
+      run(ga, j0);
+      fetch(ga, j0 + 2 * G, 1, jend);
+      run(gb, j0 + G);
     }
   } else {          // sums over j >= x: cut x is complete after step j = x
     int jbeg = d.x_lo;
     if (!d.rows_ge && rb + 1 > jbeg) jbeg = rb + 1;   // rows r < x: nothing to store once x <= r
     if (d.x_hi >= d.D) emit(d.D);
-    for (int j = d.D - 1; j >= jbeg; --j) {
-      step(j);
-      if (j <= d.x_hi) emit(j);
+    auto run = [&](const Group& g, const int j0) {
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int j = j0 - u;
+        if (j >= jbeg) {
+#pragma unroll
+          for (int t = 0; t < CPT; ++t) acc[t] = sc<T>::fmac(acc[t], g.cj[u], g.om[u][t]);
+          if (j <= d.x_hi) emit(j);
+        }
+      }
+    };
+    fetch(ga, d.D - 1, -1, jbeg);
+    for (int j0 = d.D - 1; j0 >= jbeg; j0 -= 2 * G) {
+      fetch(gb, j0 - G, -1, jbeg);
+      run(ga, j0);
+      fetch(ga, j0 - 2 * G, -1, jbeg);
+      run(gb, j0 - G);
     }
   }
 }
