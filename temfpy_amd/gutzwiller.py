@@ -262,6 +262,10 @@ def _as_fermions(mps):
                                   "and convert with iMPS.MPS_to_iMPS instead")
     if isinstance(mps, MPSData):
         return _fermions_from_slater(mps)
+    if isinstance(mps, SpinMPSData):      # (a projected spin chain as input of iMPS.MPS_to_iMPS: 2 S^z blocks or one trivial sector)
+        if mps.form != ["B"] * mps.L:
+            raise ValueError("the spin MPS is not in canonical form (return_canonical=False)")
+        return _fermions_from_dense(mps.dense_tensors(), mps.charges, mps.lam[0], 0, "Sz" if mps.conserve == "Sz" else "none")
     if hasattr(mps, "bonds") and hasattr(mps.bonds[0], "parity"):      # PfMPSData
         T = mps.dense_tensors()
         return _fermions_from_dense(T, infer_parities(T), mps.bonds[mps.ortho_center].lam, mps.ortho_center, "parity")

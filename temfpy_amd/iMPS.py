@@ -3,7 +3,9 @@
 ``MPS_to_iMPS`` (iMPS.py:232-441), ``overlap_schmidt`` (:20-62), ``basis_rotation`` (:65-192) and ``iMPSError``
 (:195-229) with the reference's names, arguments, defaults, warnings and exceptions, on the finite MPS objects
 of this package (``MPSData`` from ``slater.C_to_MPS``: U(1) charge blocks; ``PfMPSData`` from
-``pfaffian.C_to_MPS``: parity blocks, indices of every bond reordered by parity).
+``pfaffian.C_to_MPS``: parity blocks, indices of every bond reordered by parity; ``SpinMPSData`` from the Gutzwiller
+projections: 2 S^z blocks - the projected iMPS is obtained from the projected finite chains of two lengths, the
+reference's own route of projecting an infinite MPS, ``canonical_form_infinite1``, is not built).
 
 Device work (C ABI, ``include/temfpy_hip.h``; no CPU path for it):
 
@@ -426,7 +428,11 @@ def MPS_to_iMPS(mps_short, mps_long, sites_per_cell: int, cut: int, unitary_tol:
     if L_short + sites_per_cell != L_long:
         raise ValueError("The given two MPS must differ by one unit cell, got "
                          f"{L_long} - {L_short} != {sites_per_cell}")
-    if hasattr(mps_short.bonds[0], "q_left") != hasattr(mps_long.bonds[0], "q_left"):
+    def charge_kind(m):      # what the ChargeInfo of the TeNPy object would be
+        if hasattr(m, "bonds"):
+            return "N" if hasattr(m.bonds[0], "q_left") else "parity"
+        return "spin " + str(getattr(m, "conserve", None))               # gutzwiller.SpinMPSData
+    if charge_kind(mps_short) != charge_kind(mps_long):
         raise ValueError("Incompatible ChargeInfo in the two MPS")          # iMPS.py:312-313
     assert all(x is not None for x in mps_short.form), "mps_short is not canonical"
     assert all(x is not None for x in mps_long.form), "mps_long is not canonical"
@@ -444,7 +450,7 @@ def MPS_to_iMPS(mps_short, mps_long, sites_per_cell: int, cut: int, unitary_tol:
         assert sites_per_cell % unit_cell_width == 0, f"{unit_cell_width = } does not divide {sites_per_cell = }"
         cyl1 = sites_per_cell // unit_cell_width
         assert cut % cyl1 == 0, f"{cut = } not divisible into requested cylinder circumferences of {cyl1}"
-    cplx = any(np.iscomplexobj(m.sites[0].dense()) for m in (mps_short, mps_long))
+    cplx = any(np.iscomplexobj(m.sites[0].dense() if hasattr(m, "sites") else m.dense_tensors()[0]) for m in (mps_short, mps_long))
     dev = _Dev(device, cplx)
     cs, cl_ = _Chain(dev, mps_short), _Chain(dev, mps_long)
     mod = cs.mod
