@@ -324,8 +324,12 @@ def main():
     def step_host():
         m = eng.run(C0, trunc, oc, L, download="async")
         results.append(m)
-        if len(results) > 2:
-            results.pop(0).wait()       # at most two results (2 x 1.5 GB of page-locked memory) in flight
+        if len(results) > 1:
+            # Conversion k + 1 is enqueued (its kernels overlap the download of conversion k); now wait for the tensors
+            # of conversion k.  Not deeper: a conversion (25 ms) is shorter than its download (27 ms), so with two
+            # downloads allowed to queue up the copy engine falls behind until the runtime stops overlapping copies and
+            # kernels altogether (measured with tools/async_timeline.py: periods of 27, 27, 117 ms instead of 26.8).
+            results.pop(0).wait()
         return m
 
     def finish_host():
