@@ -27,6 +27,7 @@ plumbing - spawn, rendezvous, segments, leases, assembly - is testable on a mach
 from __future__ import annotations
 
 import atexit
+import functools
 import mmap
 import os
 import pickle
@@ -44,19 +45,56 @@ _LEASE_OFF = ShardArrays.HEADER_ROOM - 16      # uint64 inside the header room: 
 
 
 def shard_sites(L, oc, world):
-    """Contiguous site ranges with balanced cost  w(i) = 1 + 3 (n_i / (L/2))^3
-    (determinant stage ~ constant in the chi-saturated bulk, eigen / overlap stages ~ n^3)."""
-    i = np.arange(L)
-    n = np.where(i < oc, i + 1, L - i)
-    w = 1.0 + 3.0 * (n / max(L / 2, 1)) ** 3
-    c = np.concatenate(([0.0], np.cumsum(w)))
-    bounds = [int(np.searchsorted(c, c[-1] * r / world)) for r in range(world + 1)]
+    return list(_shard_sites(int(L), int(oc), int(world)))
+
+
+@functools.lru_cache(maxsize=64)
+def _shard_sites(L, oc, world):
+    """Contiguous site ranges that minimise the time of the slowest rank under the cost model
+
+        t(lo, hi) = 3.26 + sum_{i in [lo, hi)} (0.0131 + 0.0109 x_i^3) * 1024 / L + 3.67 max_i x_i^2   [ms],   x_i = n_i / (L / 2),
+
+    n_i = size of the smaller block at site i.  Fitted (0.5 ms residual) to the device times of the 15 shards that world
+    sizes 1, 2, 4, 8 cut out of the benchmark chain (tools/shard_cost.py): a per-site part (determinant stage ~ constant
+    in the chi-saturated bulk, eigen / overlap stages ~ n^3) and a per-rank latency that grows with the largest block of
+    the range - the per-cut kernels of a shard with fewer than 256 cuts take as long as their slowest workgroup."""
     if world > L:
         raise ValueError(f"{world} ranks for {L} sites: every rank needs at least one site")
-    bounds[0], bounds[-1] = 0, L
+    i = np.arange(L)
+    n = np.where(i < oc, i + 1, L - i)
+    x = n / max(L / 2, 1)
+    c1 = np.concatenate(([0.0], np.cumsum((0.01307 + 0.01089 * x ** 3) * (1024.0 / L))))
+    x2 = x ** 2
+
+    c1, x2 = c1.tolist(), x2.tolist()
+
+    def cut(T):            # greedy: every range as long as the budget T allows
+        b = [0]
+        while b[-1] < L and len(b) <= world:
+            lo = b[-1]
+            hi, mx = lo + 1, x2[lo]
+            while hi < L and 3.26 + (c1[hi + 1] - c1[lo]) + 3.67 * max(mx, x2[hi]) <= T:
+                mx = max(mx, x2[hi])
+                hi += 1
+            b.append(hi)
+        return b
+
+    lo_T, hi_T = 0.0, 3.26 + c1[L] + 3.67 * max(x2)
+    for _ in range(50):
+        mid = 0.5 * (lo_T + hi_T)
+        b = cut(mid)
+        if b[-1] >= L and len(b) - 1 <= world:
+            hi_T = mid
+        else:
+            lo_T = mid
+    bounds = cut(hi_T)
+    bounds[-1] = L
+    while len(bounds) - 1 < world:          # fewer ranges than ranks (tiny chains): split the longest
+        k = int(np.argmax(np.diff(bounds)))
+        bounds.insert(k + 1, (bounds[k] + bounds[k + 1]) // 2)
     for r in range(1, world):          # strictly increasing: no empty range
         bounds[r] = min(max(bounds[r], bounds[r - 1] + 1), L - (world - r))
-    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+    return tuple((bounds[r], bounds[r + 1]) for r in range(world))
 
 
 # ------------------------------------------------------------------------------------------------ shared memory
