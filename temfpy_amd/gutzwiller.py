@@ -376,15 +376,15 @@ class _Projector:
                         continue
                     sb.append((j, sg, c, b[0], a[1], b[1], a[0]))
         # prune sectors that are not connected to both ends of the chain
-        alive = [set() for _ in range(Ls + 1)]
-        alive[0] = set(kept[0])
-        for j in range(Ls):
-            alive[j + 1] = {x[3] for x in sb if x[0] == j and x[2] in alive[j]}
-        back = [set() for _ in range(Ls + 1)]
-        back[Ls] = alive[Ls]
         byj = [[] for _ in range(Ls)]
         for x in sb:
             byj[x[0]].append(x)
+        alive = [set() for _ in range(Ls + 1)]
+        alive[0] = set(kept[0])
+        for j in range(Ls):
+            alive[j + 1] = {x[3] for x in byj[j] if x[2] in alive[j]}
+        back = [set() for _ in range(Ls + 1)]
+        back[Ls] = alive[Ls]
         for j in range(Ls - 1, -1, -1):
             back[j] = {x[2] for x in byj[j] if x[3] in back[j + 1]} & alive[j]
         self.sb = [[x for x in byj[j] if x[2] in back[j] and x[3] in back[j + 1]] for j in range(Ls)]
