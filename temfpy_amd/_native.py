@@ -88,7 +88,7 @@ SYMBOLS = [
     "tmf_last_error", "tmf_version", "tmf_device_count", "tmf_gemm_batched", "tmf_gemm_tall_batched", "tmf_orth_panel_batched",
     "tmf_bcgs_work_bytes", "tmf_bcgs_batched", "tmf_jacobi_batched", "tmf_svd_left_batched",
     "tmf_jacobi_block_batched", "tmf_nested_products_batched", "tmf_recon_error_batched", "tmf_lu_schur_batched",
-    "tmf_det_gather_batched", "tmf_det_reduced_batched", "tmf_det_ppt_batched", "tmf_transpose", "tmf_fill_normal",
+    "tmf_det_gather_batched", "tmf_det_reduced_batched", "tmf_det_ppt_batched", "tmf_det_ppt_batched_w", "tmf_transpose", "tmf_fill_normal",
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_column_norms_batched", "tmf_cut_vectors",
     "tmf_site_prepare", "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_det_tiles_build", "tmf_pf_gather_batched",
     "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched", "tmf_copy_blocks_batched", "tmf_house_qr_batched", "tmf_jacobi_compact_batched", "tmf_house_slab_batched",
@@ -206,6 +206,7 @@ def load():
     lib.tmf_lu_schur_batched.argtypes = [i32, vp, i32, i32, vp]
     lib.tmf_det_gather_batched.argtypes = [i32, i32, vp, i32, i32, vp]
     lib.tmf_det_ppt_batched.argtypes = [i32, vp, i32, i32, vp]
+    lib.tmf_det_ppt_batched_w.argtypes = [i32, vp, i32, i32, i32, vp]
     lib.tmf_det_tiles_build.argtypes = [i32, vp, vp, vp, vp, i32, i64, vp, i64, vp, i64, vp, vp, vp, vp]
     lib.tmf_det_tiles_build.restype = i64
     lib.tmf_det_reduced_batched.argtypes = [i32, i32, vp, i32, i32, vp]

@@ -33,6 +33,27 @@ namespace {
 
 __device__ inline uint64_t below(int i) { return (i >= 64) ? ~0ull : ((1ull << i) - 1ull); }
 __device__ inline uint64_t above(uint64_t m, int i) { return (i >= 63) ? 0ull : (m >> (i + 1)); }
+// The same on 32-bit masks: almost every sector of a sweep has at most 32 rows and columns, and the kernel is bound by its
+// VALU instruction count (PMC: 32 k instructions per wavefront, ~1000 per pair, most of them 64-bit shifts / popcounts /
+// find-first-sets of the sign bookkeeping, each of which is 2-4 instructions on 32-bit ALUs).
+template <typename M>
+struct mk;
+template <>
+struct mk<uint64_t> {
+  static constexpr int W = 64;
+  __device__ static inline uint64_t below(int i) { return (i >= 64) ? ~0ull : ((1ull << i) - 1ull); }
+  __device__ static inline uint64_t above(uint64_t m, int i) { return (i >= 63) ? 0ull : (m >> (i + 1)); }
+  __device__ static inline int popc(uint64_t m) { return __popcll(m); }
+  __device__ static inline int ffs(uint64_t m) { return __ffsll((unsigned long long)m); }
+};
+template <>
+struct mk<uint32_t> {
+  static constexpr int W = 32;
+  __device__ static inline uint32_t below(int i) { return (i >= 32) ? ~0u : ((1u << i) - 1u); }
+  __device__ static inline uint32_t above(uint32_t m, int i) { return (i >= 31) ? 0u : (m >> (i + 1)); }
+  __device__ static inline int popc(uint32_t m) { return __popc(m); }
+  __device__ static inline int ffs(uint32_t m) { return __ffs((int)m); }
+};
 
 template <typename T, int DD, int G>
 __device__ __attribute__((noinline)) T small_det_group(const T* __restrict__ Gm, const int ld, uint64_t rmask, uint64_t cmask, const int d,
@@ -109,22 +130,20 @@ __device__ inline T wave_lds_det(T* __restrict__ A, const int n, const int lane)
 }  // namespace
 
 // dynamic LDS: [ G : sb*sk T ][ kmask : nsk u64 ][ amask : na u64 ][ per wave: scratch max(264, n*n) T | queue 72 u32 ]
-template <typename T>
-__global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __restrict__ desc, const float boost) {
-  extern __shared__ __align__(16) unsigned char smem[];
+template <typename T, typename M>
+__device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det_desc& d, const float boost, unsigned char* __restrict__ smem) {
   __shared__ unsigned red_key[4];
   __shared__ uint8_t row_of[64], col_of[64], invr[64], prow_seq[64], pcol_seq[64];
   __shared__ uint64_t s_PA, s_PB;
   __shared__ int s_singular, s_csector;
   __shared__ double s_prod[2];
 
-  const tmf_det_desc d = desc[blockIdx.x];
   const int sb = d.sb, sk = d.sk, n = d.n, nsk = d.nsk, na = d.a1 - d.a0;
   T* Gm = reinterpret_cast<T*>(smem);                       // Gm[r + c * sb]
   size_t off = ((size_t)sb * sk * sizeof(T) + 15) & ~(size_t)15;
-  uint64_t* kmask = reinterpret_cast<uint64_t*>(smem + off);
+  M* kmask = reinterpret_cast<M*>(smem + off);          // (8-byte slots in both mask widths: the host sizes the LDS for u64)
   off += (size_t)nsk * 8;
-  uint64_t* amask = reinterpret_cast<uint64_t*>(smem + off);
+  M* amask = reinterpret_cast<M*>(smem + off);
   off += (size_t)na * 8;
   off = (off + 15) & ~(size_t)15;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -138,20 +157,20 @@ __global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __rest
   const uint8_t* __restrict__ gk = reinterpret_cast<const uint8_t*>(d.ket_idx);
   const uint8_t* __restrict__ gb = reinterpret_cast<const uint8_t*>(d.bra_idx);
   for (int b = tid; b < nsk; b += 256) {
-    uint64_t m = 0;
-    for (int u = 0; u < n; ++u) m |= 1ull << gk[(size_t)b * n + u];
+    M m = 0;
+    for (int u = 0; u < n; ++u) m |= M(1) << gk[(size_t)b * n + u];
     kmask[b] = m;
   }
   for (int a = tid; a < na; a += 256) {
-    uint64_t m = 0;
-    for (int u = 0; u < n; ++u) m |= 1ull << gb[(size_t)(d.a0 + a) * n + u];
+    M m = 0;
+    for (int u = 0; u < n; ++u) m |= M(1) << gb[(size_t)(d.a0 + a) * n + u];
     amask[a] = m;
   }
   // preferred pivots: rows of the sector's leading bra set, columns of its leading ket set
-  uint64_t pref_r = 0, pref_c = 0;
+  M pref_r = 0, pref_c = 0;
   for (int u = 0; u < n; ++u) {
-    pref_r |= 1ull << gb[u];
-    pref_c |= 1ull << gk[u];
+    pref_r |= M(1) << gb[u];
+    pref_c |= M(1) << gk[u];
   }
   if (tid == 0) {
     s_PA = 0, s_PB = 0, s_singular = 0;
@@ -160,15 +179,15 @@ __global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __rest
   __syncthreads();
 
   // ---------------- n exchange steps with full pivoting over the sector matrix -----------------------
-  uint64_t usedR = 0, usedC = 0;   // uniform copies
+  M usedR = 0, usedC = 0;   // uniform copies
   for (int t = 0; t < n; ++t) {
     unsigned key = 0u;
     for (int e = tid; e < sb * sk; e += 256) {
       const int r = e % sb, c = e / sb;
-      if (((usedR >> r) | (usedC >> c)) & 1ull) continue;
+      if (((usedR >> r) | (usedC >> c)) & M(1)) continue;
       float v = (float)sc<T>::abs2(Gm[e]);
-      if ((pref_r >> r) & 1ull) v *= boost;
-      if ((pref_c >> c) & 1ull) v *= boost;
+      if ((pref_r >> r) & M(1)) v *= boost;
+      if ((pref_c >> c) & M(1)) v *= boost;
       // 20 bits of magnitude (sign bit clear), 12 bits of element index (sb * sk <= 4096): ties -> larger index
       const unsigned mag = __float_as_uint(v) & ~4095u;
       const unsigned k = mag ? (mag | (unsigned)e) : 0u;
@@ -215,7 +234,7 @@ __global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __rest
       const T q = sc<T>::mul(sc<T>::from2(s_prod[0], s_prod[1]), p);
       s_prod[0] = sc<T>::real(q), s_prod[1] = sc<T>::imag(q);
     }
-    usedR |= 1ull << pr, usedC |= 1ull << pc;
+    usedR |= M(1) << pr, usedC |= M(1) << pc;
     __syncthreads();
   }
   T* __restrict__ out = reinterpret_cast<T*>(d.out);
@@ -223,17 +242,17 @@ __global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __rest
     for (int64_t e = tid; e < (int64_t)na * nsk; e += 256) out[(size_t)d.a0 * nsk + e] = sc<T>::zero();
     return;
   }
-  const uint64_t PA = s_PA, PB = s_PB;
-  const uint64_t NPB = below(sk) & ~PB;
+  const M PA = (M)s_PA, PB = (M)s_PB;
+  const M NPB = mk<M>::below(sk) & ~PB;
   // tables: invr[r] = inversions of the sequence col_of over the pivot rows (ascending) that involve r;
   // sign of det M*_sorted relative to the product of the pivots = parity of the two pivot sequences
   if (tid < 64) {
     const int r = tid;
     int v = 0;
-    if ((PA >> r) & 1ull) {
+    if (r < mk<M>::W && ((PA >> r) & M(1))) {
       const int cr = col_of[r];
-      for (uint64_t m = PA & below(r); m; m &= m - 1) v += col_of[__ffsll((unsigned long long)m) - 1] > cr;
-      for (uint64_t m = above(PA, r); m; m &= m - 1) v += col_of[__ffsll((unsigned long long)m) + r] < cr;
+      for (M m = PA & mk<M>::below(r); m; m &= m - 1) v += col_of[mk<M>::ffs(m) - 1] > cr;
+      for (M m = mk<M>::above(PA, r); m; m &= m - 1) v += col_of[mk<M>::ffs(m) + r] < cr;
     }
     invr[r] = (uint8_t)v;
   }
@@ -252,50 +271,50 @@ __global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __rest
 
   // everything that depends on the bra set only (uniform in the wavefront)
   struct ASide {
-    uint64_t in, out_, cm;   // rows entering, pivot rows leaving, pivot columns of the leaving rows
+    M in, out_, cm;   // rows entering, pivot rows leaving, pivot columns of the leaving rows
     int da, par;
   };
-  auto a_side = [&](const uint64_t am) {
+  auto a_side = [&](const M am) {
     ASide s;
     s.in = am & ~PA, s.out_ = PA & ~am, s.cm = 0;
-    s.da = __popcll(s.in);
+    s.da = mk<M>::popc(s.in);
     int par = 0;
-    uint64_t seen = 0;
-    for (uint64_t m = s.out_; m; m &= m - 1) {
-      const int r = __ffsll((unsigned long long)m) - 1, cr = col_of[r];
-      par += __popcll(above(NPB, cr)) + invr[r] + __popcll(above(seen, cr));   // I_X0Y1, I_Y1Y1 (two parts)
-      seen |= 1ull << cr;
-      s.cm |= 1ull << cr;
+    M seen = 0;
+    for (M m = s.out_; m; m &= m - 1) {
+      const int r = mk<M>::ffs(m) - 1, cr = col_of[r];
+      par += mk<M>::popc(mk<M>::above(NPB, cr)) + invr[r] + mk<M>::popc(mk<M>::above(seen, cr));   // I_X0Y1, I_Y1Y1 (two parts)
+      seen |= M(1) << cr;
+      s.cm |= M(1) << cr;
     }
-    for (uint64_t m = s.in; m; m &= m - 1) {
-      const int r0 = __ffsll((unsigned long long)m) - 1;
-      par += __popcll(above(PA, r0)) + __popcll(above(s.out_, r0));            // I_Y0Y1
+    for (M m = s.in; m; m &= m - 1) {
+      const int r0 = mk<M>::ffs(m) - 1;
+      par += mk<M>::popc(mk<M>::above(PA, r0)) + mk<M>::popc(mk<M>::above(s.out_, r0));            // I_Y0Y1
     }
     s.par = par;
     return s;
   };
   // the pair: masks of the small determinant and the parity of the sign
-  auto pair = [&](const ASide& A, const uint64_t bm, uint64_t& Rm, uint64_t& Cm) {
-    const uint64_t bin = bm & ~PB, bout = PB & ~bm;
-    const int db = __popcll(bin);
+  auto pair = [&](const ASide& A, const M bm, M& Rm, M& Cm) {
+    const M bin = bm & ~PB, bout = PB & ~bm;
+    const int db = mk<M>::popc(bin);
     int par = csec + A.par + db * (n - A.da);                                  // sector, bra part, I_X1Y1
     Rm = A.in;
-    uint64_t seen = 0;
-    for (uint64_t m = bout; m; m &= m - 1) {
-      const int c1 = __ffsll((unsigned long long)m) - 1, r1 = row_of[c1];
-      par += c1 + __popcll(above(NPB, c1)) + __popcll(above(bin, c1))          // T1, I_X0X1
-             + __popcll(above(seen, r1)) + __popcll(A.in & below(r1));         // I_X1X1, I_X1Y0
-      seen |= 1ull << r1;
-      Rm |= 1ull << r1;
+    M seen = 0;
+    for (M m = bout; m; m &= m - 1) {
+      const int c1 = mk<M>::ffs(m) - 1, r1 = row_of[c1];
+      par += c1 + mk<M>::popc(mk<M>::above(NPB, c1)) + mk<M>::popc(mk<M>::above(bin, c1))          // T1, I_X0X1
+             + mk<M>::popc(mk<M>::above(seen, r1)) + mk<M>::popc(A.in & mk<M>::below(r1));         // I_X1X1, I_X1Y0
+      seen |= M(1) << r1;
+      Rm |= M(1) << r1;
     }
-    for (uint64_t m = bin; m; m &= m - 1) {
-      const int c0 = __ffsll((unsigned long long)m) - 1;
-      par += c0 + __popcll(PB & below(c0)) + __popcll(A.cm & below(c0));       // T1, I_X0Y1 (two parts)
+    for (M m = bin; m; m &= m - 1) {
+      const int c0 = mk<M>::ffs(m) - 1;
+      par += c0 + mk<M>::popc(PB & mk<M>::below(c0)) + mk<M>::popc(A.cm & mk<M>::below(c0));       // T1, I_X0Y1 (two parts)
     }
     Cm = bin | A.cm;
-    const int dd = __popcll(Cm);
+    const int dd = mk<M>::popc(Cm);
     int csum = 0;
-    for (uint64_t m = Cm; m; m &= m - 1) csum += __ffsll((unsigned long long)m) - 1;
+    for (M m = Cm; m; m &= m - 1) csum += mk<M>::ffs(m) - 1;
     par += dd * (sk - 1) + csum + ((dd * (dd - 1)) >> 1);                       // T5
     return par;
   };
@@ -303,9 +322,9 @@ __global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __rest
   auto slow_batch = [&](const uint32_t item, const bool live) {
     const int al = live ? (int)(item >> 16) & 0x7fff : 0, b = live ? (int)(item & 0xffffu) : 0;
     const ASide A = a_side(amask[al]);
-    uint64_t Rm, Cm;
+    M Rm, Cm;
     const int par = pair(A, kmask[b], Rm, Cm);
-    const int dd = live ? __popcll(Cm) : 0;
+    const int dd = live ? mk<M>::popc(Cm) : 0;
     unsigned dmax = (unsigned)dd;
     for (int o = 32; o > 0; o >>= 1) {
       const unsigned other = (unsigned)__shfl_xor((int)dmax, o);
@@ -314,7 +333,7 @@ __global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __rest
     T det = sc<T>::one();
     bool direct = false;
     if (dmax <= 8u) {
-      det = small_det_group<T, 8, 8>(Gm, sb, Rm, Cm, dd, c8, scr_g);
+      det = small_det_group<T, 8, 8>(Gm, sb, (uint64_t)Rm, (uint64_t)Cm, dd, c8, scr_g);
     } else {
       // (never seen in a sweep: more than 8 exchanged orbitals.)  The 8 pairs are evaluated one after the
       // other as full n x n minors of the ORIGINAL matrix, gathered from global memory into the
@@ -349,11 +368,11 @@ __global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __rest
     for (int b0 = 0; b0 < nsk; b0 += 64) {
       const int b = b0 + lane;
       const bool live = b < nsk;
-      uint64_t Rm = 0, Cm = 0;
+      M Rm = 0, Cm = 0;
       int par = 0, dd = 0;
       if (live) {
         par = pair(A, kmask[b], Rm, Cm);
-        dd = __popcll(Cm);
+        dd = mk<M>::popc(Cm);
       }
       const bool slow = live && dd > 4;
       if (live && !slow) {
@@ -362,8 +381,8 @@ __global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __rest
         for (int t = 0; t < 4; ++t) {
           iv[t] = 0, jv[t] = 0;
           if (t < dd) {
-            iv[t] = __ffsll((unsigned long long)Rm) - 1;
-            jv[t] = (__ffsll((unsigned long long)Cm) - 1) * sb;
+            iv[t] = mk<M>::ffs(Rm) - 1;
+            jv[t] = (mk<M>::ffs(Cm) - 1) * sb;
             Rm &= Rm - 1, Cm &= Cm - 1;
           }
         }
@@ -427,28 +446,50 @@ __global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __rest
   if (qn > 0) slow_batch(queue[grp < qn ? grp : 0], grp < qn);
 }
 
+
+// Two kernels, not one kernel with a branch: the 64-bit body needs 131 VGPRs (3 wavefronts per SIMD), the 32-bit one fits 4.
+template <typename T, typename M>
+__global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __restrict__ desc, const float boost) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const tmf_det_desc d = desc[blockIdx.x];
+  ppt_det_body<T, M>(d, boost, smem);
+}
+
 }  // namespace tmf
 
-extern "C" int tmf_det_ppt_batched(int dtype, const tmf_det_desc* d_desc, int ntiles, int lds_bytes, void* stream) {
+extern "C" int tmf_det_ppt_batched_w(int dtype, const tmf_det_desc* d_desc, int ntiles, int lds_bytes, int mask_bits, void* stream) {
   using namespace tmf;
   if (ntiles <= 0) return TMF_OK;
   if (lds_bytes < 0 || lds_bytes > 150 * 1024) {
     set_error("tmf_det_ppt_batched: lds_bytes %d exceeds the dynamic LDS budget (150 KiB)", lds_bytes);
     return TMF_E_LIMIT;
   }
+  if (mask_bits != 32 && mask_bits != 64) {
+    set_error("tmf_det_ppt_batched_w: mask_bits %d (32 or 64)", mask_bits);
+    return TMF_E_ARG;
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)ppt_det_kernel<cd>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void*)ppt_det_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)ppt_det_kernel<cd, uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)ppt_det_kernel<double, uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)ppt_det_kernel<cd, uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)ppt_det_kernel<double, uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr = true;
   }
   static float boost = getenv("TMF_PPT_BOOST") ? (float)atof(getenv("TMF_PPT_BOOST")) : 10.0f;  // experiment knob
-  if (dtype == TMF_C128) hipLaunchKernelGGL(ppt_det_kernel<cd>, dim3(ntiles), dim3(256), lds_bytes, s, d_desc, boost);
-  else if (dtype == TMF_F64) hipLaunchKernelGGL(ppt_det_kernel<double>, dim3(ntiles), dim3(256), lds_bytes, s, d_desc, boost);
+  const dim3 g(ntiles), b(256);
+  if (dtype == TMF_C128 && mask_bits == 32) hipLaunchKernelGGL((ppt_det_kernel<cd, uint32_t>), g, b, lds_bytes, s, d_desc, boost);
+  else if (dtype == TMF_C128) hipLaunchKernelGGL((ppt_det_kernel<cd, uint64_t>), g, b, lds_bytes, s, d_desc, boost);
+  else if (dtype == TMF_F64 && mask_bits == 32) hipLaunchKernelGGL((ppt_det_kernel<double, uint32_t>), g, b, lds_bytes, s, d_desc, boost);
+  else if (dtype == TMF_F64) hipLaunchKernelGGL((ppt_det_kernel<double, uint64_t>), g, b, lds_bytes, s, d_desc, boost);
   else {
     set_error("tmf_det_ppt_batched: bad dtype %d", dtype);
     return TMF_E_ARG;
   }
   return check_hip(hipGetLastError(), "tmf_det_ppt_batched launch");
+}
+
+extern "C" int tmf_det_ppt_batched(int dtype, const tmf_det_desc* d_desc, int ntiles, int lds_bytes, void* stream) {
+  return tmf_det_ppt_batched_w(dtype, d_desc, ntiles, lds_bytes, 64, stream);
 }

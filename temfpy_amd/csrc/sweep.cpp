@@ -1435,7 +1435,9 @@ struct Sweep {
           TMF_TRY(new_event(&ev.e1));
           HIP_TRY(hipEventRecord(ev.e0, c.s_main));
         }
-        TMF_TRY(tmf_det_ppt_batched(c.dtype, (const tmf_det_desc*)t_dd, (int)nt, lds_max, c.s_main));
+        i64 widest = 0;
+        for (i64 j = 0; j < ns; ++j) widest = std::max(widest, std::max(sbv[j], skv[j]));
+        TMF_TRY(tmf_det_ppt_batched_w(c.dtype, (const tmf_det_desc*)t_dd, (int)nt, lds_max, widest <= 32 ? 32 : 64, c.s_main));
         if (timing()) {
           HIP_TRY(hipEventRecord(ev.e1, c.s_main));
           ev.flops = fl3 * flop_per_det, ev.n = npairs, ev.kind = 0, ev.order = 0;

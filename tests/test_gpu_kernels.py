@@ -808,7 +808,8 @@ def test_det_ppt_matches_numpy(eng, cplx, n, sb, sk, mode):
                  min(nsb, (j + 1) * ta))
     lds = int(nat.ppt_det_lds(eng.elem, sb, sk, nsk, ta, n))
     t = eng._up(dd)
-    nat.check(eng.lib.tmf_det_ppt_batched(eng.dtype, t.data_ptr(), len(dd), lds, eng.stream), "ppt")
+    # (sectors of at most 32 x 32 through the 32-bit-mask kernel, as the sweep launches them)
+    nat.check(eng.lib.tmf_det_ppt_batched_w(eng.dtype, t.data_ptr(), len(dd), lds, 32 if max(sb, sk) <= 32 else 64, eng.stream), "ppt")
     torch.cuda.synchronize()
     got = out.cpu().numpy().reshape(nsb, nsk)
     ref = np.empty((nsb, nsk), S.dtype)
