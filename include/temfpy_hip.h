@@ -243,7 +243,7 @@ int tmf_det_reduced_batched(int dtype, int order, const tmf_det_desc* d_desc, in
  *   + 4 * (max(264, n*n) * elem + 288). */
 int tmf_det_ppt_batched(int dtype, const tmf_det_desc* d_desc, int ntiles, int lds_bytes, void* stream);
 /* mask_bits = 32: every tile of the launch has sb, sk <= 32 (the occupation masks and the sign bookkeeping then run on 32-bit
- * words: 2.87 instead of 3.26 ms at the benchmark size, one more wavefront per SIMD); 64: as tmf_det_ppt_batched. */
+ * words and the ket-only part of the sign is computed once per ket set: 2.72 instead of 3.26 ms at the benchmark size); 64: as tmf_det_ppt_batched. */
 int tmf_det_ppt_batched_w(int dtype, const tmf_det_desc* d_desc, int ntiles, int lds_bytes, int mask_bits, void* stream);
 
 /* Batched gathered Pfaffians (pfaffian.py:1429-1479 `_tensor_block` + :1413-1426 `_many_pfaffian`,

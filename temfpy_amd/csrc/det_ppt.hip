@@ -263,6 +263,39 @@ __device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det
     s_csector = inv & 1;
   }
   __syncthreads();
+  // Everything in the sign and the masks of a pair that depends on the ket set only is computed ONCE per ket set (32-bit
+  // masks; kmask[b] is replaced by bin = its columns outside the pivot set, the rows of its leaving pivot columns go into
+  // the spare half of the 8-byte mask slots, the parity of the ket-only terms into a bit array).  What is left per pair
+  // are two cross terms whose loops run over the bits of the BRA set, i.e. are uniform in the wavefront:
+  //   #{(x, r1): x in A.in, r1 in Rb, x < r1}  +  #{(y, c0): y in A.cm, c0 in bin, y < c0}.
+  __shared__ uint32_t parbits[64];
+  constexpr bool FAST = sizeof(M) == 4;
+  const bool fast = FAST && nsk <= 2048;
+  M* rbm = reinterpret_cast<M*>(reinterpret_cast<unsigned char*>(kmask) + (size_t)nsk * 4);   // (FAST only)
+  if (fast) {
+    if (tid < 64) parbits[tid] = 0u;
+    __syncthreads();
+    for (int b = tid; b < nsk; b += 256) {
+      const M bm = kmask[b];
+      const M bin = bm & ~PB, bout = PB & ~bm;
+      int par = 0;
+      M Rb = 0, seen = 0;
+      for (M m = bout; m; m &= m - 1) {
+        const int c1 = mk<M>::ffs(m) - 1, r1 = row_of[c1];
+        par += c1 + mk<M>::popc(mk<M>::above(NPB, c1)) + mk<M>::popc(mk<M>::above(bin, c1)) + mk<M>::popc(mk<M>::above(seen, r1));
+        seen |= M(1) << r1;
+        Rb |= M(1) << r1;
+      }
+      for (M m = bin; m; m &= m - 1) {
+        const int c0 = mk<M>::ffs(m) - 1;
+        par += c0 + mk<M>::popc(PB & mk<M>::below(c0)) + c0;          // T1, I_X0Y1 (ket part), and c0's share of csum (T5)
+      }
+      kmask[b] = bin;
+      rbm[b] = Rb;
+      if (par & 1) atomicOr(&parbits[b >> 5], 1u << (b & 31));
+    }
+    __syncthreads();
+  }
   const T scale = *reinterpret_cast<const T*>(d.scale);
   const T pref_fac = sc<T>::mul(scale, sc<T>::from2(s_prod[0], s_prod[1]));
   const int csec = s_csector;
@@ -319,11 +352,29 @@ __device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det
     return par;
   };
 
+  // bra-only extras of the fast path: csum over A.cm (T5) is folded into the bra parity
+  auto pair_fast = [&](const ASide& A, const int acm_sum, const int b, M& Rm, M& Cm) {
+    const M bin = kmask[b], Rb = rbm[b];
+    const int db = mk<M>::popc(bin), dd = db + A.da;
+    int par = csec + A.par + acm_sum + (int)((parbits[b >> 5] >> (b & 31)) & 1u) + db * (n - A.da);
+    for (M m = A.in; m; m &= m - 1) par += mk<M>::popc(mk<M>::above(Rb, mk<M>::ffs(m) - 1));     // I_X1Y0
+    for (M m = A.cm; m; m &= m - 1) par += mk<M>::popc(mk<M>::above(bin, mk<M>::ffs(m) - 1));    // I_X0Y1 (cross part)
+    par += dd * (sk - 1) + ((dd * (dd - 1)) >> 1);                                                // T5 without csum
+    Rm = A.in | Rb;
+    Cm = bin | A.cm;
+    return par;
+  };
+  auto cm_sum = [&](const ASide& A) {
+    int v = 0;
+    for (M m = A.cm; m; m &= m - 1) v += mk<M>::ffs(m) - 1;
+    return v;
+  };
+
   auto slow_batch = [&](const uint32_t item, const bool live) {
     const int al = live ? (int)(item >> 16) & 0x7fff : 0, b = live ? (int)(item & 0xffffu) : 0;
     const ASide A = a_side(amask[al]);
     M Rm, Cm;
-    const int par = pair(A, kmask[b], Rm, Cm);
+    const int par = fast ? pair_fast(A, cm_sum(A), b, Rm, Cm) : pair(A, kmask[b], Rm, Cm);
     const int dd = live ? mk<M>::popc(Cm) : 0;
     unsigned dmax = (unsigned)dd;
     for (int o = 32; o > 0; o >>= 1) {
@@ -364,6 +415,7 @@ __device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det
   int qn = 0;  // pairs waiting for the slow path (uniform in the wavefront)
   for (int al = wave; al < na; al += 4) {
     const ASide A = a_side(amask[al]);
+    const int acm = cm_sum(A);
     T* __restrict__ orow = out + (size_t)(d.a0 + al) * nsk;
     for (int b0 = 0; b0 < nsk; b0 += 64) {
       const int b = b0 + lane;
@@ -371,7 +423,7 @@ __device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det
       M Rm = 0, Cm = 0;
       int par = 0, dd = 0;
       if (live) {
-        par = pair(A, kmask[b], Rm, Cm);
+        par = fast ? pair_fast(A, acm, b, Rm, Cm) : pair(A, kmask[b], Rm, Cm);
         dd = mk<M>::popc(Cm);
       }
       const bool slow = live && dd > 4;
