@@ -68,7 +68,7 @@ __global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __re
   const int npairs = pe / 2;
   int tpp = 64;                     // lanes per pair: largest power of two with npairs*tpp <= 512
   while (tpp * npairs > 512) tpp >>= 1;
-  const int pair = tid / tpp, pl = tid % tpp;
+  const int pair = tid >> (31 - __builtin_clz(tpp)), pl = tid & (tpp - 1);      // tpp is a power of two
   // rotate while |<x_i, x_j>| > sqrt(p) eps |x_i| |x_j| (the rounding level of the p-term inner product
   // itself; a tighter bound makes pairs at that level rotate for ever: 18 of 1023 cuts hit the cap)
   const double tol2 = 1.1e-16 * 1.1e-16 * (double)p;
@@ -82,8 +82,10 @@ __global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __re
           i = m;
           j = rho;
         } else {
-          i = (rho + pair) % m;
-          j = (rho - pair + m) % m;
+          i = rho + pair;          // (rho < m, pair <= m: one conditional wrap instead of two integer divisions per round -
+          j = rho - pair;          //  the kernel is bound by its VALU instruction count, a quarter of it integer arithmetic)
+          if (i >= m) i -= m;
+          if (j < 0) j += m;
         }
         if (i > j) {
           const int t = i;
@@ -308,15 +310,17 @@ __global__ __launch_bounds__(512) void jacobi_compact_kernel(const tmf_jacobi_de
   int sweep = 0;
   for (; sweep < 60 && nact > 1; ++sweep) {
     for (int rho = 0; rho < m; ++rho) {
-      for (int pair = tid / tpp; pair < npairs; pair += slots) {
-        const int pl = tid % tpp;
+      for (int pair = tid >> (31 - __builtin_clz(tpp)); pair < npairs; pair += slots) {
+        const int pl = tid & (tpp - 1);      // tpp is a power of two
         int i, j;
         if (pair == 0) {
           i = m;
           j = rho;
         } else {
-          i = (rho + pair) % m;
-          j = (rho - pair + m) % m;
+          i = rho + pair;          // (rho < m, pair <= m: one conditional wrap instead of two integer divisions per round -
+          j = rho - pair;          //  the kernel is bound by its VALU instruction count, a quarter of it integer arithmetic)
+          if (i >= m) i -= m;
+          if (j < 0) j += m;
         }
         if (i > j) {
           const int t = i;
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(512) void jacobi_block_kernel(const tmf_jacobi_desc
   const int m = nc - 1, npairs = nc / 2;               // round-robin over nc players
   int tpp = 64;
   while (tpp * npairs > 512) tpp >>= 1;
-  const int pair = tid / tpp, pl = tid % tpp;
+  const int pair = tid >> (31 - __builtin_clz(tpp)), pl = tid & (tpp - 1);      // tpp is a power of two
   const double tol2 = 1.1e-16 * 1.1e-16 * (double)p;
 
   int sweep = 0;
@@ -501,8 +505,10 @@ __global__ __launch_bounds__(512) void jacobi_block_kernel(const tmf_jacobi_desc
               i = m;
               j = rho;
             } else {
-              i = (rho + pair) % m;
-              j = (rho - pair + m) % m;
+              i = rho + pair;
+              j = rho - pair;
+              if (i >= m) i -= m;
+              if (j < 0) j += m;
             }
             if (i > j) {
               const int t = i;
