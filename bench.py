@@ -400,7 +400,11 @@ def main():
                 "achieved": round(ach, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / FP64_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": pmc_note,
                 "launches_per_step": n_l, "avg_launch_ms": round(g_ms / max(n_l, 1), 4),
-                "flops_per_launch": round(g_fl / max(n_l, 1))}
+                "flops_per_launch": round(g_fl / max(n_l, 1)),
+                # algorithmic flops (8 M N K per complex product); the kernel forms complex products by the
+                # 3M scheme, i.e. issues 6 M N K of them to the MFMA pipe
+                "mfma_flops_issued_per_algorithmic_flop": 0.75,
+                "mfma_pipe_frac": round(0.75 * ach / FP64_PEAK_TFLOPS, 4)}
         # the step itself is bound by the host link: every conversion moves C up and the tensors down
         link_bytes = out_bytes + C0.nbytes
         roof["pcie"] = {"bound": "pcie", "bytes_per_step": link_bytes, "achieved": round(link_bytes / (ms * 1e-3) / 1e9, 2),

@@ -25,7 +25,7 @@ constexpr int KT = 16;
 constexpr int LDT = KT + 1;  // padded k-stride of the LDS tiles (doubles)
 
 template <typename T, int OPA, int TN>
-__global__ __launch_bounds__(256, 3) void gemm_kernel(const tmf_gemm_desc* __restrict__ desc,
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const tmf_gemm_desc* __restrict__ desc,
                                                    const int32_t* __restrict__ tiles, double alpha, double beta,
                                                    const int32_t* __restrict__ run_if) {
   if (run_if != nullptr && *run_if == 0) return;   // conditional-launch scope (tmf_launch_condition)
@@ -51,9 +51,16 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const tmf_gemm_desc* __res
   const int wn0 = (TN == 64) ? (wave & 1) * 32 : 0;
   const int l15 = lane & 15, l4 = lane >> 4;
 
-  d4 acc[NP][MI][NI];
+  // Complex products by the 3M scheme: P1 = sum ar br, P2 = sum ai bi, P3 = sum (ar + ai)(br + bi);  Re = P1 - P2,
+  // Im = P3 - P1 - P2.  Three real MFMAs per complex multiply-add instead of four: the fp64 MFMA pipe is the bound of this
+  // kernel (PMC: busy 77 % of the time with four), its rate on this part is 32 flop / cycle / SIMD, and two extra
+  // v_add_f64 per fragment are free next to a 64-cycle MFMA.  Error bound: normwise the same as the 4M form
+  // (eps * sum |a||b| with a constant of 4 instead of 2 on the imaginary part); every product of the sweep is followed
+  // by an orthogonalisation or a difference of O(1) quantities, where the normwise bound is the one that matters.
+  constexpr int NACC = CP ? 3 : 1;
+  d4 acc[NACC][MI][NI];
 #pragma unroll
-  for (int p = 0; p < NP; ++p)
+  for (int p = 0; p < NACC; ++p)
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -155,9 +162,8 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const tmf_gemm_desc* __res
         for (int j = 0; j < NI; ++j) {
           acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[j], ar[i], acc[0][i][j], 0, 0, 0);
           if constexpr (CP) {
-            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bi[j], ai[i], acc[0][i][j], 0, 0, 0);
-            acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[j], ar[i], acc[1][i][j], 0, 0, 0);
-            acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[j], ai[i], acc[1][i][j], 0, 0, 0);
+            acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[j], ai[i], acc[1][i][j], 0, 0, 0);
+            acc[2][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[j] + bi[j], ar[i] + ai[i], acc[2][i][j], 0, 0, 0);
           }
         }
     }
@@ -180,7 +186,8 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(const tmf_gemm_desc* __res
         if (m < d.M && n < d.N) {
           T* c = C + (size_t)m + (size_t)n * d.ldc;
           if constexpr (CP) {
-            cd v = make_cd(alpha * acc[0][i][j][r], alpha * acc[1][i][j][r]);
+            const double p1 = acc[0][i][j][r], p2 = acc[1][i][j][r], p3 = acc[2][i][j][r];
+            cd v = make_cd(alpha * (p1 - p2), alpha * (p3 - p1 - p2));
             if (beta != 0.0) {
               cd o = *c;
               v.x = fma(beta, o.x, v.x);
