@@ -228,3 +228,102 @@ def schmidt_values_of_state(chi, cutoff=1e-12):
         out.append(s / np.linalg.norm(s))
     out.append(np.ones(1))
     return out
+
+
+# --------------------------------------------------------------------------------------
+# infinite MPS (gutzwiller.py:197-206, :230-242 / :392-398, :416-447; canonical form at :272 / :475)
+# --------------------------------------------------------------------------------------
+def group_and_project_cell(T, q, cell_charge, kind="ph", conserve="N", parity=0, q_left=0):
+    """Unit cell of an infinite fermionic MPS in B form: ``T[i]`` (2, chi_i, chi_{i+1}) with chi_L = chi_0, ``q[b]``
+    (b < L) the charge labels of bond b.  The labels of the closing bond are those of bond 0 plus ``cell_charge`` (what
+    ``mps.gauge_total_charge(qtotal=...)`` arranges, gutzwiller.py:212 / :398), and the masks of bond ``idx`` are those of
+    the finite case with ``idx_next = (idx + 1) % L`` (:234-238), i.e. the closing bond keeps the indices bond 0 keeps.
+    Returns (spin tensors of the cell, kept index arrays of the L/2 + 1 bonds, first = last)."""
+    L = len(T)
+    assert L % 2 == 0, "Odd-length MPS cannot represent an Abrikosov fermion Hilbert space"
+    keep = []
+    for idx in range(L // 2):
+        qq = np.asarray(q[2 * idx])
+        if kind == "ph":
+            m = qq % 2 == parity % 2
+        elif conserve == "N":
+            m = qq == q_left + idx
+        else:
+            m = qq % 2 == (q_left + idx) % 2
+        keep.append(np.nonzero(m)[0])
+    keep.append(keep[0])
+    pairs = ((0, 0), (1, 1)) if kind == "ph" else ((0, 1), (1, 0))
+    out = []
+    for j in range(L // 2):
+        a, b = np.asarray(T[2 * j]), np.asarray(T[2 * j + 1])
+        S = np.stack([a[p1] @ b[p2] for p1, p2 in pairs])
+        out.append(S[:, keep[j]][:, :, keep[j + 1]])
+    return out, keep
+
+
+def canonical_form_infinite(M, eps=1e-15):
+    """Right-canonical form of the infinite MPS with unit cell ``M[j]`` (2, chi_j, chi_{j+1}), chi_L = chi_0: the published
+    algorithm behind TeNPy's ``MPS.canonical_form_infinite1`` on dense matrices.  Dominant left / right eigenvectors l, r of
+    the transfer matrix of the cell on bond 0 (Gram matrices, trace 1), pushed through the cell to every bond; per bond
+    r_j = Y Y^H, l_j = X^H X (eigenvalues below ``eps`` dropped), X Y = U S V^H, and B_j = (Y_j V_j)^+ M_j (Y_{j+1} V_{j+1})
+    up to the norm.  Returns (B list, S list (L + 1 entries, first = last), eta = dominant eigenvalue = norm^2 per cell)."""
+    L = len(M)
+    M = [np.asarray(m, dtype=np.result_type(m.dtype, float)) for m in M]
+    chi = M[0].shape[1]
+
+    def push_r(j, r):      # right Gram matrix from bond j+1 to bond j
+        return sum(M[j][p] @ r @ M[j][p].conj().T for p in range(2))
+
+    def push_l(j, l_):     # left Gram matrix from bond j to bond j+1
+        return sum(M[j][p].conj().T @ l_ @ M[j][p] for p in range(2))
+
+    def cell(push, order, x):
+        for j in order:
+            x = push(j, x)
+        return x
+
+    def dominant(push, order):
+        E = np.zeros((chi * chi, chi * chi), complex)
+        for k in range(chi * chi):
+            e = np.zeros(chi * chi, complex)
+            e[k] = 1
+            E[:, k] = cell(push, order, e.reshape(chi, chi)).reshape(-1)
+        w, v = np.linalg.eig(E)
+        i = int(np.argmax(np.abs(w)))
+        x = v[:, i].reshape(chi, chi)
+        x = x / np.trace(x)
+        assert np.abs(x - x.conj().T).max() < 1e-8 * np.abs(x).max(), "transfer matrix not injective"
+        return w[i], 0.5 * (x + x.conj().T)
+
+    eta_r, r0 = dominant(push_r, range(L - 1, -1, -1))
+    eta_l, l0 = dominant(push_l, range(L))
+    assert abs(eta_r - eta_l) < 1e-9 * abs(eta_r)
+    eta = float(np.real(eta_r))
+    ls, rs = [l0], [None] * L + [r0]
+    for j in range(L - 1):
+        ls.append(push_l(j, ls[-1]))
+    for j in range(L - 1, 0, -1):
+        rs[j] = push_r(j, rs[j + 1])
+    rs[0] = r0
+    G, Gi, S = [], [], []
+    for j in range(L):
+        wr, ur = np.linalg.eigh(rs[j] / np.trace(rs[j]).real)
+        k = wr > eps
+        Y, Yi = ur[:, k] * np.sqrt(wr[k]), (ur[:, k] / np.sqrt(wr[k])).conj().T
+        wl, ul = np.linalg.eigh(ls[j] / np.trace(ls[j]).real)
+        k = wl > eps
+        X = (ul[:, k] * np.sqrt(wl[k])).conj().T
+        U, s, Vh = np.linalg.svd(X @ Y, full_matrices=False)
+        k = s > np.sqrt(eps) * np.linalg.norm(s)
+        V = Vh.conj().T[:, k]
+        G.append(Y @ V)
+        Gi.append(V.conj().T @ Yi)
+        S.append(s[k] / np.linalg.norm(s[k]))
+    G.append(G[0])
+    S.append(S[0])
+    B = []
+    for j in range(L):
+        b = np.stack([Gi[j] @ M[j][p] @ G[j + 1] for p in range(2)])
+        nb = np.sqrt(np.einsum("pab,pab->", b, b.conj()).real / b.shape[1])
+        B.append(b / nb)
+    return B, S, eta

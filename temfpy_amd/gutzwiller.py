@@ -1,4 +1,4 @@
-"""Gutzwiller projections of a finite fermionic MPS to a spin-1/2 chain (temfpy/gutzwiller.py), on MI355X.
+"""Gutzwiller projections of a finite or infinite fermionic MPS to a spin-1/2 chain (temfpy/gutzwiller.py), on MI355X.
 
 ``abrikosov`` (gutzwiller.py:95-281) and ``abrikosov_ph`` (:284-486) keep the reference's names, keyword
 arguments, defaults, warnings and exceptions.  They take the result of ``slater.C_to_MPS`` /
@@ -31,9 +31,12 @@ Everything numerical runs on the GPU through the C ABI (``include/temfpy_hip.h``
   In both methods Schmidt values below ``cutoff`` are zeroed on the device (shapes stay fixed: all descriptors
   are built once, no host round trip inside a sweep) and compacted on the host.
 
-Finite MPS only: for the infinite-MPS input the reference also accepts (``canonical_form_infinite1``, gutzwiller.py:467-478)
-the entry points raise NotImplementedError; its ``q_left`` / ``offset`` / ``parity`` arguments reduce to the warnings the
-reference emits for finite input.
+Infinite MPS (gutzwiller.py:197-206, ``canonical_form_infinite1`` at :272 / :475): the unit cell ``iMPS.iMPSData`` returned by
+``C_to_iMPS`` / ``H_to_iMPS`` is projected with the reference's masks (``q_left`` required for ``abrikosov``; ``parity`` and
+``offset`` for ``abrikosov_ph``) and returned as :class:`SpiniMPSData`.  The cell is closed by the dominant eigenvectors of
+its transfer matrix (Arnoldi: Krylov bookkeeping on the host, every application of the cell on the GPU), a boundary gauge
+from two Jacobi launches, and then canonicalised by the finite algorithm between the fixed boundaries (``_close_cell``).
+For finite input ``q_left`` / ``offset`` / ``parity`` reduce to the warnings the reference emits.
 """
 from __future__ import annotations
 
@@ -48,6 +51,11 @@ import numpy as np
 from . import _native as nat
 
 logger = logging.getLogger(__name__)
+
+# Infinite MPS: the fixed points of the transfer matrix are Gram matrices, so Schmidt values below sqrt(machine epsilon)
+# are rounding noise (TeNPy's canonical_form_infinite1 drops Gram eigenvalues below 2 eps for the same reason).
+_INF_GRAM_EPS = 1e-15
+_INF_SCHMIDT_EPS = 3e-8
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -116,6 +124,22 @@ class SpinMPSData:
                 B = npc.Array.from_ndarray_trivial(T.transpose(1, 0, 2), labels=["vL", "p", "vR"])
             Bs.append(B)
         return networks.mps.MPS([site] * self.L, Bs, self._lam, form="B", unit_cell_width=self.unit_cell_width)
+
+
+class SpiniMPSData(SpinMPSData):
+    """Unit cell of an infinite spin-1/2 MPS in right-canonical form (the ``bc='infinite'`` result of gutzwiller.py:272 /
+    :475).  As :class:`SpinMPSData`, with ``lam[L] == lam[0]`` and ``charges[L] == charges[0]``; the blocks of the last
+    site obey q_l + 2 S^z(p) = q_r + ``cell_charge`` (2 S^z of one cell), as in ``iMPS.iMPSData``.  ``norm`` is the norm of
+    the projected state per unit cell (square root of the dominant transfer-matrix eigenvalue)."""
+
+    bc = "infinite"
+
+    def __init__(self, blocks, lam, charges, conserve, norm, unit_cell_width, cell_charge, timings=None):
+        super().__init__(blocks, lam, charges, conserve, norm, unit_cell_width, True, timings)
+        self.cell_charge = cell_charge
+
+    def to_tenpy(self):
+        raise NotImplementedError("TeNPy export of the infinite spin MPS is not written (physics-tenpy is not installed here)")
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -232,6 +256,26 @@ def _fermions_from_dense(T, q, lam_c, oc, conserve):
     return f
 
 
+def _fermions_from_imps(imps):
+    """Adapter for the unit cell of an infinite MPS (``iMPS.iMPSData``, all tensors in B form).  The labels of the last
+    bond are those of bond 0 plus the charge of one cell, so that q_l + p = q_r holds on every site
+    (TeNPy: ``mps.gauge_total_charge(qtotal=mps.get_total_charge())``, gutzwiller.py:202-212 / :392-398)."""
+    kind = getattr(imps, "conserve", None)
+    if kind not in ("N", "parity"):
+        raise ValueError(f"FermionSite must conserve either 'N' or 'parity', found {kind!r}")        # gutzwiller.py:172-176
+    if any(f_ != "B" for f_ in imps.form):
+        raise ValueError("the infinite MPS is not in right-canonical form")
+    q = [np.asarray(x, np.int64) for x in imps.charges[: imps.L]]
+    last = np.asarray(imps.charges[0], np.int64) + int(imps.cell_charge)
+    q.append(last % 2 if kind == "parity" else last)
+    if kind == "parity":
+        q = [x % 2 for x in q]
+    f = _fermions_from_dense(imps.dense_tensors(), q, np.ones(len(q[imps.L])), imps.L, kind)
+    f.cell_charge = int(imps.cell_charge)
+    f.infinite = True
+    return f
+
+
 def infer_parities(T, tol=1e-9):
     """Fermion parity to the left of every index of every bond of a parity-conserving MPS given as dense tensors
     T[i] (2, chi_l, chi_r): parity(right index) = parity(left index) + p (mod 2), read off the dominant entry of
@@ -257,9 +301,7 @@ def _as_fermions(mps):
     if isinstance(mps, _Fermions):
         return mps
     if isinstance(mps, iMPSData):
-        raise NotImplementedError("Gutzwiller projection of an infinite MPS (gutzwiller.py:467-478, TeNPy "
-                                  "canonical_form_infinite1) is not built; project the finite MPS of the two chains "
-                                  "and convert with iMPS.MPS_to_iMPS instead")
+        return _fermions_from_imps(mps)
     if isinstance(mps, MPSData):
         return _fermions_from_slater(mps)
     if isinstance(mps, SpinMPSData):      # (a projected spin chain as input of iMPS.MPS_to_iMPS: 2 S^z blocks or one trivial sector)
@@ -330,10 +372,49 @@ def _gemm_tiles(d):
     return tiles, tn
 
 
+def _dominant_eigenpair(apply, v0, tol=1e-13, krylov=24, restarts=400):
+    """Eigenvalue of largest modulus and its eigenvector of the linear map `apply` (host vector -> host vector) by restarted
+    Arnoldi iteration: the role of scipy's ARPACK behind TeNPy's ``TransferMatrix.eigenvectors``.  Only the Krylov
+    bookkeeping (dot products over <= `krylov` vectors, one small Hessenberg eigenproblem per restart) is done here."""
+    v = np.asarray(v0)
+    v = v / np.linalg.norm(v)
+    m = min(krylov, v.size)
+    for _ in range(restarts):
+        V = np.zeros((m + 1, v.size), v.dtype)
+        H = np.zeros((m + 1, m), v.dtype)
+        V[0], used, beta = v, m, 0.0
+        for k in range(m):
+            w = apply(V[k])
+            for _pass in range(2):                     # classical Gram-Schmidt, twice
+                h = V[: k + 1].conj() @ w
+                w = w - h @ V[: k + 1]
+                H[: k + 1, k] += h
+            beta = float(np.linalg.norm(w))
+            H[k + 1, k] = beta
+            if beta <= 1e-300 or k + 1 == v.size:
+                used, beta = k + 1, (beta if k + 1 < v.size else 0.0)
+                break
+            V[k + 1] = w / beta
+        ev, Yv = np.linalg.eig(H[:used, :used])
+        i = int(np.argmax(np.abs(ev)))
+        theta, y = ev[i], Yv[:, i]
+        if v.dtype.kind != "c":
+            if abs(theta.imag) > 1e-9 * abs(theta):
+                y, theta = y.real, theta.real          # (a complex pair in front: keep iterating with the real part)
+            else:
+                y, theta = y.real, theta.real
+        res = abs(beta * y[-1]) / max(np.linalg.norm(y), 1e-300)
+        v = y @ V[:used]
+        v = v / np.linalg.norm(v)
+        if res <= tol * abs(theta):
+            return complex(theta), v
+    raise np.linalg.LinAlgError("Arnoldi iteration for the dominant eigenvector of the transfer matrix did not converge")
+
+
 class _Projector:
     """Builds and runs the device pipeline for one projection (see the module docstring)."""
 
-    def __init__(self, fer, pairs, keep_fn, cutoff, device, method="parallel"):
+    def __init__(self, fer, pairs, keep_fn, cutoff, device, method="parallel", shift=None):
         import torch
 
         if not torch.cuda.is_available():
@@ -344,6 +425,13 @@ class _Projector:
         if method not in ("sequential", "parallel"):
             raise ValueError(f"`method` must be 'sequential' or 'parallel', got {method!r}")
         self.method = method
+        # infinite MPS: `shift` maps a sector label of the last bond of the unit cell to the label of the same sector on
+        # bond 0 (the charge of one cell subtracted); the cell is then closed by the fixed points of its transfer matrix
+        self.shift = shift
+        if shift is not None:
+            if method != "parallel":
+                raise ValueError("infinite MPS: only method='parallel' is available")
+            self.cutoff = max(cutoff, _INF_SCHMIDT_EPS)
         self.cplx = np.dtype(fer.dtype).kind == "c"
         self.dt = nat.TMF_C128 if self.cplx else nat.TMF_F64
         self.np_dt = np.dtype(np.complex128 if self.cplx else np.float64)
@@ -379,19 +467,38 @@ class _Projector:
         byj = [[] for _ in range(Ls)]
         for x in sb:
             byj[x[0]].append(x)
-        alive = [set() for _ in range(Ls + 1)]
-        alive[0] = set(kept[0])
-        for j in range(Ls):
-            alive[j + 1] = {x[3] for x in byj[j] if x[2] in alive[j]}
-        back = [set() for _ in range(Ls + 1)]
-        back[Ls] = alive[Ls]
-        for j in range(Ls - 1, -1, -1):
-            back[j] = {x[2] for x in byj[j] if x[3] in back[j + 1]} & alive[j]
+        if self.shift is None:
+            alive = [set() for _ in range(Ls + 1)]
+            alive[0] = set(kept[0])
+            for j in range(Ls):
+                alive[j + 1] = {x[3] for x in byj[j] if x[2] in alive[j]}
+            back = [set() for _ in range(Ls + 1)]
+            back[Ls] = alive[Ls]
+            for j in range(Ls - 1, -1, -1):
+                back[j] = {x[2] for x in byj[j] if x[3] in back[j + 1]} & alive[j]
+        else:      # the cell repeats: a sector survives if it lies on a closed path through the cell
+            alive = [set(k) for k in kept]
+            while True:
+                before = sum(len(a) for a in alive)
+                alive[0] &= {self.shift(c) for c in alive[Ls]}
+                alive[Ls] = {c for c in alive[Ls] if self.shift(c) in alive[0]}
+                for j in range(Ls):
+                    alive[j + 1] &= {x[3] for x in byj[j] if x[2] in alive[j]}
+                for j in range(Ls - 1, -1, -1):
+                    alive[j] &= {x[2] for x in byj[j] if x[3] in alive[j + 1]}
+                if sum(len(a) for a in alive) == before:
+                    break
+            back = alive
+            for c in alive[Ls]:
+                assert kept[Ls][c] == kept[0][self.shift(c)], "the two ends of the unit cell carry the same bond"
         self.sb = [[x for x in byj[j] if x[2] in back[j] and x[3] in back[j + 1]] for j in range(Ls)]
         self.sect = [{c: kept[j][c] for c in sorted(back[j])} for j in range(Ls + 1)]   # bond -> {c: n}
         self.tabs, self.Ls = tabs, Ls
         if any(len(s) == 0 for s in self.sect):
             raise ValueError("the projected state vanishes: no charge sector connects the two ends of the chain")
+        if self.shift is not None:
+            self.end_of = {self.shift(c): c for c in self.sect[Ls]}      # bond-0 label -> label on the last bond
+            self.sect[Ls] = {self.end_of[q]: n for q, n in self.sect[0].items()}      # same index order on both copies
 
     # ---- run ------------------------------------------------------------------------------------
     def run(self, canonical=True):
@@ -457,8 +564,13 @@ class _Projector:
                 cnt_index[(j, c)] = len(cnt_index)
         n_sec_tot = len(cnt_index)
         for b_, tab in ((0, Rb), (Ls, Lb)):
-            if len(self.sect[b_]) != 1 or next(iter(self.sect[b_].values())) != 1:
+            if self.shift is None and (len(self.sect[b_]) != 1 or next(iter(self.sect[b_].values())) != 1):
                 raise ValueError("the ends of the chain must carry a single state")
+        if self.shift is not None:     # second copies of the first and last tensor of the cell (boundary gauge, _close_cell)
+            Tping = {k: ar.take(self.sect[k[0]][k[2]] * self.sect[k[0] + 1][x3]) for k, x3 in
+                     (((x[0], x[1], x[2]), x[3]) for x in self.sb[Ls - 1])}
+            Tpong = {k: ar.take(self.sect[k[0]][k[2]] * self.sect[k[0] + 1][x3]) for k, x3 in
+                     (((x[0], x[1], x[2]), x[3]) for x in self.sb[0])}
 
         d_ar = torch.zeros(ar.n, dtype=torch.complex128 if self.cplx else torch.float64, device=self.device)
         base = d_ar.data_ptr()
@@ -529,8 +641,16 @@ class _Projector:
 
         # ================= descriptor tables =================
         t1 = time.perf_counter()
-        d_ar[Rb[0][next(iter(self.sect[0]))]] = 1.0           # R of the (empty) left end, L of the right end
-        d_ar[Lb[Ls][next(iter(self.sect[Ls]))]] = 1.0
+        if self.shift is None:
+            d_ar[Rb[0][next(iter(self.sect[0]))]] = 1.0           # R of the (empty) left end, L of the right end
+            d_ar[Lb[Ls][next(iter(self.sect[Ls]))]] = 1.0
+            cell = None
+        else:
+            from types import SimpleNamespace
+
+            cell = self._close_cell(SimpleNamespace(P=P, d_ar=d_ar, Toff=Toff, Rb=Rb, Lb=Lb, Vinfo=Vinfo, Winfo=Winfo, Yq=Yq, Wo=Wo,
+                                                    stream=stream, keep=keep_alive, Tping=Tping, Tpong=Tpong))
+            self.timings["fixed points"] = time.perf_counter() - t1
         G, CP, QR = _Launches(nat.gemm_desc), _Launches(nat.copy_desc), _Launches(nat.qr_desc)
         steps1, steps2 = [], []
         # rightward sweep: V_j = R_j T_j (left-merged), QR in place, R -> bond j+1
@@ -730,7 +850,10 @@ class _Projector:
                 copy(cb_, s2)
                 qr(qb, s2)
             cur.wait_stream(side)
-            norm = abs(complex(d_ar[Lb[0][next(iter(self.sect[0]))]].item()))       # (host sync: both sweeps done)
+            if cell is None:
+                norm = abs(complex(d_ar[Lb[0][next(iter(self.sect[0]))]].item()))   # (host sync: both sweeps done)
+            else:
+                norm = float(np.sqrt(cell["eta"]))      # norm of the projected state per unit cell
             self.timings["sweeps"] = time.perf_counter() - t2
             if not norm > 0.0 or not np.isfinite(norm):
                 raise ValueError("the Gutzwiller projection annihilates the state")
@@ -741,6 +864,24 @@ class _Projector:
             d_sw = torch.zeros(n_sec_tot, dtype=torch.int32, device=self.device)
             nat.check(lib.tmf_jacobi_compact_batched(self.dt, tabs_d["jc"].data_ptr(), n_sec_tot, int(jd["p"].max()),
                                                      d_sw.data_ptr(), s1), "tmf_jacobi_compact_batched")
+            if cell is not None:
+                # The bond that closes the cell is already in Schmidt form (_close_cell: left environment diag(lam^2), right
+                # environment 1), and both of its copies must carry the SAME basis: on the last bond the identity, on bond 0
+                # the unitary L_0 / sqrt(eta) the leftward sweep arrived with (C_0 = diag(lam) L_0 / sqrt(eta)).
+                ident, g0 = {}, []
+                for q, n in self.sect[0].items():
+                    k, ql = cell["count"][q], self.end_of[q]
+                    e = np.zeros((n, n), self.np_dt)
+                    e[np.arange(k), np.arange(k)] = 1.0
+                    d_ar[Vzb[Ls][ql]: Vzb[Ls][ql] + n * n] = torch.from_numpy(e.reshape(-1)).to(self.device)
+                    ident[q] = torch.from_numpy(np.eye(n, dtype=self.np_dt).reshape(-1).copy()).to(self.device)
+                    g0.append((P(Lb[0][q]), ident[q].data_ptr(), P(Vzb[0][q]), n, n, n, n, n, n))
+                    for b_, c_ in ((0, q), (Ls, ql)):
+                        d_sv[So[b_][c_]: So[b_][c_] + n] = 0.0
+                        d_sv[So[b_][c_]: So[b_][c_] + k] = torch.from_numpy(np.ascontiguousarray(cell["lam"][q])).to(self.device)
+                        d_cnt[cnt_index[(b_, c_)]] = k
+                keep_alive.append(ident)
+                self._gemm_now(g0, 1, s1, keep_alive, alpha=1.0 / norm)
             gemm(tail[1], s1)
             gemm(tail[2], s1, opA=1)
             torch.cuda.synchronize(self.device)
@@ -802,6 +943,268 @@ class _Projector:
         del keep_alive
         return blocks, lam, ch, norm
 
+    # ---- infinite MPS: closing the unit cell ----------------------------------------------------------
+    def _gemm_table(self, G, keep):
+        """Uploads the descriptor table of the launches collected in `G`; returns run(i, stream, opA, alpha)."""
+        torch, lib = self.torch, self.lib
+        gt = G.table()
+        tiles, span, tile_n, to = [], [], [], 0
+        for (o, n) in G.spans:
+            tl, tn = _gemm_tiles(gt[o: o + n])
+            tiles.append(tl)
+            span.append((to, len(tl)))
+            tile_n.append(tn)
+            to += len(tl)
+        tiles = np.concatenate(tiles) if tiles else np.zeros((0, 4), np.int32)
+        d_g = torch.from_numpy(gt.view(np.uint8).reshape(-1).copy() if gt.size else np.zeros(48, np.uint8)).to(self.device)
+        d_t = torch.from_numpy(tiles.reshape(-1).copy() if tiles.size else np.zeros(4, np.int32)).to(self.device)
+        keep += [d_g, d_t]
+
+        def run(i, st, opA=0, alpha=1.0):
+            (o, n), (t_o, t_n) = G.spans[i], span[i]
+            if t_n:
+                nat.check(lib.tmf_gemm_batched(self.dt, opA, alpha, 0.0, d_g.data_ptr() + 48 * o, d_t.data_ptr() + 16 * t_o,
+                                               t_n, tile_n[i], st), "tmf_gemm_batched")
+        return run
+
+    def _close_cell(self, c):
+        """Boundary of the unit cell of an infinite MPS (what TeNPy's ``MPS.canonical_form_infinite1`` obtains from the
+        dominant eigenvectors of its ``TransferMatrix``, called at gutzwiller.py:272 / :475).
+
+        The projected cell tensors T_0 .. T_{Ls-1} define the transfer maps l -> sum_s T_s^H l T_s (left Gram matrix,
+        pushed through the cell to the right) and r -> sum_s T_s r T_s^H (right Gram matrix, pushed to the left).  Their
+        dominant eigenvectors on the bond that closes the cell are found by Arnoldi iteration: the Krylov bookkeeping runs
+        on the host, every application of the cell is 2 Ls (resp. 3 Ls) batched launches over all charge sectors.  With
+        l = U_l D_l U_l^H, r = U_r D_r U_r^H (Jacobi, one launch), M = D_l^1/2 U_l^H U_r D_r^1/2 = U S V^H (Jacobi), the gauge
+        G = U_r D_r^1/2 V on the last tensor and its pseudo-inverse V^H D_r^-1/2 U_r^H on the first make the right environment
+        of that bond the identity and the left one diag(S^2): from there the cell is a finite chain between known
+        boundaries, which the two QR sweeps and the per-bond SVDs of the finite algorithm canonicalise."""
+        torch, lib, Ls, el = self.torch, self.lib, self.Ls, self.elem
+        P, d_ar, Toff, Rb, Lb, stream, keep = c.P, c.d_ar, c.Toff, c.Rb, c.Lb, c.stream, c.keep
+        sec0 = list(self.sect[0])
+        secL = [self.end_of[q] for q in sec0]
+        n0 = np.array([self.sect[0][q] for q in sec0], np.int64)
+        if int(n0.max()) > 512:
+            raise NotImplementedError(f"a charge sector of the cell boundary holds {int(n0.max())} > 512 states")
+        nsec = len(sec0)
+        sq_off = np.concatenate(([0], np.cumsum((n0 * n0 + 1) & ~1)))
+        tdt = d_ar.dtype
+
+        def room(count):
+            t = torch.zeros(int(count) + 2, dtype=tdt, device=self.device)
+            keep.append(t)
+            return t
+
+        # ---- merged copies of the tensors: (s, c) rows x c' (left-merged) and ((s, c') x c)^H (right-merged) -----------
+        TVm, TWh, cp = {}, {}, []
+        for j in range(Ls):
+            for cp_, (voff, m, rows) in c.Vinfo[j].items():
+                TVm[(j, cp_)] = room(m * self.sect[j + 1][cp_]).data_ptr()
+            for q, v in c.Winfo[j].items():
+                TWh[(j, q)] = room(v[1] * self.sect[j][q]).data_ptr()
+            for x in self.sb[j]:
+                _, sg, q, cp_, *_ = x
+                n, npr = self.sect[j][q], self.sect[j + 1][cp_]
+                m, rows = c.Vinfo[j][cp_][1], c.Vinfo[j][cp_][2]
+                w, cols = c.Winfo[j][q][1], c.Winfo[j][q][2]
+                src = P(Toff[(j, sg, q)])
+                cp.append((src, TVm[(j, cp_)] + el * rows[(sg, q)], n, npr, n, m, 0, 0))
+                cp.append((src, TWh[(j, q)] + el * cols[(sg, cp_)], n, npr, n, w, 3 if self.cplx else 1, 0))
+        self._copy(np.array(cp, nat.copy_desc), stream, keep)
+        # ---- launch tables of the two transfer maps ---------------------------------------------------------------
+        G, CPY = _Launches(nat.gemm_desc), _Launches(nat.copy_desc)
+        left, right = [], []
+        for j in range(Ls):
+            ga, gb = [], []
+            for x in self.sb[j]:
+                _, sg, q, cp_, *_ = x
+                voff, m, rows = c.Vinfo[j][cp_]
+                n, npr = self.sect[j][q], self.sect[j + 1][cp_]
+                ga.append((P(Rb[j][q]), P(Toff[(j, sg, q)]), P(voff + rows[(sg, q)]), n, npr, n, n, n, m))
+            for cp_, (voff, m, rows) in c.Vinfo[j].items():
+                npr = self.sect[j + 1][cp_]
+                gb.append((TVm[(j, cp_)], P(voff), P(Rb[j + 1][cp_]), npr, npr, m, m, m, npr))
+            left.append((G.add(_gemm_recs(ga)), G.add(_gemm_recs(gb))))
+        for j in range(Ls - 1, -1, -1):
+            ga, gb, cpy, wl, o = [], [], [], {}, 0
+            for q, v in c.Winfo[j].items():
+                wl[q] = o
+                o += (self.sect[j][q] * v[1] + 1) & ~1
+            for x in self.sb[j]:
+                _, sg, q, cp_, *_ = x
+                n, npr = self.sect[j][q], self.sect[j + 1][cp_]
+                cols = c.Winfo[j][q][2]
+                ga.append((P(Toff[(j, sg, q)]), P(Lb[j + 1][cp_]), P(c.Wo + wl[q] + n * cols[(sg, cp_)]), n, npr, npr, n, npr, n))
+            for q, v in c.Winfo[j].items():
+                n, w = self.sect[j][q], v[1]
+                cpy.append((P(c.Wo + wl[q]), P(c.Yq[j][q]), n, w, n, w, 3 if self.cplx else 1, 0))
+                gb.append((P(c.Yq[j][q]), TWh[(j, q)], P(Lb[j][q]), n, n, w, w, w, n))
+            right.append((G.add(_gemm_recs(ga)), CPY.add(np.array(cpy, nat.copy_desc)), G.add(_gemm_recs(gb))))
+        gemm = self._gemm_table(G, keep)
+        stage = room(sq_off[-1])
+        sc = {}
+        for name, dst_tab, dst_sec, src_tab, src_sec in (("l", Rb[0], sec0, Rb[Ls], secL), ("r", Lb[Ls], secL, Lb[0], sec0)):
+            put, get = np.zeros(nsec, nat.copy_desc), np.zeros(nsec, nat.copy_desc)
+            for i in range(nsec):
+                n = int(n0[i])
+                put[i] = (stage.data_ptr() + el * int(sq_off[i]), P(dst_tab[dst_sec[i]]), n, n, n, n, 0, 0)
+                get[i] = (P(src_tab[src_sec[i]]), stage.data_ptr() + el * int(sq_off[i]), n, n, n, n, 0, 0)
+            sc[name] = (CPY.add(put), CPY.add(get))
+        d_cp = torch.from_numpy(CPY.table().view(np.uint8).reshape(-1).copy()).to(self.device)
+        keep.append(d_cp)
+        cpt = CPY.table()
+        cp_max = [int((_cdiv(cpt[o: o + n]["rows"].astype(np.int64), 32) * _cdiv(cpt[o: o + n]["cols"].astype(np.int64), 32)).max())
+                  for o, n in CPY.spans]
+
+        def copy(i):
+            o, n = CPY.spans[i]
+            nat.check(lib.tmf_copy_blocks_batched(self.dt, d_cp.data_ptr() + 40 * o, n, cp_max[i], stream), "tmf_copy_blocks_batched")
+
+        self.cell_applications = 0
+
+        def apply(which, vec):
+            self.cell_applications += 1
+            stage[: vec.size].copy_(torch.from_numpy(np.ascontiguousarray(vec, self.np_dt)))
+            copy(sc[which][0])
+            if which == "l":
+                for a, b in left:
+                    gemm(a, stream)
+                    gemm(b, stream, opA=1)
+            else:
+                for a, cc, b in right:
+                    gemm(a, stream)
+                    copy(cc)
+                    gemm(b, stream, opA=1)
+            copy(sc[which][1])
+            return stage[: vec.size].cpu().numpy()
+
+        v0 = np.zeros(int(sq_off[-1]), self.np_dt)
+        for i in range(nsec):
+            n = int(n0[i])
+            v0[sq_off[i]: sq_off[i] + n * n] = np.eye(n).reshape(-1)
+        eta_l, lv = _dominant_eigenpair(lambda v: apply("l", v), v0)
+        eta_r, rv = _dominant_eigenpair(lambda v: apply("r", v), v0)
+        eta = 0.5 * (eta_l + eta_r)
+        if not (abs(eta_l - eta_r) <= 1e-8 * abs(eta) and abs(eta.imag) <= 1e-8 * abs(eta) and eta.real > 0):
+            raise ValueError(f"the transfer matrix of the projected unit cell has no unique positive dominant eigenvalue "
+                             f"(left {eta_l}, right {eta_r}): the projected state vanishes or is not injective")
+        eta = float(eta.real)
+
+        def gram(vec, what):
+            out, tr = [], 0.0
+            for i in range(nsec):
+                n = int(n0[i])
+                out.append(vec[sq_off[i]: sq_off[i] + n * n].reshape(n, n, order="F"))
+                tr = tr + np.trace(out[-1])
+            out = [b / tr for b in out]                      # fixes the phase as well: a Gram matrix has a positive trace
+            herm = max(np.abs(b - b.conj().T).max() for b in out)
+            if herm > 1e-7 * max(np.abs(b).max() for b in out):
+                raise ValueError(f"the dominant {what} eigenvector of the transfer matrix is not Hermitian ({herm:.1e}): "
+                                 "the projected infinite MPS is not injective")
+            return [0.5 * (b + b.conj().T) for b in out]
+
+        lb, rb = gram(lv, "left"), gram(rv, "right")
+        tau = float(sum(np.sum(a * b.T).real for a, b in zip(lb, rb)))        # tr(l r) = sum of the squared Schmidt weights
+        # ---- eigen-decompositions of l and r: one Jacobi launch -----------------------------------------------------
+        X = room(2 * sq_off[-1])
+        Uv = room(2 * sq_off[-1])
+        for k_, bl in enumerate((lb, rb)):
+            h = np.zeros(int(sq_off[-1]), self.np_dt)
+            for i, b in enumerate(bl):
+                h[sq_off[i]: sq_off[i] + b.size] = b.reshape(-1, order="F")
+            X[k_ * int(sq_off[-1]): (k_ + 1) * int(sq_off[-1])].copy_(torch.from_numpy(h))
+        s_off = np.concatenate(([0], np.cumsum(n0)))
+        d_s = torch.zeros(2 * int(s_off[-1]) + 1, dtype=torch.float64, device=self.device)
+        d_c = torch.zeros(2 * nsec, dtype=torch.int32, device=self.device)
+        d_sw = torch.zeros(2 * nsec, dtype=torch.int32, device=self.device)
+        jd = np.zeros(2 * nsec, nat.jacobi_desc)
+        for k_ in range(2):
+            for i in range(nsec):
+                n, o = int(n0[i]), el * (k_ * int(sq_off[-1]) + int(sq_off[i]))
+                jd[k_ * nsec + i] = (X.data_ptr() + o, 0, Uv.data_ptr() + o, d_s.data_ptr() + 8 * (k_ * int(s_off[-1]) + int(s_off[i])),
+                                     d_c.data_ptr() + 4 * (k_ * nsec + i), _INF_GRAM_EPS ** 2, n, n, n, n)
+        d_jd = torch.from_numpy(jd.view(np.uint8).reshape(-1).copy()).to(self.device)
+        nat.check(lib.tmf_jacobi_compact_batched(self.dt, d_jd.data_ptr(), 2 * nsec, int(n0.max()), d_sw.data_ptr(), stream),
+                  "tmf_jacobi_compact_batched")
+        nat.check_jacobi_sweeps(d_sw.cpu().numpy(), "Jacobi eigen-decomposition of the transfer-matrix fixed points")
+        h_s, h_c = d_s.cpu().numpy(), d_c.cpu().numpy()
+        # (a Gram matrix is positive: its singular values are its eigenvalues and sum to its trace)
+        for k_, what in enumerate(("left", "right")):
+            tot = float(h_s[k_ * int(s_off[-1]): (k_ + 1) * int(s_off[-1])].sum())
+            if abs(tot - 1.0) > 1e-6:
+                raise ValueError(f"the dominant {what} eigenvector of the transfer matrix is not positive (sum of |eigenvalues| = "
+                                 f"{tot:.9f} for trace 1): the projected infinite MPS is not injective")
+        # ---- M = D_l^1/2 U_l^H U_r D_r^1/2 and its SVD ---------------------------------------------------------------
+        Dh = np.zeros(3 * int(sq_off[-1]), self.np_dt)
+        for i in range(nsec):
+            n = int(n0[i])
+            for k_, (src, pw) in enumerate(((0, 0.5), (1, 0.5), (1, -0.5))):
+                ev = h_s[src * int(s_off[-1]) + int(s_off[i]): src * int(s_off[-1]) + int(s_off[i]) + n]
+                kk = int(h_c[src * nsec + i])
+                d = np.zeros(n)
+                d[:kk] = ev[:kk] ** pw
+                Dh[k_ * int(sq_off[-1]) + int(sq_off[i]): k_ * int(sq_off[-1]) + int(sq_off[i]) + n * n] = np.diag(d).reshape(-1)
+        D = room(Dh.size)
+        D[: Dh.size].copy_(torch.from_numpy(Dh))
+        A1, Y, Yi, M, Wk, Vs, Gm, Hm = (room(sq_off[-1]) for _ in range(8))
+        at = lambda t, i, k_=0: t.data_ptr() + el * (k_ * int(sq_off[-1]) + int(sq_off[i]))      # noqa: E731
+        it = []
+        for i in range(nsec):
+            n = int(n0[i])
+            it += [(at(Uv, i, 0), at(D, i, 0), at(A1, i), n, n, n, n, n, n), (at(Uv, i, 1), at(D, i, 1), at(Y, i), n, n, n, n, n, n),
+                   (at(Uv, i, 1), at(D, i, 2), at(Yi, i), n, n, n, n, n, n)]
+        self._gemm_now(it, 0, stream, keep)
+        self._gemm_now([(at(A1, i), at(Y, i), at(M, i), int(n0[i]), int(n0[i]), int(n0[i]), int(n0[i]), int(n0[i]), int(n0[i]))
+                        for i in range(nsec)], 1, stream, keep)
+        jd = np.zeros(nsec, nat.jacobi_desc)
+        for i in range(nsec):
+            n = int(n0[i])
+            jd[i] = (at(M, i), at(Wk, i), at(Vs, i), d_s.data_ptr() + 8 * int(s_off[i]), d_c.data_ptr() + 4 * i,
+                     _INF_SCHMIDT_EPS ** 2 * tau, n, n, n, n)
+        d_jd2 = torch.from_numpy(jd.view(np.uint8).reshape(-1).copy()).to(self.device)
+        nat.check(lib.tmf_jacobi_compact_batched(self.dt, d_jd2.data_ptr(), nsec, int(n0.max()), d_sw.data_ptr(), stream),
+                  "tmf_jacobi_compact_batched")
+        nat.check_jacobi_sweeps(d_sw[:nsec].cpu().numpy(), "Jacobi SVD of the boundary bond of the unit cell")
+        h_s, h_c = d_s.cpu().numpy(), d_c.cpu().numpy()
+        keep += [d_jd, d_jd2, d_s, d_c, d_sw]
+        count = {q: int(h_c[i]) for i, q in enumerate(sec0)}
+        lam = {q: h_s[int(s_off[i]): int(s_off[i]) + count[q]].copy() for i, q in enumerate(sec0)}
+        tot = np.sqrt(sum(float((v ** 2).sum()) for v in lam.values()))
+        if not tot > 0:
+            raise ValueError("the Gutzwiller projection annihilates the state")
+        lam = {q: v / tot for q, v in lam.items()}
+        # ---- gauge matrices, boundary tensors, boundary values of the two sweeps --------------------------------------
+        it = []
+        for i in range(nsec):
+            n = int(n0[i])
+            it += [(at(Y, i), at(Vs, i), at(Gm, i), n, n, n, n, n, n), (at(Yi, i), at(Vs, i), at(Hm, i), n, n, n, n, n, n)]
+        self._gemm_now(it, 0, stream, keep)
+        idx0 = {q: i for i, q in enumerate(sec0)}
+        it = []
+        for x in self.sb[Ls - 1]:
+            _, sg, q, cp_, *_ = x
+            n, npr = self.sect[Ls - 1][q], self.sect[Ls][cp_]
+            it.append((P(Toff[(Ls - 1, sg, q)]), at(Gm, idx0[self.shift(cp_)]), P(c.Tping[(Ls - 1, sg, q)]), n, npr, npr, n, npr, n))
+        self._gemm_now(it, 0, stream, keep)
+        for x in self.sb[Ls - 1]:
+            Toff[(Ls - 1, x[1], x[2])] = c.Tping[(Ls - 1, x[1], x[2])]
+        it = []
+        for x in self.sb[0]:
+            _, sg, q, cp_, *_ = x
+            n, npr = self.sect[0][q], self.sect[1][cp_]
+            it.append((at(Hm, idx0[q]), P(Toff[(0, sg, q)]), P(c.Tpong[(0, sg, q)]), n, npr, n, n, n, n))
+        self._gemm_now(it, 1, stream, keep)
+        for x in self.sb[0]:
+            Toff[(0, x[1], x[2])] = c.Tpong[(0, x[1], x[2])]
+        for i, q in enumerate(sec0):
+            n, k = int(n0[i]), count[q]
+            e = np.zeros((n, n), self.np_dt)
+            e[np.arange(k), np.arange(k)] = lam[q]
+            d_ar[Rb[0][q]: Rb[0][q] + n * n] = torch.from_numpy(e.reshape(-1)).to(self.device)
+            e[np.arange(k), np.arange(k)] = 1.0
+            d_ar[Lb[Ls][secL[i]]: Lb[Ls][secL[i]] + n * n] = torch.from_numpy(e.reshape(-1)).to(self.device)
+        return {"eta": eta, "lam": lam, "count": count}
+
     # ---- helpers ----------------------------------------------------------------------------------
     def _copy(self, recs, stream, keep):
         if len(recs) == 0:
@@ -839,7 +1242,7 @@ class _Projector:
         nat.check(self.lib.tmf_bcgs_batched(self.dt, t_bd.data_ptr(), nat._p(bd), base.size, 2, 1, d_work.data_ptr(), wb, stream),
                   "tmf_bcgs_batched")
 
-    def _gemm_now(self, items, opA, stream, keep):
+    def _gemm_now(self, items, opA, stream, keep, alpha=1.0):
         if not items:
             return
         d = _gemm_recs(items)
@@ -847,7 +1250,7 @@ class _Projector:
         td = self.torch.from_numpy(d.view(np.uint8).reshape(-1).copy()).to(self.device)
         tt = self.torch.from_numpy(tiles.reshape(-1).copy()).to(self.device)
         keep += [td, tt]
-        nat.check(self.lib.tmf_gemm_batched(self.dt, opA, 1.0, 0.0, td.data_ptr(), tt.data_ptr(), len(tiles), tn, stream),
+        nat.check(self.lib.tmf_gemm_batched(self.dt, opA, alpha, 0.0, td.data_ptr(), tt.data_ptr(), len(tiles), tn, stream),
                   "tmf_gemm_batched")
 
 
@@ -869,7 +1272,7 @@ def _check_unit_cell_width(mps, unit_cell_width, group=2):
 
 def _finish(mps, inplace, res):
     if inplace:
-        mps.__class__ = SpinMPSData
+        mps.__class__ = res.__class__
         mps.__dict__.clear()
         mps.__dict__.update(res.__dict__)
         return None
@@ -890,25 +1293,44 @@ def abrikosov(mps, *, inplace: bool = False, return_canonical: bool = True, cuto
     assert mps.L % 2 == 0, "Odd-length MPS cannot represent an Abrikosov fermion Hilbert space"   # :158-160
     fer = _as_fermions(mps)
     conserve = fer.conserve
-    q, target = _total_charge(fer), fer.L // 2
+    infinite = getattr(fer, "infinite", False)
+    q, target = (fer.cell_charge if infinite else _total_charge(fer)), fer.L // 2
     err = f"Total charge must match number of spin sites. Got {q}, expected {target}"           # :178-187
     if conserve == "N":
         assert q == target, err
     else:
         assert q % 2 == target % 2, err + " (mod 2)"
-    if q_left not in (None, 0):
-        warn(f"`q_left` must be 0 for finite MPS, got {q_left = }, setting it to 0.")               # :192-196
+    shift = None
+    if infinite:                                                                                    # :197-206
+        if q_left is None:
+            raise ValueError("Must specify `q_left` for infinite MPS.")
+        sectors = np.unique(fer.charges[0])
+        if q_left not in sectors:
+            raise ValueError(f"`q_left` must be a charge sector of the leftmost virtual leg, got {q_left = }, "
+                             f"valid sectors are {sectors.tolist()}")
+        shift = (lambda c: c - q) if conserve == "N" else (lambda c: (c - q) % 2)
+    else:
+        if q_left not in (None, 0):
+            warn(f"`q_left` must be 0 for finite MPS, got {q_left = }, setting it to 0.")           # :192-196
+        q_left = 0
     ucw = _check_unit_cell_width(mps, unit_cell_width)
     if conserve == "N":
-        keep = lambda j, c: c == j                   # noqa: E731   number_mask(leg, q_left + idx), :236-238
+        keep = lambda j, c: c == q_left + j                      # noqa: E731   number_mask(leg, q_left + idx), :236-238
     else:
-        keep = lambda j, c: c % 2 == j % 2           # noqa: E731   parity_mask(leg, q_left + idx)
-    pr = _Projector(fer, ((0, 1), (1, 0)), keep, cutoff, device, method)    # kept physical states in leg order 01, 10
+        keep = lambda j, c: c % 2 == (q_left + j) % 2            # noqa: E731   parity_mask(leg, q_left + idx)
+    pr = _Projector(fer, ((0, 1), (1, 0)), keep, cutoff, device, method, shift=shift)   # kept physical states in leg order 01, 10
     blocks, lam, ch, norm = pr.run(return_canonical)
     logger.info("Completed projection to spin-1/2 space. No conserved charges left.")              # :260
     if not return_canonical:
         warn("The MPS is not in canonical form after Gutzwiller projection.\nConsider setting 'return_canonical=True'")
-    res = SpinMPSData(blocks, lam, ch, None, norm, ucw, canonical=return_canonical, timings=pr.timings)
+    if infinite:
+        blocks[-1] = [(p, ql, shift(qr)) + tuple(rest) for (p, ql, qr, *rest) in blocks[-1]]
+        ch[-1] = ch[0]
+        res = SpiniMPSData(blocks, lam, ch, None, norm, ucw, 0, timings=pr.timings)
+        if not return_canonical:
+            res.form = [None] * res.L
+    else:
+        res = SpinMPSData(blocks, lam, ch, None, norm, ucw, canonical=return_canonical, timings=pr.timings)
     return _finish(mps, inplace, res)
 
 
@@ -921,25 +1343,41 @@ def abrikosov_ph(mps, *, inplace: bool = False, return_canonical: bool = True, c
     assert mps.L % 2 == 0, "Odd-length MPS cannot represent an Abrikosov fermion Hilbert space"   # :354-356
     fer = _as_fermions(mps)
     conserve = fer.conserve
-    q = _total_charge(fer)
+    infinite = getattr(fer, "infinite", False)
+    q = fer.cell_charge if infinite else _total_charge(fer)
     assert q % 2 == 0, f"Total fermion parity of MPS must be even, got {q}"                       # :374-376
-    if parity != 0:
-        warn(f"Must use even parity sector in finite MPS, ignoring {parity = }")                  # :380-381
-    if offset != 0 and conserve == "N":
-        warn(f"Cannot offset charge of finite MPS, ignoring {offset = }")                         # :382-383
+    shift = None
+    if infinite:
+        shift = (lambda c: c - q) if conserve == "N" else (lambda c: (c - q) % 2)
+    else:
+        if parity != 0:
+            warn(f"Must use even parity sector in finite MPS, ignoring {parity = }")              # :380-381
+        if offset != 0 and conserve == "N":
+            warn(f"Cannot offset charge of finite MPS, ignoring {offset = }")                     # :382-383
+        offset = parity = 0                                                                       # :384
     ucw = _check_unit_cell_width(mps, unit_cell_width)
-    keep = lambda j, c: c % 2 == 0                   # noqa: E731   parity_mask(leg, 0), :418-419
-    pr = _Projector(fer, ((0, 0), (1, 1)), keep, cutoff, device, method)    # kept physical states 00, 11 = [down, up]
+    keep = lambda j, c: c % 2 == parity % 2          # noqa: E731   parity_mask(leg, parity), :418-419
+    pr = _Projector(fer, ((0, 0), (1, 1)), keep, cutoff, device, method, shift=shift)    # kept physical states 00, 11 = [down, up]
     blocks, lam, ch, norm = pr.run(return_canonical)
     spin = "Sz" if conserve == "N" else None
+    cell = 0
+    if infinite:          # the last bond is bond 0 of the next cell: its labels without the charge of one cell
+        blocks[-1] = [(p, ql, shift(qr) + (fer.L // 2 if spin == "Sz" else 0)) + tuple(rest) for (p, ql, qr, *rest) in blocks[-1]]
     if spin == "Sz":     # leg charges -= offset + idx (finite: offset = 0), :438-441
-        ch = [c - j for j, c in enumerate(ch)]
-        blocks = [[(p, ql - j, qr - j - 1) + tuple(rest) for (p, ql, qr, *rest) in bl] for j, bl in enumerate(blocks)]
+        ch = [c - offset - j for j, c in enumerate(ch)]
+        blocks = [[(p, ql - offset - j, qr - offset - j - 1) + tuple(rest) for (p, ql, qr, *rest) in bl] for j, bl in enumerate(blocks)]
+        cell = q - fer.L // 2          # 2 S^z of one cell (the reference gauges the last tensor by qtotal - L, :446-447)
     logger.info("Completed projection to spin-1/2 space. Conserved charge is now %s", spin)       # :462-465
     if not return_canonical:
         warn("The MPS is not in canonical form after Gutzwiller projection.\nConsider setting 'return_canonical=True'")
-    res = SpinMPSData(blocks, lam, ch, spin, norm, ucw, canonical=return_canonical, timings=pr.timings)
+    if infinite:
+        ch[-1] = ch[0]
+        res = SpiniMPSData(blocks, lam, ch, spin, norm, ucw, cell, timings=pr.timings)
+        if not return_canonical:
+            res.form = [None] * res.L
+    else:
+        res = SpinMPSData(blocks, lam, ch, spin, norm, ucw, canonical=return_canonical, timings=pr.timings)
     return _finish(mps, inplace, res)
 
 
-__all__ = ["abrikosov", "abrikosov_ph", "SpinMPSData"]
+__all__ = ["abrikosov", "abrikosov_ph", "SpinMPSData", "SpiniMPSData"]

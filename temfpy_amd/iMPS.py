@@ -90,10 +90,11 @@ class iMPSData:
 
     bc = "infinite"
 
-    def __init__(self, blocks, lam, charges, cell_charge, unit_cell_width):
+    def __init__(self, blocks, lam, charges, cell_charge, unit_cell_width, conserve=None):
         self.blocks, self.lam, self.charges = blocks, lam, charges
         self.L = len(blocks)
         self.cell_charge, self.unit_cell_width = cell_charge, unit_cell_width
+        self.conserve = conserve      # 'N' / 'parity' (FermionSite) or 'spin Sz' / 'spin None' (SpinHalfSite) of the two chains
         self.form = ["B"] * self.L
 
     @property
@@ -524,7 +525,8 @@ def MPS_to_iMPS(mps_short, mps_long, sites_per_cell: int, cut: int, unitary_tol:
             lab = (lambda c: (c - offset) % mod) if mod else (lambda c: c - offset)
             bl.append((p, lab(cl), lab(cr), l0, l0 + nl, r0, r0 + nr, buf))
         blocks.append(bl)
-    res = iMPSData(blocks, lam, [(q - offset) % mod if mod else q - offset for q in q_b], dq, unit_cell_width)
+    res = iMPSData(blocks, lam, [(q - offset) % mod if mod else q - offset for q in q_b], dq, unit_cell_width,
+                   conserve=charge_kind(mps_short))
     return res, iMPSError(left_unitary, left_schmidt, right_unitary, right_schmidt)
 
 

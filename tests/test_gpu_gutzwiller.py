@@ -292,3 +292,128 @@ def test_chi512_sample_against_oracle():
     for b in (1, 16, 32, 63):      # 2 S^z labels of the kept Schmidt indices: same multiset per charge
         for c in np.unique(Q[b]):
             assert abs((res.charges[b] == c).sum() - (Q[b] == c).sum()) <= 2
+
+
+# ---------------------------------------------------------------------------------------------------
+# infinite MPS (gutzwiller.py:197-206, :272 / :475)
+# ---------------------------------------------------------------------------------------------------
+def _ssh(L, t1=-1.5, t2=-1.0):
+    M = t1 * np.ones(L - 1)
+    M[1::2] = t2
+    M = np.diag(M, 1)
+    return M + M.T
+
+
+def _mixed_transfer_dominant(A, B):
+    E = None
+    for a, b in zip(A, B):
+        e = np.einsum("pab,pcd->acbd", a, np.conj(b)).reshape(a.shape[1] * b.shape[1], a.shape[2] * b.shape[2])
+        E = e if E is None else E @ e
+    return np.abs(np.linalg.eigvals(E)).max()
+
+
+@pytest.mark.parametrize("kind,spinful,chi", [("ph", "PH", 24), ("std", "simple", 24), ("ph", "PH", 40)])
+def test_infinite_mps_against_oracle(kind, spinful, chi):
+    """Projection of the unit cell of an infinite fermionic MPS (``slater.H_to_iMPS``) against the dense restatement
+    (oracle ``group_and_project_cell`` + ``canonical_form_infinite``) fed with the SAME cell: Schmidt values of every bond
+    (1e-8: both sides take them from Gram matrices, i.e. with sqrt(eps) resolution), the state per unit cell (dominant
+    eigenvalue of the mixed transfer matrix = 1 within 1e-8), norm per cell, right-canonical tensors (1e-10), left
+    environment diag(lam^2) (1e-7), 2 S^z labels."""
+    from temfpy_amd import gutzwiller, slater
+
+    L, cut = 24, 12
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cell, _ = slater.H_to_iMPS(_ssh(L), _ssh(L + 2), {"chi_max": chi}, 2, cut, spinful=spinful)
+        assert cell.L == 4 and cell.conserve == "N"
+        if kind == "ph":
+            out = gutzwiller.abrikosov_ph(cell)
+        else:
+            with pytest.raises(ValueError, match="q_left"):
+                gutzwiller.abrikosov(cell)
+            with pytest.raises(ValueError, match="charge sector"):
+                gutzwiller.abrikosov(cell, q_left=10**6)
+            out = gutzwiller.abrikosov(cell, q_left=0)
+    assert out.bc == "infinite" and out.L == 2 and out.form == ["B", "B"]
+    T, q = cell.dense_tensors(), [np.asarray(x) for x in cell.charges[:4]]
+    M, keep = gw.group_and_project_cell(T, q, cell.cell_charge, kind, "N", 0, 0)
+    Bo, So, eta = gw.canonical_form_infinite(M)
+    assert abs(out.norm - np.sqrt(eta)) < 1e-9 * np.sqrt(eta)
+    Bd = out.dense_tensors()
+    for b in range(3):
+        a, r = np.sort(out.lam[b])[::-1], np.sort(So[b])[::-1]
+        n = min(len(a), len(r))
+        assert n > 0 and np.abs(a[:n] - r[:n]).max() < 1e-8, (b, len(a), len(r))
+        assert np.all(a[n:] < 1e-6) and np.all(r[n:] < 1e-6)
+    np.testing.assert_array_equal(out.lam[0], out.lam[2])
+    np.testing.assert_array_equal(out.charges[0], out.charges[2])
+    for j, t in enumerate(Bd):
+        X = np.einsum("pab,pcb->ac", t, t.conj())
+        assert np.abs(X - np.eye(len(X))).max() < 1e-10
+        l2 = sum(t[p].conj().T @ np.diag(out.lam[j] ** 2) @ t[p] for p in range(2))
+        assert np.abs(l2 - np.diag(out.lam[j + 1] ** 2)).max() < 1e-7
+    # the same state per unit cell as the oracle's, and as the projected (non-canonical) cell itself
+    own = _mixed_transfer_dominant(Bd, Bd)
+    assert abs(own - 1) < 1e-9
+    assert abs(_mixed_transfer_dominant(Bd, Bo) / np.sqrt(own * _mixed_transfer_dominant(Bo, Bo)) - 1) < 1e-8
+    assert abs(_mixed_transfer_dominant(Bd, M) / np.sqrt(own * eta) - 1) < 1e-8
+    if kind == "ph":       # 2 S^z labels: p = 0 lowers, p = 1 raises; the last site closes the cell with cell_charge
+        assert out.conserve == "Sz" and out.cell_charge == cell.cell_charge - 2
+        for j, bl in enumerate(out.blocks):
+            for p, ql, qr, l0, l1, r0, r1, a in bl:
+                assert ql + (1 if p else -1) == qr + (out.cell_charge if j == out.L - 1 else 0)
+                assert np.all(out.charges[j][l0:l1] == ql) and np.all(out.charges[j + 1][r0:r1] == qr)
+    else:
+        assert out.conserve is None
+    # not canonical: the projected cell as it is
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        raw = gutzwiller.abrikosov_ph(cell, return_canonical=False) if kind == "ph" else gutzwiller.abrikosov(
+            cell, q_left=0, return_canonical=False)
+    assert raw.form == [None, None]
+    assert abs(_mixed_transfer_dominant(raw.dense_tensors(), M) / eta - 1) < 1e-10
+
+
+def test_infinite_mps_parity_conserving_complex():
+    """Unit cell of a Kitaev chain (``pfaffian.H_to_iMPS``: parity labels, complex tensors, two fermion sites = one spin site
+    per cell): whichever projection the parity of the cell admits, against the dense restatement."""
+    from temfpy_amd import gutzwiller, pfaffian
+
+    t1, t2, L, cut = 1.5j, 1j, 20, 10
+
+    def kitaev(n):
+        M = t1 * np.ones(2 * n - 1, complex)
+        M[1::2] = t2
+        M = np.diag(M, 1)
+        return M + M.T.conj()
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cell, _ = pfaffian.H_to_iMPS(kitaev(L), kitaev(L + 2), {"chi_max": 16}, 2, cut, basis="M")
+        assert cell.L == 2 and cell.conserve == "parity"
+        if cell.cell_charge % 2 == 0:
+            kind, out = "ph", gutzwiller.abrikosov_ph(cell, parity=1)
+            with pytest.raises(AssertionError, match="Total charge"):
+                gutzwiller.abrikosov(cell, q_left=0)
+            par = 1
+        else:
+            kind, out = "std", gutzwiller.abrikosov(cell, q_left=1)
+            with pytest.raises(AssertionError, match="parity"):
+                gutzwiller.abrikosov_ph(cell)
+            par = 0
+    assert out.bc == "infinite" and out.L == 1 and out.conserve is None
+    T, q = cell.dense_tensors(), [np.asarray(x) for x in cell.charges[:2]]
+    M, keep = gw.group_and_project_cell(T, q, cell.cell_charge, kind, "parity", par, 1)
+    Bo, So, eta = gw.canonical_form_infinite(M)
+    assert abs(out.norm - np.sqrt(eta)) < 1e-9 * np.sqrt(eta)
+    Bd = out.dense_tensors()
+    a, r = np.sort(out.lam[0])[::-1], np.sort(So[0])[::-1]
+    n = min(len(a), len(r))
+    assert n > 0 and np.abs(a[:n] - r[:n]).max() < 1e-8 and np.all(a[n:] < 1e-6) and np.all(r[n:] < 1e-6)
+    X = np.einsum("pab,pcb->ac", Bd[0], Bd[0].conj())
+    assert np.abs(X - np.eye(len(X))).max() < 1e-10
+    own = _mixed_transfer_dominant(Bd, Bd)
+    assert abs(own - 1) < 1e-9
+    assert abs(_mixed_transfer_dominant(Bd, Bo) / np.sqrt(own * _mixed_transfer_dominant(Bo, Bo)) - 1) < 1e-8
+    assert abs(_mixed_transfer_dominant(Bd, M) / np.sqrt(own * eta) - 1) < 1e-8
+    assert out.timings and gutzwiller.SpiniMPSData is type(out)

@@ -226,5 +226,5 @@ def test_gutzwiller_projected_chains_to_imps():
     ov = io.overlap(Tv, lv, fv, Tr, lr, fr)
     nr, nv = io.overlap(Tr, lr, fr, Tr, lr, fr).real, io.overlap(Tv, lv, fv, Tv, lv, fv).real
     assert abs(abs(ov) / np.sqrt(nr * nv) - 1) < 1e-5
-    with pytest.raises(NotImplementedError, match="infinite MPS"):
+    with pytest.raises(ValueError, match="FermionSite must conserve"):      # a spin cell is not a fermionic MPS (gutzwiller.py:172-176)
         gutzwiller.abrikosov_ph(res)

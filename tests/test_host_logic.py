@@ -254,3 +254,26 @@ def test_merged_leg_order_against_the_reference_fixtures(name):
         for col in range(len(ref_ket)):
             mine = [occupied(ket, int(o), col, 0) for o in r["col_sel"][ka:]]
             assert mine == ref_ket[col].tolist(), (name, i, col)
+
+
+def test_arnoldi_dominant_eigenpair():
+    """gutzwiller._dominant_eigenpair (host side of the transfer-matrix fixed points): non-normal maps, real and complex,
+    dimension below and above the Krylov size, slowly separating spectrum."""
+    from temfpy_amd.gutzwiller import _dominant_eigenpair
+
+    rng = np.random.default_rng(3)
+    for n, cplx, gap in ((1, False, 0.5), (3, True, 0.5), (200, False, 0.5), (300, True, 0.97)):
+        V = rng.normal(size=(n, n)) + (1j * rng.normal(size=(n, n)) if cplx else 0)
+        w = gap * rng.uniform(0.0, 1.0, n) * np.exp(2j * np.pi * rng.uniform(size=n) if cplx else 0)
+        w[0] = 1.3
+        A = (V * w) @ np.linalg.inv(V)
+        if not cplx:
+            A = A.real
+        calls = [0]
+
+        def apply(v):
+            calls[0] += 1
+            return A @ v
+        th, v = _dominant_eigenpair(apply, np.ones(n, complex if cplx else float))
+        assert abs(th - 1.3) < 1e-11 and np.linalg.norm(A @ v - th * v) < 1e-10 * np.linalg.norm(v)
+        assert calls[0] < 60 * 24

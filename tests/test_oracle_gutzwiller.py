@@ -80,3 +80,50 @@ def test_infer_parities_host_logic():
     bad[3][1] += bad[3][0]
     with pytest.raises(ValueError, match="parity"):
         infer_parities(bad)
+
+
+def test_infinite_canonical_form_against_a_long_finite_chain():
+    """oracle.canonical_form_infinite pinned independently of its own arithmetic: the Schmidt values in the middle of a
+    long finite chain of repeated cells (oracle.canonical_form_finite: QR + SVD sweeps, no Gram matrices) are those of the
+    infinite MPS once the chain is much longer than the correlation length; the result is right-canonical, its left
+    environment is diag(S^2) and it is the same state per unit cell."""
+    rng = np.random.default_rng(5)
+    chi, L, N = 5, 3, 80
+    M = [rng.normal(size=(2, chi, chi)) + 1j * rng.normal(size=(2, chi, chi)) for _ in range(L)]
+    B, S, eta = gw.canonical_form_infinite(M)
+    M = [m / eta ** (0.5 / L) for m in M]
+    for j, t in enumerate(B):
+        X = np.einsum("pab,pcb->ac", t, t.conj())
+        assert np.abs(X - np.eye(len(X))).max() < 1e-12
+        l2 = sum(t[p].conj().T @ np.diag(S[j] ** 2) @ t[p] for p in range(2))
+        assert np.abs(l2 - np.diag(S[j + 1] ** 2)).max() < 1e-12
+    chain = [m for _ in range(N) for m in M]
+    chain[0] = np.einsum("a,pab->pb", rng.normal(size=chi), chain[0])[:, None, :]
+    chain[-1] = np.einsum("pab,b->pa", chain[-1], rng.normal(size=chi))[:, :, None]
+    _, Sf, _ = gw.canonical_form_finite(chain, cutoff=1e-14)
+    mid = L * (N // 2)
+    for j in range(L):
+        s = np.sort(Sf[mid + j])[::-1]
+        assert np.abs(s[: len(S[j])] - np.sort(S[j])[::-1]).max() < 1e-10
+
+    def mixed(A, C):
+        E = None
+        for a, c in zip(A, C):
+            e = np.einsum("pab,pcd->acbd", a, np.conj(c)).reshape(a.shape[1] * c.shape[1], a.shape[2] * c.shape[2])
+            E = e if E is None else E @ e
+        return np.abs(np.linalg.eigvals(E)).max()
+    assert abs(mixed(B, M) / np.sqrt(mixed(B, B) * mixed(M, M)) - 1) < 1e-10
+
+
+def test_cell_projection_masks():
+    """group_and_project_cell: the closing bond keeps the indices bond 0 keeps (idx_next = (idx + 1) % L, gutzwiller.py:235)."""
+    rng = np.random.default_rng(1)
+    q = [np.array([0, 0, 1, 1, 2]), np.array([0, 1, 1, 2, 2, 3]), np.array([1, 1, 2, 2, 3]), np.array([1, 2, 2, 3, 3, 4])]
+    T = [rng.normal(size=(2, len(q[i]), len(q[(i + 1) % 4]))) for i in range(4)]
+    M, keep = gw.group_and_project_cell(T, q, 2, "std", "N", 0, 1)
+    assert keep[0].tolist() == [2, 3] and keep[1].tolist() == [2, 3] and keep[2].tolist() == [2, 3]
+    assert [m.shape for m in M] == [(2, 2, 2), (2, 2, 2)]
+    np.testing.assert_allclose(M[0][1], (T[0][1] @ T[1][0])[np.ix_(keep[0], keep[1])])
+    M, keep = gw.group_and_project_cell(T, q, 2, "ph", "N", 1, 0)
+    assert keep[0].tolist() == [2, 3] and keep[1].tolist() == [0, 1, 4]
+    np.testing.assert_allclose(M[1][0], (T[2][0] @ T[3][0])[np.ix_(keep[1], keep[2])])
