@@ -152,7 +152,9 @@ class PfMPSData:
                 if got.shape != want.shape or not np.array_equal(got, want):
                     raise RuntimeError(f"TeNPy assembly self-check failed at site {i} (Pfaffian path); use as_tenpy=False")
             tensors.append(B)
-        return networks.mps.MPS([site] * self.L, tensors, self.lam, form=self.form, unit_cell_width=self.unit_cell_width)
+        psi = networks.mps.MPS([site] * self.L, tensors, self.lam, form=self.form, unit_cell_width=self.unit_cell_width)
+        psi._temfpy_amd = self
+        return psi
 
 
 class PfEngine(Engine):

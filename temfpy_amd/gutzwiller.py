@@ -123,7 +123,9 @@ class SpinMPSData:
             else:
                 B = npc.Array.from_ndarray_trivial(T.transpose(1, 0, 2), labels=["vL", "p", "vR"])
             Bs.append(B)
-        return networks.mps.MPS([site] * self.L, Bs, self._lam, form="B", unit_cell_width=self.unit_cell_width)
+        psi = networks.mps.MPS([site] * self.L, Bs, self._lam, form="B", unit_cell_width=self.unit_cell_width)
+        psi._temfpy_amd = self
+        return psi
 
 
 class SpiniMPSData(SpinMPSData):
@@ -293,6 +295,17 @@ def infer_parities(T, tol=1e-9):
     return q
 
 
+def native(mps):
+    """The package's own container behind a TeNPy ``MPS`` it returned (``to_tenpy`` leaves a reference on the object), or
+    ``mps`` itself.  A TeNPy ``MPS`` from elsewhere, or one modified after the conversion, is not supported as input."""
+    own = getattr(mps, "_temfpy_amd", None)
+    if own is not None:
+        if getattr(mps, "L", own.L) != own.L or list(getattr(mps, "chi", [])) not in ([], [len(x) for x in own.lam[1:-1]]):
+            raise ValueError("the TeNPy MPS was modified after the conversion; convert with as_tenpy=False and pass that result")
+        return own
+    return mps
+
+
 def _as_fermions(mps):
     from .mps_data import MPSData
 
@@ -300,6 +313,7 @@ def _as_fermions(mps):
 
     if isinstance(mps, _Fermions):
         return mps
+    mps = native(mps)
     if isinstance(mps, iMPSData):
         return _fermions_from_imps(mps)
     if isinstance(mps, MPSData):
@@ -1259,6 +1273,7 @@ class _Projector:
 # ---------------------------------------------------------------------------------------------------
 def _check_unit_cell_width(mps, unit_cell_width, group=2):
     """gutzwiller.py:73-88."""
+    mps = native(mps)
     if unit_cell_width is None:
         unit_cell_width = mps.unit_cell_width
         if (mps.L // group) % unit_cell_width != 0:
@@ -1271,6 +1286,11 @@ def _check_unit_cell_width(mps, unit_cell_width, group=2):
 
 
 def _finish(mps, inplace, res):
+    if getattr(mps, "_temfpy_amd", None) is not None:      # a TeNPy MPS came in: a TeNPy MPS goes out (gutzwiller.py:277-281)
+        try:
+            res = res.to_tenpy()
+        except (ImportError, NotImplementedError):
+            pass
     if inplace:
         mps.__class__ = res.__class__
         mps.__dict__.clear()

@@ -425,6 +425,9 @@ def MPS_to_iMPS(mps_short, mps_long, sites_per_cell: int, cut: int, unitary_tol:
             matrix itself, and the right-hand errors are reported as zero."""
     if right not in ("rotate", "project"):
         raise ValueError(f"`right` must be 'rotate' or 'project', got {right!r}")
+    from .gutzwiller import native
+
+    mps_short, mps_long = native(mps_short), native(mps_long)      # TeNPy objects this package returned
     L_short, L_long = mps_short.L, mps_long.L
     if L_short + sites_per_cell != L_long:
         raise ValueError("The given two MPS must differ by one unit cell, got "

@@ -330,5 +330,7 @@ class MPSData:
                         "from the converter's own (LegPipe row order other than slater.py:943-952 documents?). "
                         "Use slater.C_to_MPS(..., as_tenpy=False) for the backend-neutral MPSData.")
             tensors.append(B)
-        return networks.mps.MPS([site] * self.L, tensors, self.lam, form=self.form,
-                                unit_cell_width=self.unit_cell_width)
+        psi = networks.mps.MPS([site] * self.L, tensors, self.lam, form=self.form,
+                               unit_cell_width=self.unit_cell_width)
+        psi._temfpy_amd = self      # gutzwiller / iMPS entry points of this package continue from the device-side layout
+        return psi

@@ -417,3 +417,27 @@ def test_infinite_mps_parity_conserving_complex():
     assert abs(_mixed_transfer_dominant(Bd, Bo) / np.sqrt(own * _mixed_transfer_dominant(Bo, Bo)) - 1) < 1e-8
     assert abs(_mixed_transfer_dominant(Bd, M) / np.sqrt(own * eta) - 1) < 1e-8
     assert out.timings and gutzwiller.SpiniMPSData is type(out)
+
+
+def test_tenpy_object_returned_by_the_package_is_accepted():
+    """With TeNPy installed ``slater.C_to_MPS`` returns a TeNPy ``MPS`` (as the reference does); ``to_tenpy`` leaves a
+    reference to the device-side container on it, through which the projections and ``iMPS.MPS_to_iMPS`` continue.  TeNPy
+    is not installed here: a stand-in object carries the reference."""
+    from temfpy_amd import gutzwiller, iMPS
+
+    class Stand:
+        def __init__(self, own):
+            self._temfpy_amd, self.L = own, own.L
+
+    mps = hip_mps(uniform_chain(8), 256, "PH")
+    a = gutzwiller.abrikosov_ph(mps)
+    b = gutzwiller.abrikosov_ph(Stand(mps))          # (no TeNPy: the native container comes back)
+    for x, y in zip(a.lam, b.lam):
+        np.testing.assert_array_equal(x, y)
+    s = Stand(mps)
+    assert gutzwiller.abrikosov_ph(s, inplace=True) is None and isinstance(s, gutzwiller.SpinMPSData)
+    bad = Stand(mps)
+    bad.L = 4
+    with pytest.raises(ValueError, match="modified"):
+        gutzwiller.abrikosov_ph(bad)
+    assert gutzwiller.native(a) is a and iMPS.MPS_to_iMPS is not None
