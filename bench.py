@@ -177,6 +177,7 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(a)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (before HIP / RCCL load: dmabuf IPC between the ranks)
     dry = os.environ.get("TMF_DRY_ENGINE") == "1"
     same_dev = os.environ.get("TMF_BENCH_SAME_DEVICE") == "1"
     # The contract is ONE JSON line on stdout.  Libraries underneath write to the C-level stdout (gloo announces its

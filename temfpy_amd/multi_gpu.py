@@ -417,6 +417,7 @@ def spawn_ranks(argv, world, extra_env=None, **popen_kw):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), TMF_SHM_TAG=f"tmf{os.getpid()}p{port}")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL between processes needs on this driver
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=env, **popen_kw))
     return procs
