@@ -694,6 +694,46 @@ class Engine:
         C = 0.5 * (np.eye(n) - X)
         return (C + C.conj().T) / 2, steps
 
+    def lowest_projector(self, H, N, max_bisections=80):
+        """Projector onto the N lowest eigenvectors of a Hermitian matrix (``v[:, :N] v[:, :N]^H`` of slater.py:1174-1179)
+        without an eigensolver: bisection on the chemical potential mu, the number of levels below mu counted as the trace
+        of :meth:`negative_projector` of H - mu (converged loosely while searching, to 1e-14 at the end).  A degenerate
+        level at the Fermi energy (levels N and N + 1 equal) has no unique projector: ValueError, where LAPACK's ordering
+        decides in the reference.  Returns (C, mu, sign iterations in total)."""
+        H = np.asarray(H)
+        n = len(H)
+        assert H.shape == (n, n), f"Got non-square {H.shape} Hamiltonian"
+        if not 0 <= N <= n:
+            raise ValueError(f"cannot occupy {N} of {n} orbitals")
+        if N == 0 or N == n:
+            return (np.zeros_like(H) if N == 0 else np.eye(n, dtype=H.dtype)), None, 0
+        bound = float(min(np.linalg.norm(H), np.abs(H).sum(axis=0).max()))      # >= spectral radius
+        lo, hi, total = -1.001 * bound - 1e-300, 1.001 * bound + 1e-300, 0     # fewer than N levels below lo, at least N below hi
+        eye = np.eye(n, dtype=H.dtype)
+        mu, shift = 0.5 * (lo + hi), 0.0
+        for _ in range(max_bisections):
+            try:
+                C, steps = self.negative_projector(H - (mu + shift) * eye, tol=1e-7, max_iter=70)
+            except RuntimeError:          # mu sits on a level: move a little inside the bracket
+                shift = (hi - lo) * (0.0137 if shift == 0.0 else -1.7 * shift / (hi - lo))
+                if abs(shift) > 0.4 * (hi - lo):
+                    break
+                continue
+            total += steps
+            cnt = int(np.rint(np.trace(C).real))
+            if cnt == N:
+                C, steps = self.negative_projector(H - (mu + shift) * eye)
+                return C, mu + shift, total + steps
+            if cnt < N:
+                lo = mu + shift
+            else:
+                hi = mu + shift
+            mu, shift = 0.5 * (lo + hi), 0.0
+            if hi - lo <= 1e-13 * bound:
+                break
+        raise ValueError(f"no gap between level {N} and level {N + 1} (chemical potential bracket [{lo}, {hi}]): "
+                         f"{N} particles do not fill a shell, the ground state is not a unique Slater determinant")
+
     # ------------------------------------------------------------------ the sweep
     sweep_impl = os.environ.get("TMF_SWEEP", "cpp")    # "cpp": tmf_sweep_* (csrc/sweep.cpp); "python": run_gen below (A/B)
 

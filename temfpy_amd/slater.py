@@ -37,11 +37,15 @@ def correlation_matrix(H: np.ndarray, N: int | None = None, *, device: str | Non
 
     Outside the timed C -> MPS path.  Default: host LAPACK like the reference.
     ``device="cuda:0"`` (extra keyword): the occupied-orbital projector is computed on the GPU as
-    (1 - sign(H)) / 2 by a GEMM-only Newton-Schulz iteration (``Engine.negative_projector``); only for
-    ``N=None`` (occupy all negative-energy orbitals), where no eigenvalue ordering is needed."""
+    (1 - sign(H - mu)) / 2 by a GEMM-only Newton-Schulz iteration (``Engine.negative_projector``), with mu = 0 for
+    ``N=None`` (all negative-energy orbitals) and mu found by bisection on the level count for a given ``N``
+    (``Engine.lowest_projector``; a degenerate Fermi level raises ValueError)."""
     if device is not None and N is None:
         C, _ = _engine(device).negative_projector(H)
         N = int(np.round(np.trace(C).real))
+    elif device is not None:
+        C, _, _ = _engine(device).lowest_projector(H, int(N))
+        N = int(N)
     else:
         e, v = np.linalg.eigh(H)
         if N is None:

@@ -515,6 +515,32 @@ def test_correlation_matrix_on_device_matches_eigh(L, seed, real):
     np.testing.assert_allclose(C1 @ C1, C1, rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("L,seed,N", [(64, 0, 20), (120, 2, 61), (48, 1, 1), (48, 1, 47), (32, 3, 0), (32, 3, 32)])
+def test_correlation_matrix_on_device_with_particle_number(L, seed, N):
+    """slater.correlation_matrix(H, N, device=...): the N lowest levels by bisection on the chemical potential with the sign
+    iteration as level counter, against the host eigh path (slater.py:1174-1179); a degenerate Fermi level is refused."""
+    from tests_inputs import random_hopping
+    from temfpy_amd import slater
+
+    H = random_hopping(L, seed)
+    C0, N0 = slater.correlation_matrix(H, N)
+    C1, N1 = slater.correlation_matrix(H, N, device="cuda:0")
+    assert N1 == N0 == N and abs(np.trace(C1).real - N) < 1e-9
+    np.testing.assert_allclose(C1, C0, rtol=0, atol=1e-10)
+    if 0 < N < L:
+        np.testing.assert_allclose(C1 @ C1, C1, rtol=0, atol=1e-11)
+
+
+def test_correlation_matrix_on_device_degenerate_fermi_level():
+    from temfpy_amd import slater
+
+    H = np.diag([-2.0, -1.0, -1.0, 0.5, 3.0]).astype(complex)
+    with pytest.raises(ValueError, match="do not fill a shell"):
+        slater.correlation_matrix(H, 2, device="cuda:0")
+    C, N = slater.correlation_matrix(H, 3, device="cuda:0")
+    np.testing.assert_allclose(C, np.diag([1.0, 1, 1, 0, 0]), rtol=0, atol=1e-12)
+
+
 @pytest.mark.parametrize("svd_min,deg_tol", [(1e-4, 1e-12), (3e-7, 1e-12), (1e-6, 1e-9)])
 def test_non_default_truncation_parameters(svd_min, deg_tol):
     """trunc_par beyond chi_max (schmidt_utils.py:22-54): svd_min moves the orbital cutoff svd_min^2
