@@ -421,6 +421,9 @@ def main():
         # REFERENCE's algorithm (one (8/3) n^3 LU per minor); the pivoted-exchange kernel evaluates
         # order-d minors of one shared exchange instead and executes almost none of those flops.  The hardware-true
         # figure of this kernel is its HBM rate (output bound): traffic / avg_launch_ms.
+        if dom == "ppt":      # the kernel is instantiated per mask width: take the instance the PMC pass saw
+            seen = [k for k in pmc_k if k.startswith("tmf::ppt_det_kernel<tmf::cd")]
+            kname = max(seen, key=lambda k: pmc_k[k].get("launches", 0)) if seen else kname
         hbm = pmc_k.get(kname, {}).get("hbm_bytes_per_launch")
         roof["determinant_kernel"] = {
             "kernel": kname, "avg_launch_ms": round(avg_ms, 3), "dets_per_launch": det_n[dom],

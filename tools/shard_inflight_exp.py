@@ -22,7 +22,7 @@ print("range", rng, flush=True)
 DEPTH = int(os.environ.get('EXP_DEPTH', 0))
 for nctx, nthr in ((1, 1), (2, 1)) if DEPTH else ((1, 1), (2, 1), (3, 1), (2, 2), (3, 3)):
     engs = [Engine("cuda:0") for _ in range(nctx)]
-    ht = max(2, 16 // max(nthr, 1))
+    ht = int(os.environ.get('EXP_THREADS', 0)) or max(2, 16 // max(nthr, 1))
 
     def work(es, n):
         res = []
