@@ -665,6 +665,7 @@ class _Projector:
             cell = self._close_cell(SimpleNamespace(P=P, d_ar=d_ar, Toff=Toff, Rb=Rb, Lb=Lb, Vinfo=Vinfo, Winfo=Winfo, Yq=Yq, Wo=Wo,
                                                     stream=stream, keep=keep_alive, Tping=Tping, Tpong=Tpong))
             self.timings["fixed points"] = time.perf_counter() - t1
+            self.timings["cell applications"] = self.cell_applications
         G, CP, QR = _Launches(nat.gemm_desc), _Launches(nat.copy_desc), _Launches(nat.qr_desc)
         steps1, steps2 = [], []
         # rightward sweep: V_j = R_j T_j (left-merged), QR in place, R -> bond j+1
