@@ -166,7 +166,7 @@ def self_spawn(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--L", type=int, default=1024)
     ap.add_argument("--chi", type=int, default=512)
