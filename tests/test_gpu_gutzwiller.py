@@ -372,6 +372,17 @@ def test_infinite_mps_against_oracle(kind, spinful, chi):
             cell, q_left=0, return_canonical=False)
     assert raw.form == [None, None]
     assert abs(_mixed_transfer_dominant(raw.dense_tensors(), M) / eta - 1) < 1e-10
+    if kind == "ph":       # offset shifts every 2 S^z label (gutzwiller.py:333); inplace turns the cell itself into the result
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            shifted = gutzwiller.abrikosov_ph(cell, offset=3)
+            assert gutzwiller.abrikosov_ph(cell, inplace=True) is None
+        for a, b in zip(shifted.charges, out.charges):
+            np.testing.assert_array_equal(a, b - 3)
+        assert shifted.cell_charge == out.cell_charge
+        assert isinstance(cell, gutzwiller.SpiniMPSData) and cell.bc == "infinite" and cell.L == 2
+        for a, b in zip(cell.lam, out.lam):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
 
 
 def test_infinite_mps_parity_conserving_complex():
