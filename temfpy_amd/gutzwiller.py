@@ -141,7 +141,14 @@ class SpiniMPSData(SpinMPSData):
         self.cell_charge = cell_charge
 
     def to_tenpy(self):
-        raise NotImplementedError("TeNPy export of the infinite spin MPS is not written (physics-tenpy is not installed here)")
+        """``tenpy.networks.mps.MPS(..., bc="infinite", form="B")`` on ``SpinHalfSite`` (what gutzwiller.py:272 / :475 leave
+        behind).  Needs physics-tenpy: written against its documented interface, exercised by no test here."""
+        from tenpy import networks
+
+        from .iMPS import cell_to_tenpy
+
+        return cell_to_tenpy(self, networks.site.SpinHalfSite("Sz" if self.conserve == "Sz" else None),
+                             charged=self.conserve == "Sz")
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -300,7 +307,8 @@ def native(mps):
     ``mps`` itself.  A TeNPy ``MPS`` from elsewhere, or one modified after the conversion, is not supported as input."""
     own = getattr(mps, "_temfpy_amd", None)
     if own is not None:
-        if getattr(mps, "L", own.L) != own.L or list(getattr(mps, "chi", [])) not in ([], [len(x) for x in own.lam[1:-1]]):
+        dims = [len(x) for x in own.lam]          # TeNPy's chi: bonds 1 .. L-1 of a finite MPS, bonds 0 .. L-1 of an infinite one
+        if getattr(mps, "L", own.L) != own.L or list(getattr(mps, "chi", [])) not in ([], dims[1:-1], dims[:-1]):
             raise ValueError("the TeNPy MPS was modified after the conversion; convert with as_tenpy=False and pass that result")
         return own
     return mps

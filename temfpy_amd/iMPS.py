@@ -111,6 +111,46 @@ class iMPSData:
             out.append(T)
         return out
 
+    def to_tenpy(self):
+        """``tenpy.networks.mps.MPS(..., bc="infinite", form="B")`` of the unit cell, as slater.py:1555-1562 /
+        pfaffian.py:2083-2090 build it.  Needs physics-tenpy, which is not installed in the build environment: written
+        against its documented interface and exercised by no test here; the assembled tensors are read back and compared
+        with the cell's own, a mismatch raises."""
+        from tenpy import networks
+
+        if self.conserve in ("N", "parity"):
+            site = networks.site.FermionSite(self.conserve)
+        elif self.conserve in ("spin Sz", "spin None"):
+            site = networks.site.SpinHalfSite("Sz" if self.conserve == "spin Sz" else None)
+        else:
+            raise ValueError(f"unknown charge kind {self.conserve!r}")
+        return cell_to_tenpy(self, site, charged=self.conserve != "spin None")
+
+
+def cell_to_tenpy(cell, site, charged=True):
+    """Shared by ``iMPSData.to_tenpy`` and ``gutzwiller.SpiniMPSData.to_tenpy``: B tensors with legs (vL, p, vR), the charges
+    of bond L being those of bond 0 (the last tensor then carries the cell's charge as its ``qtotal``, which
+    ``npc.Array.from_ndarray`` detects)."""
+    import tenpy.linalg.np_conserved as npc
+    from tenpy import networks
+
+    chinfo = site.leg.chinfo
+    Bs = []
+    for j, T in enumerate(cell.dense_tensors()):
+        if charged:
+            legs = [npc.LegCharge.from_qflat(chinfo, [[int(q)] for q in cell.charges[j]], qconj=+1), site.leg,
+                    npc.LegCharge.from_qflat(chinfo, [[int(q)] for q in cell.charges[(j + 1) % cell.L]], qconj=-1)]
+            B = npc.Array.from_ndarray(T.transpose(1, 0, 2), legs, labels=["vL", "p", "vR"], cutoff=0.0)
+        else:
+            B = npc.Array.from_ndarray_trivial(T.transpose(1, 0, 2), labels=["vL", "p", "vR"])
+        if not np.array_equal(B.to_ndarray(), T.transpose(1, 0, 2)):
+            raise RuntimeError(f"TeNPy assembly self-check failed at site {j} of the unit cell")
+        Bs.append(B)
+    psi = networks.mps.MPS([site] * cell.L, Bs, [np.asarray(x) for x in cell.lam], bc="infinite", form="B",
+                           unit_cell_width=cell.unit_cell_width)
+    psi._temfpy_amd = cell
+    return psi
+
 
 # ---------------------------------------------------------------------------------------------------
 # device helper
@@ -427,6 +467,7 @@ def MPS_to_iMPS(mps_short, mps_long, sites_per_cell: int, cut: int, unitary_tol:
         raise ValueError(f"`right` must be 'rotate' or 'project', got {right!r}")
     from .gutzwiller import native
 
+    came_as_tenpy = getattr(mps_short, "_temfpy_amd", None) is not None
     mps_short, mps_long = native(mps_short), native(mps_long)      # TeNPy objects this package returned
     L_short, L_long = mps_short.L, mps_long.L
     if L_short + sites_per_cell != L_long:
@@ -530,6 +571,11 @@ def MPS_to_iMPS(mps_short, mps_long, sites_per_cell: int, cut: int, unitary_tol:
         blocks.append(bl)
     res = iMPSData(blocks, lam, [(q - offset) % mod if mod else q - offset for q in q_b], dq, unit_cell_width,
                    conserve=charge_kind(mps_short))
+    if came_as_tenpy:          # TeNPy in, TeNPy out (iMPS.py:430-441)
+        try:
+            res = res.to_tenpy()
+        except ImportError:
+            pass
     return res, iMPSError(left_unitary, left_schmidt, right_unitary, right_schmidt)
 
 

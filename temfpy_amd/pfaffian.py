@@ -194,7 +194,8 @@ def H_to_MPS(H: np.ndarray, trunc_par: dict | StoppingCondition, *, basis: str, 
 
 def C_to_iMPS(C_short: np.ndarray, C_long: np.ndarray, trunc_par: dict | StoppingCondition, sites_per_cell: int,
               cut: int, *, basis: str, diag_tol: float = _DIAG_TOL, unitary_tol: float = 1e-6,
-              schmidt_tol: float = 1e-6, unit_cell_width: int | None = None, device: str = "cuda:0"):
+              schmidt_tol: float = 1e-6, unit_cell_width: int | None = None, device: str = "cuda:0",
+              as_tenpy: bool | None = None):
     """iMPS representation of a Nambu mean-field state from the correlation matrices of two chains that differ by
     one unit cell (pfaffian.py:1924-2091): same arguments, defaults and exceptions.  As in the reference the last
     tensor of the unit cell is expressed in the right Schmidt vectors of the SHORT chain (pfaffian.py:2039-2056) and no
@@ -217,14 +218,18 @@ def C_to_iMPS(C_short: np.ndarray, C_long: np.ndarray, trunc_par: dict | Stoppin
     res, err = iMPS.MPS_to_iMPS(mps_s, mps_l, sites_per_cell, cut, unitary_tol=unitary_tol, schmidt_tol=schmidt_tol,
                                 offset=0, unit_cell_width=sites_per_cell, device=device, right="project")
     res.unit_cell_width = unit_cell_width
-    return res, err
+    from .slater import _maybe_tenpy
+
+    return _maybe_tenpy(res, as_tenpy), err
 
 
 def H_to_iMPS(H_short: np.ndarray, H_long: np.ndarray, trunc_par: dict | StoppingCondition, sites_per_cell: int,
               cut: int, *, basis: str, diag_tol: float = _DIAG_TOL, unitary_tol: float = 1e-6,
-              schmidt_tol: float = 1e-6, unit_cell_width: int | None = None, device: str = "cuda:0"):
+              schmidt_tol: float = 1e-6, unit_cell_width: int | None = None, device: str = "cuda:0",
+              as_tenpy: bool | None = None):
     """pfaffian.py:2151-2242."""
     C_short = correlation_matrix(H_short, basis=f"{basis}->{basis}")
     C_long = correlation_matrix(H_long, basis=f"{basis}->{basis}")
     return C_to_iMPS(C_short, C_long, trunc_par, sites_per_cell, cut, basis=basis, diag_tol=diag_tol,
-                     unitary_tol=unitary_tol, schmidt_tol=schmidt_tol, unit_cell_width=unit_cell_width, device=device)
+                     unitary_tol=unitary_tol, schmidt_tol=schmidt_tol, unit_cell_width=unit_cell_width, device=device,
+                     as_tenpy=as_tenpy)

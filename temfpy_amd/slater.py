@@ -124,6 +124,19 @@ def C_to_MPS(
         return mps
 
 
+def _maybe_tenpy(res, as_tenpy):
+    """``as_tenpy`` False: the package's container; True: the TeNPy object (ImportError without TeNPy); None: the TeNPy
+    object if TeNPy is importable."""
+    if as_tenpy is False:
+        return res
+    try:
+        return res.to_tenpy()
+    except ImportError:
+        if as_tenpy:
+            raise
+        return res
+
+
 def H_to_MPS(
     H: np.ndarray,
     trunc_par: dict | StoppingCondition,
@@ -156,6 +169,7 @@ def C_to_iMPS(
     offset: int | Literal["auto"] = "auto",
     unit_cell_width: int | None = None,
     device: str = "cuda:0",
+    as_tenpy: bool | None = None,
 ):
     """iMPS representation of a Slater determinant from the correlation matrices of two chains that differ by
     one unit cell (slater.py:1356-1565): same arguments, defaults, offset rules and exceptions.
@@ -200,7 +214,7 @@ def C_to_iMPS(
                                 schmidt_tol=schmidt_tol, offset=offset, unit_cell_width=mult * sites_per_cell,
                                 device=device, right="project")
     res.unit_cell_width = unit_cell_width
-    return res, err
+    return _maybe_tenpy(res, as_tenpy), err
 
 
 def H_to_iMPS(
@@ -217,13 +231,14 @@ def H_to_iMPS(
     offset: int | Literal["auto"] = "auto",
     unit_cell_width: int | None = None,
     device: str = "cuda:0",
+    as_tenpy: bool | None = None,
 ):
     """iMPS representation of a Slater determinant from single-particle Hamiltonians (slater.py:1630-1734)."""
     C_short, _ = correlation_matrix(H_short)
     C_long, _ = correlation_matrix(H_long)
     return C_to_iMPS(C_short, C_long, trunc_par, sites_per_cell, cut, diag_tol=diag_tol, unitary_tol=unitary_tol,
                      schmidt_tol=schmidt_tol, spinful=spinful, offset=offset, unit_cell_width=unit_cell_width,
-                     device=device)
+                     device=device, as_tenpy=as_tenpy)
 
 
 __all__ = ["C_to_MPS", "H_to_MPS", "C_to_iMPS", "H_to_iMPS", "correlation_matrix", "spinful_correlation_matrix", "MPSData"]
