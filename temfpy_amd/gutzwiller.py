@@ -407,15 +407,18 @@ def _dominant_eigenpair(apply, v0, tol=1e-13, krylov=24, restarts=400):
         V[0], used, beta = v, m, 0.0
         for k in range(m):
             w = apply(V[k])
+            size = float(np.linalg.norm(w))
             for _pass in range(2):                     # classical Gram-Schmidt, twice
                 h = V[: k + 1].conj() @ w
                 w = w - h @ V[: k + 1]
                 H[: k + 1, k] += h
             beta = float(np.linalg.norm(w))
-            H[k + 1, k] = beta
-            if beta <= 1e-300 or k + 1 == v.size:
-                used, beta = k + 1, (beta if k + 1 < v.size else 0.0)
+            if beta <= 1e-11 * size or k + 1 == v.size:
+                # the Krylov space is exhausted (an invariant subspace: the vectors may live in fewer dimensions than their
+                # length says); what is left of w is rounding noise and must not become a basis vector
+                used, beta = k + 1, 0.0
                 break
+            H[k + 1, k] = beta
             V[k + 1] = w / beta
         ev, Yv = np.linalg.eig(H[:used, :used])
         i = int(np.argmax(np.abs(ev)))

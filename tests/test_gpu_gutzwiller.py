@@ -452,3 +452,51 @@ def test_tenpy_object_returned_by_the_package_is_accepted():
     with pytest.raises(ValueError, match="modified"):
         gutzwiller.abrikosov_ph(bad)
     assert gutzwiller.native(a) is a and iMPS.MPS_to_iMPS is not None
+
+
+@pytest.mark.parametrize("kind,seed,cplx", [("ph", 0, True), ("std", 1, True), ("ph", 2, False), ("std", 3, False)])
+def test_infinite_mps_hand_made_cells(kind, seed, cplx):
+    """Random charge-conserving cells of six fermion sites (three spin sites per cell, several sectors per bond, some of them
+    not on any closed path through the cell): sector bookkeeping of the periodic projector against the dense restatement.
+    (The cell is not canonical and not normalised: the projection does not care.)"""
+    from temfpy_amd import gutzwiller
+    from temfpy_amd.iMPS import iMPSData
+
+    rng = np.random.default_rng(seed)
+    L, Q = 6, (4 if kind == "ph" else 3)          # cell charge: even for abrikosov_ph, number of spin sites for abrikosov
+    # charge labels of bond i: a window of four values that drifts with the filling, Q particles per cell
+    q = [np.sort(np.concatenate((np.arange(4), rng.integers(0, 4, size=rng.integers(2, 6))))) + (i * Q) // L for i in range(L)]
+    blocks = []
+    for i in range(L):
+        ql, qr = q[i], (q[i + 1] if i + 1 < L else q[0] + Q)
+        bl = []
+        for p in (0, 1):
+            for cl in np.unique(ql):
+                rows = np.nonzero(ql == cl)[0]
+                cols = np.nonzero(qr == cl + p)[0]
+                if len(rows) and len(cols):
+                    a = rng.normal(size=(len(rows), len(cols))) + (1j * rng.normal(size=(len(rows), len(cols))) if cplx else 0)
+                    lab_r = int(cl + p - (Q if i + 1 == L else 0))
+                    bl.append((p, int(cl), lab_r, int(rows[0]), int(rows[-1]) + 1, int(cols[0]), int(cols[-1]) + 1, a))
+        blocks.append(bl)
+    lam = [np.ones(len(x)) / np.sqrt(len(x)) for x in q] + [np.ones(len(q[0])) / np.sqrt(len(q[0]))]
+    cell = iMPSData(blocks, lam, q + [q[0]], Q, 3, conserve="N")
+    q_left = 1
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = gutzwiller.abrikosov_ph(cell) if kind == "ph" else gutzwiller.abrikosov(cell, q_left=q_left)
+    M, keep = gw.group_and_project_cell(cell.dense_tensors(), q, Q, kind, "N", 0, q_left)
+    Bo, So, eta = gw.canonical_form_infinite(M)
+    assert out.L == 3 and abs(out.norm - np.sqrt(eta)) < 1e-9 * np.sqrt(eta)
+    Bd = out.dense_tensors()
+    for b in range(4):
+        a, r = np.sort(out.lam[b])[::-1], np.sort(So[b])[::-1]
+        n = min(len(a), len(r))
+        assert n > 0 and np.abs(a[:n] - r[:n]).max() < 1e-8 and np.all(a[n:] < 1e-6) and np.all(r[n:] < 1e-6), b
+    for t in Bd:
+        X = np.einsum("pab,pcb->ac", t, t.conj())
+        assert np.abs(X - np.eye(len(X))).max() < 1e-10
+    own = _mixed_transfer_dominant(Bd, Bd)
+    assert abs(own - 1) < 1e-9
+    assert abs(_mixed_transfer_dominant(Bd, Bo) / np.sqrt(own * _mixed_transfer_dominant(Bo, Bo)) - 1) < 1e-8
+    assert abs(_mixed_transfer_dominant(Bd, M) / np.sqrt(own * eta) - 1) < 1e-8

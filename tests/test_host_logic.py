@@ -277,3 +277,19 @@ def test_arnoldi_dominant_eigenpair():
         th, v = _dominant_eigenpair(apply, np.ones(n, complex if cplx else float))
         assert abs(th - 1.3) < 1e-11 and np.linalg.norm(A @ v - th * v) < 1e-10 * np.linalg.norm(v)
         assert calls[0] < 60 * 24
+    # a map that lives in fewer dimensions than the length of its vectors (padding entries of the packed blocks): the Krylov
+    # space is exhausted before the Krylov size is reached, and the leftover rounding noise must not produce Ritz values
+    n, pad = 13, 3
+    V = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+    w = np.concatenate(([3926.9], 1500 * rng.uniform(0, 1, n - 1) * np.exp(2j * np.pi * rng.uniform(size=n - 1))))
+    A = np.zeros((n + pad, n + pad), complex)
+    A[:n, :n] = (V * w) @ np.linalg.inv(V)
+    v0 = np.concatenate((np.ones(n), np.zeros(pad))).astype(complex)
+    calls = [0]
+
+    def apply_padded(x):
+        calls[0] += 1
+        return A @ x
+    th, v = _dominant_eigenpair(apply_padded, v0)
+    assert abs(th - 3926.9) < 1e-8 and np.linalg.norm(A @ v - th * v) < 1e-8 * np.linalg.norm(v)
+    assert calls[0] == n          # stopped when the 13-dimensional space was exhausted, not at the vector length
