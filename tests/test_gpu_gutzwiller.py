@@ -454,42 +454,64 @@ def test_tenpy_object_returned_by_the_package_is_accepted():
     assert gutzwiller.native(a) is a and iMPS.MPS_to_iMPS is not None
 
 
-@pytest.mark.parametrize("kind,seed,cplx", [("ph", 0, True), ("std", 1, True), ("ph", 2, False), ("std", 3, False)])
-def test_infinite_mps_hand_made_cells(kind, seed, cplx):
-    """Random charge-conserving cells of six fermion sites (three spin sites per cell, several sectors per bond, some of them
-    not on any closed path through the cell): sector bookkeeping of the periodic projector against the dense restatement.
-    (The cell is not canonical and not normalised: the projection does not care.)"""
-    from temfpy_amd import gutzwiller
+def _random_cell(rng, L, Q, conserve, cplx):
+    """Random charge-conserving unit cell of L fermion sites with Q particles per cell (labels mod 2 for 'parity')."""
     from temfpy_amd.iMPS import iMPSData
 
-    rng = np.random.default_rng(seed)
-    L, Q = 6, (4 if kind == "ph" else 3)          # cell charge: even for abrikosov_ph, number of spin sites for abrikosov
-    # charge labels of bond i: a window of four values that drifts with the filling, Q particles per cell
-    q = [np.sort(np.concatenate((np.arange(4), rng.integers(0, 4, size=rng.integers(2, 6))))) + (i * Q) // L for i in range(L)]
+    mod = 2 if conserve == "parity" else None
+    if mod:
+        q = [np.sort(np.concatenate((np.arange(2), rng.integers(0, 2, size=rng.integers(3, 7))))) for _ in range(L)]
+    else:     # a window of four values that drifts with the filling
+        q = [np.sort(np.concatenate((np.arange(4), rng.integers(0, 4, size=rng.integers(2, 6))))) + (i * Q) // L for i in range(L)]
     blocks = []
     for i in range(L):
-        ql, qr = q[i], (q[i + 1] if i + 1 < L else q[0] + Q)
+        ql = q[i]
+        qr = q[i + 1] if i + 1 < L else ((q[0] + Q) % 2 if mod else q[0] + Q)       # labels in the convention q_l + p = q_r
         bl = []
         for p in (0, 1):
             for cl in np.unique(ql):
                 rows = np.nonzero(ql == cl)[0]
-                cols = np.nonzero(qr == cl + p)[0]
+                cols = np.nonzero(qr == ((cl + p) % 2 if mod else cl + p))[0]
                 if len(rows) and len(cols):
+                    assert np.all(np.diff(cols) == 1) or mod      # (parity: the shifted labels of the last bond are not sorted)
                     a = rng.normal(size=(len(rows), len(cols))) + (1j * rng.normal(size=(len(rows), len(cols))) if cplx else 0)
-                    lab_r = int(cl + p - (Q if i + 1 == L else 0))
-                    bl.append((p, int(cl), lab_r, int(rows[0]), int(rows[-1]) + 1, int(cols[0]), int(cols[-1]) + 1, a))
+                    lab = (cl + p - (Q if i + 1 == L else 0))
+                    lab = int(lab % 2) if mod else int(lab)
+                    if np.all(np.diff(cols) == 1):
+                        bl.append((p, int(cl), lab, int(rows[0]), int(rows[-1]) + 1, int(cols[0]), int(cols[-1]) + 1, a))
+                    else:
+                        raise AssertionError("non-contiguous block")
         blocks.append(bl)
     lam = [np.ones(len(x)) / np.sqrt(len(x)) for x in q] + [np.ones(len(q[0])) / np.sqrt(len(q[0]))]
-    cell = iMPSData(blocks, lam, q + [q[0]], Q, 3, conserve="N")
+    return iMPSData(blocks, lam, q + [q[0]], (Q % 2 if mod else Q), max(L // 2, 1), conserve=conserve), q
+
+
+@pytest.mark.parametrize("kind,seed,cplx,L,conserve", [("ph", 0, True, 6, "N"), ("std", 1, True, 6, "N"), ("ph", 2, False, 6, "N"),
+                                                      ("std", 3, False, 6, "N"), ("ph", 4, True, 4, "parity"),
+                                                      ("std", 5, True, 2, "parity"), ("std", 6, False, 6, "parity"),
+                                                      ("ph", 7, False, 2, "N"), ("std", 8, True, 4, "N")])
+def test_infinite_mps_hand_made_cells(kind, seed, cplx, L, conserve):
+    """Random charge-conserving cells (one to three spin sites per cell, number or parity labels, several sectors per bond,
+    some of them on no closed path through the cell): sector bookkeeping of the periodic projector against the dense
+    restatement.  (The cell is not canonical and not normalised: the projection does not care.)"""
+    from temfpy_amd import gutzwiller
+
+    rng = np.random.default_rng(seed)
+    if kind == "std":
+        Q = L // 2                                     # one particle per spin site (gutzwiller.py:178-187)
+    else:
+        Q = 2 * (L // 4) + 2 if conserve == "N" else 0   # even (gutzwiller.py:374-376), about half filling
+    cell, q = _random_cell(rng, L, Q, conserve, cplx)
     q_left = 1
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         out = gutzwiller.abrikosov_ph(cell) if kind == "ph" else gutzwiller.abrikosov(cell, q_left=q_left)
-    M, keep = gw.group_and_project_cell(cell.dense_tensors(), q, Q, kind, "N", 0, q_left)
+    M, keep = gw.group_and_project_cell(cell.dense_tensors(), q, Q, kind, conserve, 0, q_left)
     Bo, So, eta = gw.canonical_form_infinite(M)
-    assert out.L == 3 and abs(out.norm - np.sqrt(eta)) < 1e-9 * np.sqrt(eta)
+    Ls = L // 2
+    assert out.L == Ls and abs(out.norm - np.sqrt(eta)) < 1e-9 * np.sqrt(eta)
     Bd = out.dense_tensors()
-    for b in range(4):
+    for b in range(Ls + 1):
         a, r = np.sort(out.lam[b])[::-1], np.sort(So[b])[::-1]
         n = min(len(a), len(r))
         assert n > 0 and np.abs(a[:n] - r[:n]).max() < 1e-8 and np.all(a[n:] < 1e-6) and np.all(r[n:] < 1e-6), b
