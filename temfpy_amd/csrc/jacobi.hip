@@ -69,9 +69,12 @@ __global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __re
   int tpp = 64;                     // lanes per pair: largest power of two with npairs*tpp <= 512
   while (tpp * npairs > 512) tpp >>= 1;
   const int pair = tid >> (31 - __builtin_clz(tpp)), pl = tid & (tpp - 1);      // tpp is a power of two
-  // rotate while |<x_i, x_j>| > sqrt(p) eps |x_i| |x_j| (the rounding level of the p-term inner product
-  // itself; a tighter bound makes pairs at that level rotate for ever: 18 of 1023 cuts hit the cap)
-  const double tol2 = 1.1e-16 * 1.1e-16 * (double)p;
+  // rotate while |<x_i, x_j>| > sqrt(max(p, 16)) eps |x_i| |x_j| (the rounding level of the p-term inner product
+  // itself; a tighter bound makes pairs at that level rotate for ever: 18 of 1023 cuts hit the cap).  The floor of 4 eps
+  // is the accuracy of a rotation (c, s from rsq / rcp + Newton steps, a few ulp): below it a rotated pair is as
+  // orthogonal as it gets, and without the floor every 3 x 3 problem with three significant columns kept "rotating" by
+  // rounding-level angles until the sweep cap (results correct, LinAlgError raised: tools/soak_small.py seed 1919).
+  const double tol2 = 1.1e-16 * 1.1e-16 * (double)(p > 16 ? p : 16);
 
   int sweep = 0;
   for (; sweep < 60; ++sweep) {
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(512) void jacobi_compact_kernel(const tmf_jacobi_de
   int tpp = 64;
   while (tpp * npairs > 512 && tpp > 1) tpp >>= 1;
   const int slots = 512 / tpp;                    // pairs processed at once (npairs may exceed it for tpp = 1)
-  const double tol2 = 1.1e-16 * 1.1e-16 * (double)p;
+  const double tol2 = 1.1e-16 * 1.1e-16 * (double)(p > 16 ? p : 16);      // (floor: see jacobi_kernel)
   int sweep = 0;
   for (; sweep < 60 && nact > 1; ++sweep) {
     for (int rho = 0; rho < m; ++rho) {
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(512) void jacobi_block_kernel(const tmf_jacobi_desc
   int tpp = 64;
   while (tpp * npairs > 512) tpp >>= 1;
   const int pair = tid >> (31 - __builtin_clz(tpp)), pl = tid & (tpp - 1);      // tpp is a power of two
-  const double tol2 = 1.1e-16 * 1.1e-16 * (double)p;
+  const double tol2 = 1.1e-16 * 1.1e-16 * (double)(p > 16 ? p : 16);      // (floor: see jacobi_kernel)
 
   int sweep = 0;
   for (; sweep < 60; ++sweep) {

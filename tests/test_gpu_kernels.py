@@ -1130,3 +1130,36 @@ def test_single_call_sweep_entry_point_and_accessors():
     finally:
         lib.tmf_result_free(res)
         lib.tmf_ctx_destroy(ctx)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("left_only", [True, False])
+def test_jacobi_every_small_size(eng, cplx, left_only):
+    """One-sided Jacobi on every problem size 1 .. 24 and a few larger odd ones (an odd number of active columns leaves
+    one player of the tournament idle; sizes up to 16 run with 64 lanes per pair): converges within a few sweeps,
+    singular values to 1e-12, orthonormal vectors.  Includes the 3 x 3 triangular factor of a cut of an L = 14 chain that
+    did not converge before the idle player's partner was kept out of the reductions (tools/soak_small.py, seed 1919)."""
+    setup(eng, cplx)
+    rng = np.random.default_rng(77)
+    ps = list(range(1, 25)) + [31, 33, 47, 63]
+    Xs = [rnd(rng, (p, p), cplx) * np.logspace(0, -3, p)[None, :] for p in ps]
+    Xs[2] = np.array([[0.47502447471382064, 0.0, 0.0], [0.05627941268549051, -0.10970793908097089, 0.0],
+                      [-0.0913023802829401, 0.05655712241246387, -0.07941423969753784]]).astype(Xs[2].dtype)
+    dX = [dev(eng, x) for x in Xs]
+    dO = [dev(eng, np.zeros_like(x)) for x in Xs]
+    ds = [torch.zeros(p, dtype=torch.float64, device="cuda:0") for p in ps]
+    dc = torch.zeros(len(ps), dtype=torch.int32, device="cuda:0")
+    eng._keep.clear()
+    eng.jacobi([d[1] for d in dX], [d[1] for d in dO], [s.data_ptr() for s in ds], dc.data_ptr() + 4 * np.arange(len(ps)),
+               1e-30, ps, ps, ps, left_only=left_only)
+    torch.cuda.synchronize()
+    sweeps = [t for t in eng._keep if getattr(t, "dtype", None) == torch.int32][-1].cpu().numpy()
+    assert sweeps.max() <= 12, sweeps.tolist()
+    for p, X, do, s_ in zip(ps, Xs, dO, ds):
+        O, s = back(do[0], (p, p)), s_.cpu().numpy()
+        np.testing.assert_allclose(s, np.linalg.svd(X, compute_uv=False), rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(O.conj().T @ O, np.eye(p), atol=1e-12)
+        if left_only:       # U diag(s) U^H = X X^H
+            np.testing.assert_allclose((O * s**2) @ O.conj().T, X @ X.conj().T, atol=1e-12)
+        else:               # right vectors: X V has orthogonal columns of norm s
+            np.testing.assert_allclose(np.linalg.norm(X @ O, axis=0), s, rtol=1e-11, atol=1e-14)
