@@ -16,7 +16,7 @@ from temfpy_amd import slater  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-bad = 0
+bad = both_raise = 0
 for seed in range(first, first + n_cases):
     rng = np.random.default_rng(seed)
     L = int(rng.integers(2, 29))
@@ -86,8 +86,9 @@ for seed in range(first, first + n_cases):
                 orc.c_to_mps(orc.correlation_matrix(H, N)[0], {"chi_max": chi}, ortho_center=oc, spinful=spinful)
         except Exception as e2:     # noqa: BLE001
             same = type(e2) is type(e) or isinstance(e, (np.linalg.LinAlgError, AssertionError)) and isinstance(e2, (np.linalg.LinAlgError, AssertionError))
+        both_raise += same
         if not same:
             bad += 1
             print("MISMATCH", tag, "->", type(e).__name__, str(e)[:200], flush=True)
-print(f"{n_cases} cases, {bad} mismatches")      # (multiplets cut differently in spinful cases are not counted)
+print(f"{n_cases} cases, {bad} mismatches, {both_raise} where the oracle raises as well")      # (multiplets cut differently in spinful cases are not counted)
 sys.exit(1 if bad else 0)
