@@ -33,7 +33,8 @@ __device__ inline void reflector(T alpha, double xn2, T& tau, T& scal, T& beta) 
   tau = sc<T>::zero();
   scal = sc<T>::zero();
   beta = alpha;
-  if (xn2 > 0.0 || sc<T>::imag(alpha) != 0.0) {
+  // (a column whose squared length underflows is a zero column: no reflector; b = 0 would give tau = 0 / 0, see house_slab.hip)
+  if ((xn2 > 0.0 || sc<T>::imag(alpha) != 0.0) && sc<T>::abs2(alpha) + xn2 > 1e-290) {
     double b = sqrt(sc<T>::abs2(alpha) + xn2);
     if (sc<T>::real(alpha) > 0.0) b = -b;  // beta = -sign(Re alpha) |(alpha, x)|
     beta = sc<T>::from_real(b);

@@ -881,6 +881,12 @@ class _Projector:
             else:
                 norm = float(np.sqrt(cell["eta"]))      # norm of the projected state per unit cell
             self.timings["sweeps"] = time.perf_counter() - t2
+            if os.environ.get("TMF_GW_DEBUG"):      # development aid: the triangular factors of both sweeps, per bond and sector
+                h_all = d_ar.cpu().numpy()
+                self.debug = {"R": {(j, c): h_all[Rb[j][c]: Rb[j][c] + n * n].reshape(n, n).T.copy() for j in range(Ls + 1)
+                                    for c, n in self.sect[j].items()},
+                              "L": {(j, c): h_all[Lb[j][c]: Lb[j][c] + n * n].reshape(n, n).T.copy() for j in range(Ls + 1)
+                                    for c, n in self.sect[j].items()}, "sect": [dict(s_) for s_ in self.sect]}
             if not norm > 0.0 or not np.isfinite(norm):
                 raise ValueError("the Gutzwiller projection annihilates the state")
             # ================= every bond at once =================

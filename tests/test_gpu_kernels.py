@@ -1,5 +1,7 @@
 """GPU parity tests of every device entry point of the C ABI against NumPy (fp64).
 Tolerances are stated per test; everything is called through libtemfpy_hip.so."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1163,3 +1165,46 @@ def test_jacobi_every_small_size(eng, cplx, left_only):
             np.testing.assert_allclose((O * s**2) @ O.conj().T, X @ X.conj().T, atol=1e-12)
         else:               # right vectors: X V has orthogonal columns of norm s
             np.testing.assert_allclose(np.linalg.norm(X @ O, axis=0), s, rtol=1e-11, atol=1e-14)
+
+
+@pytest.mark.parametrize("kernel", ["tmf_house_qr_batched", "tmf_house_slab_batched"])
+def test_householder_far_past_the_rank(eng, kernel):
+    """Householder QR of exactly rank-deficient blocks with many more steps than rank (Gutzwiller-projected tensors: zero rows,
+    rank 4 of 16 x 19): past the rank every step works on the rounding noise of the previous one, whose squared length
+    underflows after a dozen steps; such a column is a zero column.  (Before that guard: tau = 0 / 0, NaN in R, wrong
+    Schmidt values from that bond on - tools/soak_gutzwiller.py seed 67; the first matrix is the one from that case.)"""
+    lib = eng.lib
+    rng = np.random.default_rng(3)
+    mats = [np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kernels", "qr_rank4_16x19.npy"))]
+    for m, n, r, cplx in ((16, 19, 4, True), (40, 24, 3, True), (30, 30, 2, False), (64, 70, 5, False), (12, 40, 1, True)):
+        A = rnd(rng, (m, r), cplx) @ rnd(rng, (r, n), cplx)
+        A[rng.permutation(m)[: m // 2]] = 0          # exact zero rows
+        mats.append(A)
+    for V in mats:
+        cplx = np.iscomplexobj(V)
+        setup(eng, cplx)
+        dt, tdt = (eng.nat.TMF_C128, torch.complex128) if cplx else (eng.nat.TMF_F64, torch.float64)
+        m, n = V.shape
+        dA = torch.from_numpy(np.ascontiguousarray(V.T).reshape(-1).copy()).to("cuda:0")
+        dR = torch.zeros(n * n, dtype=tdt, device="cuda:0")
+        st = torch.cuda.current_stream().cuda_stream
+        if kernel == "tmf_house_qr_batched":
+            d = np.zeros(1, eng.nat.qr_desc)
+            d[0] = (dA.data_ptr(), dR.data_ptr(), m, n, m, n, 0, 0)
+            dd = torch.from_numpy(d.view(np.uint8).copy()).to("cuda:0")
+            eng.nat.check(lib.tmf_house_qr_batched(dt, dd.data_ptr(), 1, m, n, st), kernel)
+            Q = None
+        else:
+            dQ = torch.zeros(m * n + 2, dtype=tdt, device="cuda:0")
+            d = np.zeros(1, eng.nat.slab_desc)
+            d[0] = (dA.data_ptr(), dQ.data_ptr(), dR.data_ptr(), m, n, m, m, n, 0)
+            dd = torch.from_numpy(d.view(np.uint8).copy()).to("cuda:0")
+            eng.nat.check(lib.tmf_house_slab_batched(dt, dd.data_ptr(), 1, m, n, st), kernel)
+        torch.cuda.synchronize()
+        R = dR.cpu().numpy().reshape(n, n).T
+        Q = dA.cpu().numpy().reshape(n, m).T
+        assert np.isfinite(R).all() and np.isfinite(Q).all()
+        scale = np.abs(V).max() ** 2
+        np.testing.assert_allclose(R.conj().T @ R, V.conj().T @ V, rtol=0, atol=1e-13 * scale * max(m, n))
+        k = min(m, n)
+        np.testing.assert_allclose(Q[:, :k] @ R[:k], V, rtol=0, atol=1e-13 * np.abs(V).max() * max(m, n))
