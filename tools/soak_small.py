@@ -1,7 +1,7 @@
 """Randomised soak of slater.C_to_MPS against the CPU oracle on small inputs: random length, filling, hopping range, chi_max,
 spinful mode and orthogonality centre.  A mismatch prints the case (seed) and the script exits non-zero.  Development aid,
 not part of the tests (it imports the oracle).
-usage: python tools/soak_small.py [cases] [first seed]"""
+usage: python tools/soak_small.py [cases] [first seed] [largest L, default 28]"""
 import os
 import sys
 import warnings
@@ -16,10 +16,11 @@ from temfpy_amd import slater  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_L = int(sys.argv[3]) if len(sys.argv) > 3 else 28
 bad = both_raise = 0
 for seed in range(first, first + n_cases):
     rng = np.random.default_rng(seed)
-    L = int(rng.integers(2, 29))
+    L = int(rng.integers(2, max_L + 1))
     rng_h = float(rng.choice([0.7, 1.5, 3.0, 6.0]))
     cplx = bool(rng.integers(0, 2))
     x, y = np.meshgrid(np.arange(L), np.arange(L), indexing="ij")
@@ -28,7 +29,7 @@ for seed in range(first, first + n_cases):
     H = H + H.conj().T
     N = int(rng.integers(0, L + 1)) if rng.integers(0, 3) == 0 else None
     spinful = [None, None, None, None, "simple", "PH"][int(rng.integers(0, 6))]
-    chi = int(rng.choice([2, 5, 16, 40, 128]))
+    chi = int(rng.choice([2, 5, 16, 40, 128] if max_L <= 28 else [16, 40, 128, 300]))
     Lf = L * (1 if spinful is None else 2)
     oc = int(rng.integers(1, Lf)) if (Lf > 1 and rng.integers(0, 2)) else None
     tag = f"seed {seed}: L={L} range={rng_h} complex={cplx} N={N} spinful={spinful} chi={chi} oc={oc}"
