@@ -462,6 +462,28 @@ struct Sweep {
     return tmf_house_slab_batched(c.dtype, (const tmf_slab_desc*)t_d, (int)d.size(), (int)maxn, (int)maxc, c.s_main);
   }
 
+  // Householder QR of slabs of any width in place (global-memory kernel, one workgroup per slab): the range finders wider
+  // than the 64 columns of the slab kernel.  Orthogonal for any rank - the blocked Gram-Schmidt that used to run here lost
+  // an entangled orbital on a spinful chain whose two species decouple exactly (rounding noise has no component outside
+  // span(Q)): tools/soak_small.py seed 30023, 80 instead of 81 orbitals at one cut, weak eigenvalues
+  // off by 1 - 5 %.
+  int house_general(const std::vector<Slab>& s_in) {
+    std::vector<tmf_qr_desc> d;
+    i64 maxm = 0, maxn = 0;
+    for (const Slab& x : s_in) {
+      if (!(x.rows > 0 && x.c1 > 0)) continue;
+      tmf_qr_desc q{};
+      q.A = x.base, q.R = 0, q.m = (int32_t)x.rows, q.n = (int32_t)x.c1, q.lda = (int32_t)x.ld, q.ldr = 1, q.flags = 0;
+      d.push_back(q);
+      maxm = std::max(maxm, x.rows), maxn = std::max(maxn, x.c1);
+    }
+    if (d.empty()) return TMF_OK;
+    std::stable_sort(d.begin(), d.end(), [](const tmf_qr_desc& a, const tmf_qr_desc& b) { return (i64)a.m * a.n > (i64)b.m * b.n; });
+    u64 t_d;
+    TMF_TRY(up_vec(d, &t_d));
+    return tmf_house_qr_batched(c.dtype, (const tmf_qr_desc*)t_d, (int)d.size(), (int)maxm, (int)maxn, c.s_main);
+  }
+
   // One-sided Jacobi per problem (p > 0 only).  left_only: U receives the normalised left singular vectors.
   int jacobi(const std::vector<u64>& X, const std::vector<u64>& V, const std::vector<u64>& s, const std::vector<u64>* count,
              double thresh2, const std::vector<i64>& p, bool left_only) {
@@ -722,6 +744,7 @@ struct Sweep {
       std::vector<Slab> s;
       for (i64 i = 0; i < ncs; ++i)
         if (c.doE[i]) s.push_back(Slab{ptr[i], rows[i], rows[i], 0, p[i], scrp[i]});
+      if (!(c.par.flags & TMF_SWEEP_RANGE_BCGS)) return house_general(s);
       return bcgs(s, 3, false);
     };
     TMF_TRY(rqr(Yp, c.n));

@@ -284,6 +284,21 @@ class Engine:
             out[keep] = d["Q"].astype(np.int64)
         return out
 
+    def house_general(self, base, rows, ld, cols):
+        """Householder QR in place of slabs of any width (tmf_house_qr_batched: matrix in global memory, one workgroup per
+        slab): the range finders wider than the slab kernel's 64 columns.  Orthogonal for any rank, where the blocked
+        Gram-Schmidt lost an entangled orbital of a spinful chain with exactly decoupled species (tools/soak_small.py seed 30023)."""
+        base, rows, ld, cols = (np.asarray(x, np.int64) for x in (base, rows, ld, cols))
+        keep = np.nonzero((rows > 0) & (cols > 0))[0]
+        if keep.size == 0:
+            return
+        keep = keep[np.argsort(-(rows[keep] * cols[keep]), kind="stable")]
+        d = np.zeros(keep.size, nat.qr_desc)
+        d["A"], d["R"], d["m"], d["n"], d["lda"], d["ldr"], d["flags"] = base[keep], 0, rows[keep], cols[keep], ld[keep], 1, 0
+        t_d = self._up(d)
+        nat.check(self.lib.tmf_house_qr_batched(self.dtype, t_d.data_ptr(), keep.size, int(rows[keep].max()), int(cols[keep].max()),
+                                                self.stream), "tmf_house_qr_batched")
+
     def jacobi(self, X, V, s, count, thresh2, p, ldx, ldv, left_only=False):
         """One-sided Jacobi per problem.  ``left_only``: ``V`` receives the normalised LEFT singular
         vectors (tmf_svd_left_batched, no rotation accumulator) instead of the right ones.
@@ -453,6 +468,8 @@ class Engine:
                 # Q stays in the buffer the kernel builds it in (no copy back over the slab)
                 ptr = np.array(ptr, np.int64)
                 ptr[doE] = self.house_slab(ptr[doE], rows_[doE], rows_[doE], p[doE], inplace=False)
+            elif self.range_qr == "house":
+                self.house_general(np.asarray(ptr, np.int64)[doE], rows_[doE], rows_[doE], p[doE])
             else:
                 self.bcgs2(ptr[doE], rows_[doE], rows_[doE], zero[doE], p[doE], scrp[doE], passes=3)
             return ptr

@@ -413,7 +413,7 @@ def basis_rotation(overlap: BlockMatrix, Schmidt_bra: np.ndarray, Schmidt_ket: n
     for i, (p, o) in enumerate(zip(ps, off[:-1])):
         scale = max(float(np.abs(Ms[keys[i]]).max()), 1e-300)
         jd[i] = (d_X.data_ptr() + el * o, d_W.data_ptr() + el * o, d_V.data_ptr() + el * o, d_s.data_ptr() + 8 * so[i],
-                 d_c.data_ptr() + 4 * i, (1e-14 * scale) ** 2, p, p, p, p)
+                 d_c.data_ptr() + 4 * i, (1e-100 * scale) ** 2, p, p, p, p)
         gg.append((d_M.data_ptr() + el * o, d_V.data_ptr() + el * o, d_G.data_ptr() + el * o, p, p, p, p, p, p))
         cn[i] = (d_G.data_ptr() + el * o, d_U.data_ptr() + el * o, p, p, p, p, 0, 0)
         cp.append((d_V.data_ptr() + el * o, d_VH.data_ptr() + el * o, p, p, p, p, 3 if cplx else 1, 0))

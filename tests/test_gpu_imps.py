@@ -213,14 +213,23 @@ def test_gutzwiller_projected_chains_to_imps():
     # degenerate across and inside the 2 S^z sectors: the basis inside a multiplet is fixed by rounding, element-wise
     # parity does not exist): transfer matrix of the HIP cell against the oracle's, dominant eigenvalue 1, sub-leading
     # eigenvalues equal within the reported conversion error
-    def transfer(cell):
+    # (restricted to Schmidt states of weight > 1e-6: the rotation of the weaker ones - their weights go down to the 1e-12
+    # cutoff of the projection - is fixed by rounding alone, here as in LAPACK, and a transfer matrix counts every state of
+    # the bond alike, whatever its weight)
+    def transfer(cell, lam):
+        keep = [np.nonzero(np.asarray(x) > 1e-6)[0] for x in lam]
         E = None
-        for t in cell:
+        for j, t in enumerate(cell):
+            t = t[:, keep[j]][:, :, keep[j + 1]]
             e = np.einsum("pab,pcd->acbd", t, np.conj(t)).reshape(t.shape[1] ** 2, t.shape[2] ** 2)
             E = e if E is None else E @ e
         return np.sort(np.abs(np.linalg.eigvals(E)))[::-1]
-    th, to = transfer(res.dense_tensors()), transfer(B)
+    th, to = transfer(res.dense_tensors(), res.lam), transfer(B, S)
     assert abs(th[0] - 1) < 1e-8 and np.abs(th[:6] - to[:6]).max() < 10 * err.total_error     # both cells carry that error
+    for t, sl in zip(res.dense_tensors(), res.lam):     # right-canonical where it carries weight (the gauge blocks are rectangular
+        X = np.einsum("pab,pcb->ac", t, t.conj())     #  where the two chains keep different numbers of states in a sector)
+        k = np.nonzero(np.asarray(sl) > 1e-6)[0]
+        assert np.abs(X[np.ix_(k, k)] - np.eye(len(k))).max() < 1e-4
     Tr, lr, fr = io.insert_cells(Ts, ls, fs, res.dense_tensors(), res.lam, cut, n_cell)
     Tv, lv, fv = dense(mv)
     ov = io.overlap(Tv, lv, fv, Tr, lr, fr)

@@ -7,13 +7,14 @@ from oracle import slater_oracle as orc
 from temfpy_amd import slater
 seed = int(sys.argv[1])
 rng = np.random.default_rng(seed)
-L = int(rng.integers(2, 29)); rng_h = float(rng.choice([0.7, 1.5, 3.0, 6.0])); cplx = bool(rng.integers(0, 2))
+max_L = int(sys.argv[2]) if len(sys.argv) > 2 else 28
+L = int(rng.integers(2, max_L + 1)); rng_h = float(rng.choice([0.7, 1.5, 3.0, 6.0])); cplx = bool(rng.integers(0, 2))
 x, y = np.meshgrid(np.arange(L), np.arange(L), indexing="ij")
 M = rng.normal(size=(2, L, L)) * np.exp(-abs(x - y) / rng_h)
 H = M[0] + (1j * M[1] if cplx else 0); H = H + H.conj().T
 N = int(rng.integers(0, L + 1)) if rng.integers(0, 3) == 0 else None
 spinful = [None, None, None, None, "simple", "PH"][int(rng.integers(0, 6))]
-chi = int(rng.choice([2, 5, 16, 40, 128]))
+chi = int(rng.choice([2, 5, 16, 40, 128] if max_L <= 28 else [16, 40, 128, 300]))
 Lf = L * (1 if spinful is None else 2)
 oc = int(rng.integers(1, Lf)) if (Lf > 1 and rng.integers(0, 2)) else None
 print(f"seed {seed}: L={L} range={rng_h} complex={cplx} N={N} spinful={spinful} chi={chi} oc={oc}")
@@ -35,6 +36,12 @@ for b in range(Lf + 1):
     ea, eo = np.asarray(a.e), np.asarray(o.e)
     print(b, "k", len(ea), len(eo), "chi", len(a.lam), len(o.lam), "sets equal", same,
           "max|de|", (np.abs(ea - eo).max() if len(ea) == len(eo) and len(ea) else None))
+    if len(ea) != len(eo):
+        w = lambda e: np.minimum(e, 1 - e)
+        print("   weakest hip   ", np.sort(w(ea))[:16])
+        print("   weakest oracle", np.sort(w(eo))[:16])
     if not same and len(ea) == len(eo):
         print("   e hip   ", np.array2string(ea, precision=15, max_line_width=250))
         print("   e oracle", np.array2string(eo, precision=15, max_line_width=250))
+eng = slater._engine("cuda:0")
+print("range finder: width", eng.range_width, "iterations", eng.range_iterations_used, "smallest captured sigma", eng.range_floor)
