@@ -938,6 +938,8 @@ class _Projector:
         # ================= results =================
         t4 = time.perf_counter()
         h_sv, h_cnt = d_sv.cpu().numpy(), d_cnt.cpu().numpy()
+        if not np.isfinite(h_sv).all():      # (never silently: a NaN in a factorisation would otherwise just thin out the bonds)
+            raise FloatingPointError("non-finite Schmidt values in the canonicalisation of the projected MPS")
         b_lo = min(o for bo in Bho for o in bo.values())
         b_hi = max(Bho[j][c] + v[1] * self.sect[j][c] for j in range(Ls) for c, v in Winfo[j].items())
         h_b = d_ar[b_lo: b_hi].cpu().numpy()
