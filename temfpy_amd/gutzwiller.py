@@ -881,6 +881,8 @@ class _Projector:
             else:
                 norm = float(np.sqrt(cell["eta"]))      # norm of the projected state per unit cell
             self.timings["sweeps"] = time.perf_counter() - t2
+            if not bool(torch.isfinite(torch.view_as_real(d_ar) if self.cplx else d_ar).all()):
+                raise FloatingPointError("non-finite entries after the QR sweeps of the projected MPS")
             if os.environ.get("TMF_GW_DEBUG"):      # development aid: the triangular factors of both sweeps, per bond and sector
                 h_all = d_ar.cpu().numpy()
                 self.debug = {"R": {(j, c): h_all[Rb[j][c]: Rb[j][c] + n * n].reshape(n, n).T.copy() for j in range(Ls + 1)
