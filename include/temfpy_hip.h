@@ -338,8 +338,10 @@ int tmf_copy_blocks_batched(int dtype, const tmf_copy_desc* d_desc, int nprob, i
 /* Householder QR of many matrices, one workgroup each: A (m x n, column-major) is replaced by the thin
  * orthonormal factor Q and R (n x n upper triangular; flags & 1: its conjugate transpose R^H instead) is
  * written to `R` (may be 0).  flags & 2: only R is wanted, Q is not formed (A is left holding the reflectors).  For m < n, Q is m x m followed by zero columns and R has zero rows beyond m,
- * so shapes stay fixed.  Orthogonal to machine precision for any rank (no rank decision): the `npc.qr` /
- * first half of `npc.svd` of TeNPy's MPS.canonical_form_finite behind gutzwiller.py:266 / :471. */
+ * so shapes stay fixed.  Orthogonal to machine precision for any rank (no rank decision; a column whose squared length
+ * underflows counts as zero): the `npc.qr` / first half of `npc.svd` of TeNPy's MPS.canonical_form_finite behind
+ * gutzwiller.py:266 / :471, and the orthonormal bases of range finders wider than 64 columns inside the replacement of
+ * numpy.linalg.eigh (slater.py:347) for cuts with more than 64 entangled orbitals. */
 typedef struct {
   uint64_t A, R;
   int32_t m, n, lda, ldr, flags, pad;
