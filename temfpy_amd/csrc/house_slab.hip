@@ -109,7 +109,7 @@ void house_slab_kernel(const tmf_slab_desc* __restrict__ desc, int w) {
       T tau = sc<T>::zero(), scal = sc<T>::zero(), beta = alpha;
       // (a column whose squared length underflows - the rounding noise of rounding noise, reached after a dozen steps past
       // the rank of an exactly rank-deficient block - is a zero column: no reflector.  Without the guard b_ = 0 and
-      // tau = 0 / 0 poisoned R: tools/soak_gutzwiller.py, pinned in tests/test_gpu_kernels.py.)
+      // tau = 0 / 0 poisoned R: tests/soak/soak_gutzwiller.py, pinned in tests/test_gpu_kernels.py.)
       if ((s_ > 0.0 || sc<T>::imag(alpha) != 0.0) && sc<T>::abs2(alpha) + s_ > 1e-290) {
         double b_ = sqrt(sc<T>::abs2(alpha) + s_);
         if (sc<T>::real(alpha) > 0.0) b_ = -b_;

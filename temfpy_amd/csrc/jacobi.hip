@@ -73,7 +73,7 @@ __global__ __launch_bounds__(512) void jacobi_kernel(const tmf_jacobi_desc* __re
   // itself; a tighter bound makes pairs at that level rotate for ever: 18 of 1023 cuts hit the cap).  The floor of 4 eps
   // is the accuracy of a rotation (c, s from rsq / rcp + Newton steps, a few ulp): below it a rotated pair is as
   // orthogonal as it gets, and without the floor every 3 x 3 problem with three significant columns kept "rotating" by
-  // rounding-level angles until the sweep cap (results correct, LinAlgError raised: tools/soak_small.py seed 1919).
+  // rounding-level angles until the sweep cap (results correct, LinAlgError raised: tests/soak/soak_small.py seed 1919).
   const double tol2 = 1.1e-16 * 1.1e-16 * (double)(p > 16 ? p : 16);
 
   int sweep = 0;

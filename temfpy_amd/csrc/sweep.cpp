@@ -465,7 +465,7 @@ struct Sweep {
   // Householder QR of slabs of any width in place (global-memory kernel, one workgroup per slab): the range finders wider
   // than the 64 columns of the slab kernel.  Orthogonal for any rank - the blocked Gram-Schmidt that used to run here lost
   // an entangled orbital on a spinful chain whose two species decouple exactly (rounding noise has no component outside
-  // span(Q)): tools/soak_small.py seed 30023, 80 instead of 81 orbitals at one cut, weak eigenvalues
+  // span(Q)): tests/soak/soak_small.py seed 30023, 80 instead of 81 orbitals at one cut, weak eigenvalues
   // off by 1 - 5 %.
   int house_general(const std::vector<Slab>& s_in) {
     std::vector<tmf_qr_desc> d;

@@ -287,7 +287,7 @@ class Engine:
     def house_general(self, base, rows, ld, cols):
         """Householder QR in place of slabs of any width (tmf_house_qr_batched: matrix in global memory, one workgroup per
         slab): the range finders wider than the slab kernel's 64 columns.  Orthogonal for any rank, where the blocked
-        Gram-Schmidt lost an entangled orbital of a spinful chain with exactly decoupled species (tools/soak_small.py seed 30023)."""
+        Gram-Schmidt lost an entangled orbital of a spinful chain with exactly decoupled species (tests/soak/soak_small.py seed 30023)."""
         base, rows, ld, cols = (np.asarray(x, np.int64) for x in (base, rows, ld, cols))
         keep = np.nonzero((rows > 0) & (cols > 0))[0]
         if keep.size == 0:

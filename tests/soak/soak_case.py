@@ -1,7 +1,7 @@
-"""One case of tools/soak_small.py in detail.  usage: python tools/soak_case.py <seed>"""
+"""One case of tests/soak/soak_small.py in detail.  usage: python tests/soak/soak_case.py <seed>"""
 import os, sys, warnings
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import slater_oracle as orc
 from temfpy_amd import slater

@@ -1,13 +1,13 @@
 """Randomised soak of the Gutzwiller projections of infinite cells: the hand-made random cells of
 tests/test_gpu_gutzwiller.py::test_infinite_mps_hand_made_cells over many seeds, sizes and label kinds.  Development aid.
-usage: python tools/soak_cells.py [cases] [first seed]"""
+usage: python tests/soak/soak_cells.py [cases] [first seed]"""
 import os
 import sys
 import warnings
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_gutzwiller as tg  # noqa: E402

@@ -1,13 +1,13 @@
 """Randomised soak of the Gutzwiller projections of finite chains (both kinds, both methods) against the CPU oracle fed with
 the same fermion MPS, using the acceptance check of tests/test_gpu_gutzwiller.py on random small chains.  Development aid.
-usage: python tools/soak_gutzwiller.py [cases] [first seed]"""
+usage: python tests/soak/soak_gutzwiller.py [cases] [first seed]"""
 import os
 import sys
 import warnings
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_gutzwiller as tg  # noqa: E402

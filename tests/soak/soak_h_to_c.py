@@ -2,7 +2,7 @@
 random sizes, ranges, fillings, some Hamiltonians with exactly degenerate levels.  Development aid."""
 import sys, numpy as np
 import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from temfpy_amd import slater
 bad = deg = 0
 for seed in range(300):

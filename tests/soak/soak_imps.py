@@ -1,13 +1,13 @@
 """Randomised soak of iMPS.MPS_to_iMPS against the CPU oracle fed with the same two finite MPS: dimerised chains with random
 hoppings (gapped), random length, cut, chi, Peierls phase and orthogonality centres.  Development aid.
-usage: python tools/soak_imps.py [cases] [first seed]"""
+usage: python tests/soak/soak_imps.py [cases] [first seed]"""
 import os
 import sys
 import warnings
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import imps_oracle as io  # noqa: E402

@@ -1,13 +1,13 @@
 """Randomised soak of pfaffian.C_to_MPS (Majorana basis) against the CPU oracle on small random BdG chains: random length,
 coupling range, chi_max and orthogonality centre.  Development aid, not part of the tests (it imports the oracle).
-usage: python tools/soak_pfaffian.py [cases] [first seed]"""
+usage: python tests/soak/soak_pfaffian.py [cases] [first seed]"""
 import os
 import sys
 import warnings
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import pfaffian_oracle as porc  # noqa: E402

@@ -3,14 +3,14 @@ into random contiguous site ranges, every range converted on its own and compare
 (tensor blocks, Schmidt values, occupation masks).  One GPU, no process group: every range decides the range-finder width on
 its own, so cases in which a shard would decide differently from the whole chain are reported separately (the multi-GPU
 path reduces those decisions over the ranks).  Development aid.
-usage: python tools/soak_shards.py [cases] [first seed] [largest L]"""
+usage: python tests/soak/soak_shards.py [cases] [first seed] [largest L]"""
 import os
 import sys
 import warnings
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from temfpy_amd import slater  # noqa: E402

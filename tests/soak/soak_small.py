@@ -1,14 +1,14 @@
 """Randomised soak of slater.C_to_MPS against the CPU oracle on small inputs: random length, filling, hopping range, chi_max,
 spinful mode and orthogonality centre.  A mismatch prints the case (seed) and the script exits non-zero.  Development aid,
 not part of the tests (it imports the oracle).
-usage: python tools/soak_small.py [cases] [first seed] [largest L, default 28]"""
+usage: python tests/soak/soak_small.py [cases] [first seed] [largest L, default 28]"""
 import os
 import sys
 import warnings
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import slater_oracle as orc  # noqa: E402

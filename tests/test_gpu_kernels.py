@@ -1140,7 +1140,7 @@ def test_jacobi_every_small_size(eng, cplx, left_only):
     """One-sided Jacobi on every problem size 1 .. 24 and a few larger odd ones (an odd number of active columns leaves
     one player of the tournament idle; sizes up to 16 run with 64 lanes per pair): converges within a few sweeps,
     singular values to 1e-12, orthonormal vectors.  Includes the 3 x 3 triangular factor of a cut of an L = 14 chain that
-    did not converge before the idle player's partner was kept out of the reductions (tools/soak_small.py, seed 1919)."""
+    did not converge before the idle player's partner was kept out of the reductions (tests/soak/soak_small.py, seed 1919)."""
     setup(eng, cplx)
     rng = np.random.default_rng(77)
     ps = list(range(1, 25)) + [31, 33, 47, 63]
@@ -1172,7 +1172,7 @@ def test_householder_far_past_the_rank(eng, kernel):
     """Householder QR of exactly rank-deficient blocks with many more steps than rank (Gutzwiller-projected tensors: zero rows,
     rank 4 of 16 x 19): past the rank every step works on the rounding noise of the previous one, whose squared length
     underflows after a dozen steps; such a column is a zero column.  (Before that guard: tau = 0 / 0, NaN in R, wrong
-    Schmidt values from that bond on - tools/soak_gutzwiller.py seed 67; the first matrix is the one from that case.)"""
+    Schmidt values from that bond on - tests/soak/soak_gutzwiller.py seed 67; the first matrix is the one from that case.)"""
     lib = eng.lib
     rng = np.random.default_rng(3)
     mats = [np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kernels", "qr_rank4_16x19.npy"))]
