@@ -460,13 +460,25 @@ extern "C" int tmf_jacobi_compact_batched(int dtype, const tmf_jacobi_desc* d_de
 // ---------------------------------------------------------------------------------------------
 namespace tmf {
 
+// widest block (a power of two <= 32) whose pair, x2 with the rotation accumulator, fits 150 KiB of LDS for a p-row problem
+__host__ __device__ inline int jacobi_block_width(int p, bool with_v, size_t elem) {
+  int bw = 32;
+  while (bw > 1 && (size_t)(with_v ? 2 : 1) * 2 * bw * p * elem + 64 > 150 * 1024) bw >>= 1;
+  return bw;
+}
+
 template <typename T, bool WITH_V>
-__global__ __launch_bounds__(512) void jacobi_block_kernel(const tmf_jacobi_desc* __restrict__ desc, int bw,
+__global__ __launch_bounds__(512) void jacobi_block_kernel(const tmf_jacobi_desc* __restrict__ desc, int,
                                                            int32_t* __restrict__ sweeps_out) {
   extern __shared__ __align__(16) unsigned char smem[];
   const tmf_jacobi_desc d = desc[blockIdx.x];
   const int p = d.p;
   if (p <= 0) return;
+  // The block width follows from the problem's OWN size, not from the largest problem of the launch: the order of the
+  // rotations - and with it every rounding - must not depend on what else is in the batch.  (A shard of a multi-GPU
+  // conversion and its neighbour both compute the cut between them; with the width taken from the launch they disagreed
+  // by 1e-16, which exactly degenerate spectra turn into different bases: tests/soak/soak_shards.py seed 1952.)
+  const int bw = jacobi_block_width(p, WITH_V, sizeof(T));
   const int nc = 2 * bw;                               // columns resident in LDS
   T* Xs = reinterpret_cast<T*>(smem);                  // Xs[c * p + r], c < nc
   T* Vs = Xs + (size_t)nc * p;                         // only WITH_V
@@ -617,9 +629,12 @@ extern "C" int tmf_jacobi_block_batched(int dtype, int with_v, const tmf_jacobi_
     set_error("tmf_jacobi_block_batched: p = %d not in 1..512", max_p);
     return TMF_E_LIMIT;
   }
-  int bw = 32;  // widest block whose pair (x2 with the rotation accumulator) fits 150 KiB of LDS
-  while (bw > 1 && (size_t)(with_v ? 2 : 1) * 2 * bw * max_p * elem + 64 > 150 * 1024) bw >>= 1;
-  const size_t lds = (size_t)(with_v ? 2 : 1) * 2 * bw * max_p * elem + 64;
+  size_t lds = 0;          // every problem picks its own block width (jacobi_block_width): room for the largest need
+  for (int q = 1; q <= max_p; ++q) {
+    const size_t need = (size_t)(with_v ? 2 : 1) * 2 * jacobi_block_width(q, with_v != 0, elem) * q * elem + 64;
+    lds = need > lds ? need : lds;
+  }
+  const int bw = 0;        // (kernel argument kept for the launch signature; unused)
   if (lds > 160 * 1024 || lds < (size_t)max_p * 8) {
     set_error("tmf_jacobi_block_batched: p = %d does not fit the LDS staging", max_p);
     return TMF_E_LIMIT;

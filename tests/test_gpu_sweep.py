@@ -213,6 +213,46 @@ def test_site_sharding_reproduces_unsharded_result_bitwise():
                 assert np.array_equal(part.bonds[b].masks, full.bonds[b].masks)
 
 
+def test_site_sharding_bitwise_on_the_wide_range_finder():
+    """A spinful chain whose central cuts carry more than 64 entangled orbitals (range finder at 128 columns, block Jacobi
+    in global memory), cut into two ranges: bit-identical to the unsharded conversion.  The block width of that Jacobi
+    kernel used to follow the LARGEST problem of the launch, so a shard and the whole chain rotated in different orders
+    (1e-16 apart, different bases inside the exactly degenerate multiplets of the two spin species:
+    tests/soak/soak_shards.py seed 1952, whose input this is)."""
+    import warnings
+
+    from temfpy_amd import slater
+    from temfpy_amd.engine import Engine
+    from temfpy_amd.schmidt_utils import to_stopping_condition
+
+    rng = np.random.default_rng(1952)
+    L = int(rng.integers(4, 111))
+    rng_h = float(rng.choice([0.7, 1.5, 3.0, 6.0]))
+    cplx = bool(rng.integers(0, 2))
+    x, y = np.meshgrid(np.arange(L), np.arange(L), indexing="ij")
+    M = rng.normal(size=(2, L, L)) * np.exp(-abs(x - y) / rng_h)
+    H = M[0] + (1j * M[1] if cplx else 0)
+    C, _ = slater.correlation_matrix(H + H.conj().T)
+    C = slater.spinful_correlation_matrix(C, True)
+    Lf, oc, chi = len(C), 96, 32
+    assert Lf == 174
+    tr = to_stopping_condition({"chi_max": chi})
+    eng = Engine("cuda:0")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        full = eng.run(C, tr, oc, Lf)
+        assert eng.range_width == 128
+        for (lo, hi) in ((0, 70), (70, 174)):
+            part = eng.run(C, tr, oc, Lf, site_range=(lo, hi))
+            assert eng.range_width == 128
+            for b in range(lo, hi + 1):
+                assert np.array_equal(part.bonds[b].e, full.bonds[b].e), b
+                assert np.array_equal(part.bonds[b].lam, full.bonds[b].lam) and np.array_equal(part.bonds[b].masks, full.bonds[b].masks)
+            for i in range(lo, hi):
+                for bp, bf in zip(part.sites[i].blocks, full.sites[i].blocks):
+                    assert bp[:5] == bf[:5] and np.array_equal(bp[5], bf[5]), i
+
+
 def test_block_local_elimination_against_fully_pivoted_lu():
     """Default Schur-complement path (row search inside the 64 x 64 diagonal blocks, tmf_diag_inverse_batched) against the
     fully pivoted blocked LU on a chain whose always-blocks span several diagonal blocks; the forced fallback (statistics
