@@ -394,13 +394,14 @@ def _gemm_tiles(d):
     return tiles, tn
 
 
-def _dominant_eigenpair(apply, v0, tol=1e-13, krylov=24, restarts=400):
+def _dominant_eigenpair(apply, v0, tol=2e-15, krylov=24, restarts=400, stagnation=1e-11):
     """Eigenvalue of largest modulus and its eigenvector of the linear map `apply` (host vector -> host vector) by restarted
     Arnoldi iteration: the role of scipy's ARPACK behind TeNPy's ``TransferMatrix.eigenvectors``.  Only the Krylov
     bookkeeping (dot products over <= `krylov` vectors, one small Hessenberg eigenproblem per restart) is done here."""
     v = np.asarray(v0)
     v = v / np.linalg.norm(v)
     m = min(krylov, v.size)
+    last_res = np.inf
     for _ in range(restarts):
         V = np.zeros((m + 1, v.size), v.dtype)
         H = np.zeros((m + 1, m), v.dtype)
@@ -431,8 +432,11 @@ def _dominant_eigenpair(apply, v0, tol=1e-13, krylov=24, restarts=400):
         res = abs(beta * y[-1]) / max(np.linalg.norm(y), 1e-300)
         v = y @ V[:used]
         v = v / np.linalg.norm(v)
-        if res <= tol * abs(theta):
+        # done at `tol`, or when the residual has stopped falling at the rounding level of `apply` (the Schmidt values of
+        # the boundary bond are square roots of Gram eigenvalues: an eigenvector good to 1e-13 leaves noise of 3e-7 there)
+        if res <= tol * abs(theta) or (res <= stagnation * abs(theta) and res > 0.5 * last_res):
             return complex(theta), v
+        last_res = res
     raise np.linalg.LinAlgError("Arnoldi iteration for the dominant eigenvector of the transfer matrix did not converge")
 
 
@@ -899,22 +903,18 @@ class _Projector:
             nat.check(lib.tmf_jacobi_compact_batched(self.dt, tabs_d["jc"].data_ptr(), n_sec_tot, int(jd["p"].max()),
                                                      d_sw.data_ptr(), s1), "tmf_jacobi_compact_batched")
             if cell is not None:
-                # The bond that closes the cell is already in Schmidt form (_close_cell: left environment diag(lam^2), right
-                # environment 1), and both of its copies must carry the SAME basis: on the last bond the identity, on bond 0
-                # the unitary L_0 / sqrt(eta) the leftward sweep arrived with (C_0 = diag(lam) L_0 / sqrt(eta)).
-                ident, g0 = {}, []
+                # The bond that closes the cell must carry the SAME basis on both of its copies.  On the last bond the SVD of
+                # C_Ls = R_Ls / sqrt(eta) just taken stands: R_Ls is diag(lam) of _close_cell pushed through the cell once more
+                # in factored form, which reproduces the Schmidt values of the fixed point and damps what the Gram matrices
+                # put there by rounding (directions the projected cell annihilates came out of them at 1e-7 .. 1e-6).  Bond 0
+                # takes values and count from there, and its basis is that one carried through the unitary the leftward
+                # sweep arrived with: L_0 Vz_0 = sqrt(eta) L_Ls Vz_Ls with L_Ls = 1, i.e. Vz_0 = L_0^H Vz_Ls / sqrt(eta).
+                g0 = []
                 for q, n in self.sect[0].items():
-                    k, ql = cell["count"][q], self.end_of[q]
-                    e = np.zeros((n, n), self.np_dt)
-                    e[np.arange(k), np.arange(k)] = 1.0
-                    d_ar[Vzb[Ls][ql]: Vzb[Ls][ql] + n * n] = torch.from_numpy(e.reshape(-1)).to(self.device)
-                    ident[q] = torch.from_numpy(np.eye(n, dtype=self.np_dt).reshape(-1).copy()).to(self.device)
-                    g0.append((P(Lb[0][q]), ident[q].data_ptr(), P(Vzb[0][q]), n, n, n, n, n, n))
-                    for b_, c_ in ((0, q), (Ls, ql)):
-                        d_sv[So[b_][c_]: So[b_][c_] + n] = 0.0
-                        d_sv[So[b_][c_]: So[b_][c_] + k] = torch.from_numpy(np.ascontiguousarray(cell["lam"][q])).to(self.device)
-                        d_cnt[cnt_index[(b_, c_)]] = k
-                keep_alive.append(ident)
+                    ql = self.end_of[q]
+                    g0.append((P(Lb[0][q]), P(Vzb[Ls][ql]), P(Vzb[0][q]), n, n, n, n, n, n))
+                    d_sv[So[0][q]: So[0][q] + n] = d_sv[So[Ls][ql]: So[Ls][ql] + n]
+                    d_cnt[cnt_index[(0, q)]] = d_cnt[cnt_index[(Ls, ql)]]
                 self._gemm_now(g0, 1, s1, keep_alive, alpha=1.0 / norm)
             gemm(tail[1], s1)
             gemm(tail[2], s1, opA=1)
@@ -1307,6 +1307,43 @@ def _check_unit_cell_width(mps, unit_cell_width, group=2):
     return unit_cell_width
 
 
+def _drop_dead_boundary_states(blocks, lam, ch):
+    """Infinite cell: a state of the closing bond whose row of the first tensor vanished (the batched Gram-Schmidt found it
+    dependent on stronger ones: a direction the Gram matrices of the fixed points put there by rounding, weight < 1e-12)
+    is removed from both copies of that bond."""
+    n0 = len(lam[0])
+    w = np.zeros(n0)
+    for (_p, _ql, _qr, l0, l1, _r0, _r1, a) in blocks[0]:
+        w[l0:l1] += (np.abs(a) ** 2).sum(axis=1)
+    keep = w > 0.25
+    if keep.all() or not keep.any():
+        return blocks, lam, ch
+    pos = np.cumsum(keep) - 1
+
+    def cut(bl, rows):
+        out = []
+        for (p, ql, qr, l0, l1, r0, r1, a) in bl:
+            lo, hi = (l0, l1) if rows else (r0, r1)
+            sel = keep[lo:hi]
+            if not sel.any():
+                continue
+            a2 = a[sel] if rows else a[:, sel]
+            n_lo = int(pos[lo + int(np.argmax(sel))])
+            rng_ = (n_lo, n_lo + int(sel.sum()))
+            out.append((p, ql, qr, rng_[0], rng_[1], r0, r1, a2) if rows else (p, ql, qr, l0, l1, rng_[0], rng_[1], a2))
+        return out
+    blocks = list(blocks)
+    if len(blocks) == 1:
+        blocks[0] = cut(cut(blocks[0], True), False)
+    else:
+        blocks[0], blocks[-1] = cut(blocks[0], True), cut(blocks[-1], False)
+    lam, ch = list(lam), list(ch)
+    new = np.asarray(lam[0])[keep]
+    lam[0] = lam[-1] = new / np.linalg.norm(new)
+    ch[0] = ch[-1] = np.asarray(ch[0])[keep]
+    return blocks, lam, ch
+
+
 def _finish(mps, inplace, res):
     if getattr(mps, "_temfpy_amd", None) is not None:      # a TeNPy MPS came in: a TeNPy MPS goes out (gutzwiller.py:277-281)
         try:
@@ -1368,6 +1405,8 @@ def abrikosov(mps, *, inplace: bool = False, return_canonical: bool = True, cuto
     if infinite:
         blocks[-1] = [(p, ql, shift(qr)) + tuple(rest) for (p, ql, qr, *rest) in blocks[-1]]
         ch[-1] = ch[0]
+        if return_canonical:
+            blocks, lam, ch = _drop_dead_boundary_states(blocks, lam, ch)
         res = SpiniMPSData(blocks, lam, ch, None, norm, ucw, 0, timings=pr.timings)
         if not return_canonical:
             res.form = [None] * res.L
@@ -1414,6 +1453,8 @@ def abrikosov_ph(mps, *, inplace: bool = False, return_canonical: bool = True, c
         warn("The MPS is not in canonical form after Gutzwiller projection.\nConsider setting 'return_canonical=True'")
     if infinite:
         ch[-1] = ch[0]
+        if return_canonical:
+            blocks, lam, ch = _drop_dead_boundary_states(blocks, lam, ch)
         res = SpiniMPSData(blocks, lam, ch, spin, norm, ucw, cell, timings=pr.timings)
         if not return_canonical:
             res.form = [None] * res.L

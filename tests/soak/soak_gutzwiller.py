@@ -45,6 +45,9 @@ for seed in range(first, first + n_cases):
                     vanish += 1
                     continue
                 raise
+        if res.norm < 1e-13:        # the projection leaves rounding noise only (relative comparisons mean nothing there)
+            vanish += 1
+            continue
         tg.check(res, T, q, lam, oc, kind, isometry=None if method == "parallel" else 1e-10)
     except NotImplementedError as e:        # documented size limit (a charge sector above 512 states)
         print("limit", tag, "->", str(e)[:80], flush=True)
