@@ -310,3 +310,32 @@ def test_sharded_range_finder_decisions_are_global():
     eng.coord = None
     part = eng.run(C, tr, L // 2, L, site_range=ranges[0])       # undecorated end shard: no iteration, other gauge
     assert eng.range_iterations_used == 0
+
+
+def test_config3_shards_of_an_eight_way_split_are_bitwise_the_unsharded_conversion():
+    """The multi-GPU headline (`bench.py --gpus 8`) assembles the benchmark chain from eight site ranges, and a cut on a range
+    boundary is computed by both neighbours.  Every cut of every range (eigenvalues, Schmidt values, occupation masks) and
+    every seventh site tensor are bit-identical to the one-GPU conversion (checked here range by range on one GPU; the
+    cross-rank reduction of the range-finder decisions does not fire on this input)."""
+    from tests_inputs import random_hopping
+    from temfpy_amd import slater
+    from temfpy_amd.engine import Engine
+    from temfpy_amd.multi_gpu import shard_sites
+    from temfpy_amd.schmidt_utils import to_stopping_condition
+
+    L, chi = 1024, 512
+    C, _ = slater.correlation_matrix(random_hopping(L, 0))
+    tr = to_stopping_condition({"chi_max": chi})
+    eng = Engine("cuda:0")
+    full = eng.run(C, tr, L // 2, L)
+    setting = (eng.range_width, eng.range_iterations_used)
+    for (lo, hi) in shard_sites(L, L // 2, 8):
+        part = eng.run(C, tr, L // 2, L, site_range=(lo, hi))
+        assert (eng.range_width, eng.range_iterations_used) == setting
+        for b in range(lo, hi + 1):
+            assert np.array_equal(part.bonds[b].e, full.bonds[b].e), b
+            assert np.array_equal(part.bonds[b].lam, full.bonds[b].lam) and np.array_equal(part.bonds[b].masks, full.bonds[b].masks), b
+        for i in range(lo, hi, 7):
+            assert len(part.sites[i].blocks) == len(full.sites[i].blocks)
+            for bp, bf in zip(part.sites[i].blocks, full.sites[i].blocks):
+                assert bp[:5] == bf[:5] and np.array_equal(bp[5], bf[5]), i
