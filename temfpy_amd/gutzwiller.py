@@ -1308,39 +1308,48 @@ def _check_unit_cell_width(mps, unit_cell_width, group=2):
 
 
 def _drop_dead_boundary_states(blocks, lam, ch):
-    """Infinite cell: a state of the closing bond whose row of the first tensor vanished (the batched Gram-Schmidt found it
+    """Infinite cell: a state of a bond whose row of the tensor to its right vanished (the batched Gram-Schmidt found it
     dependent on stronger ones: a direction the Gram matrices of the fixed points put there by rounding, weight < 1e-12)
-    is removed from both copies of that bond."""
-    n0 = len(lam[0])
-    w = np.zeros(n0)
-    for (_p, _ql, _qr, l0, l1, _r0, _r1, a) in blocks[0]:
-        w[l0:l1] += (np.abs(a) ** 2).sum(axis=1)
-    keep = w > 0.25
-    if keep.all() or not keep.any():
-        return blocks, lam, ch
-    pos = np.cumsum(keep) - 1
+    is removed from that bond - on the closing bond from both of its copies.  The rows of the tensor to the left lose the
+    removed column (<= 1e-7 of their norm, measured) and are rescaled to unit length."""
+    blocks, lam, ch = list(blocks), list(lam), list(ch)
+    Ls = len(blocks)
+    for j in range(Ls):
+        n0 = len(lam[j])
+        w = np.zeros(n0)
+        for (_p, _ql, _qr, l0, l1, _r0, _r1, a) in blocks[j]:
+            w[l0:l1] += (np.abs(a) ** 2).sum(axis=1)
+        keep = w > 0.25
+        if keep.all() or not keep.any():
+            continue
+        pos = np.cumsum(keep) - 1
 
-    def cut(bl, rows):
-        out = []
-        for (p, ql, qr, l0, l1, r0, r1, a) in bl:
-            lo, hi = (l0, l1) if rows else (r0, r1)
-            sel = keep[lo:hi]
-            if not sel.any():
-                continue
-            a2 = a[sel] if rows else a[:, sel]
-            n_lo = int(pos[lo + int(np.argmax(sel))])
-            rng_ = (n_lo, n_lo + int(sel.sum()))
-            out.append((p, ql, qr, rng_[0], rng_[1], r0, r1, a2) if rows else (p, ql, qr, l0, l1, rng_[0], rng_[1], a2))
-        return out
-    blocks = list(blocks)
-    if len(blocks) == 1:
-        blocks[0] = cut(cut(blocks[0], True), False)
-    else:
-        blocks[0], blocks[-1] = cut(blocks[0], True), cut(blocks[-1], False)
-    lam, ch = list(lam), list(ch)
-    new = np.asarray(lam[0])[keep]
-    lam[0] = lam[-1] = new / np.linalg.norm(new)
-    ch[0] = ch[-1] = np.asarray(ch[0])[keep]
+        def cut(bl, rows):
+            out = []
+            for (p, ql, qr, l0, l1, r0, r1, a) in bl:
+                lo, hi = (l0, l1) if rows else (r0, r1)
+                sel = keep[lo:hi]
+                if not sel.any():
+                    continue
+                a2 = a[sel] if rows else a[:, sel]
+                n_lo = int(pos[lo + int(np.argmax(sel))])
+                rng_ = (n_lo, n_lo + int(sel.sum()))
+                out.append((p, ql, qr, rng_[0], rng_[1], r0, r1, a2) if rows else (p, ql, qr, l0, l1, rng_[0], rng_[1], a2))
+            return out
+        left = (j - 1) % Ls
+        blocks[j] = cut(blocks[j], True)
+        blocks[left] = cut(blocks[left], False)
+        nl = len(lam[left])                      # rescale the rows of the tensor that lost a column
+        w2 = np.zeros(nl)
+        for (_p, _ql, _qr, l0, l1, _r0, _r1, a) in blocks[left]:
+            w2[l0:l1] += (np.abs(a) ** 2).sum(axis=1)
+        sc = np.where(w2 > 0.25, 1.0 / np.sqrt(np.maximum(w2, 1e-300)), 1.0)
+        blocks[left] = [(p, ql, qr, l0, l1, r0, r1, a * sc[l0:l1, None]) for (p, ql, qr, l0, l1, r0, r1, a) in blocks[left]]
+        new = np.asarray(lam[j])[keep]
+        lam[j] = new / np.linalg.norm(new)
+        ch[j] = np.asarray(ch[j])[keep]
+        if j == 0:
+            lam[Ls], ch[Ls] = lam[0], ch[0]
     return blocks, lam, ch
 
 
