@@ -299,7 +299,7 @@ def main():
                                            f"svd_min=1e-6; sites sharded over {world} ranks {ranges}; host C on rank 0 -> "
                                            f"RCCL broadcast -> per-rank PCIe download into shared page-locked host memory -> "
                                            f"one assembled MPS on rank 0; the download of conversion k overlaps conversion k+1",
-                               "N_fermions": N, "backend": dist.get_backend(),
+                               "N_fermions": N, "backend": dist.get_backend(), "contexts_per_rank": len(group.engines),
                                "busy_ms_per_rank": [round(float(x), 2) for x in busy_k.mean(axis=0)]},
                        replicas=replicas)
             if os.path.exists(REF_SUMMARY) and L == 1024 and chi == 512 and not dry:
