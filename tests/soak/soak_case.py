@@ -17,14 +17,18 @@ spinful = [None, None, None, None, "simple", "PH"][int(rng.integers(0, 6))]
 chi = int(rng.choice([2, 5, 16, 40, 128] if max_L <= 28 else [16, 40, 128, 300]))
 Lf = L * (1 if spinful is None else 2)
 oc = int(rng.integers(1, Lf)) if (Lf > 1 and rng.integers(0, 2)) else None
-print(f"seed {seed}: L={L} range={rng_h} complex={cplx} N={N} spinful={spinful} chi={chi} oc={oc}")
+trunc = {"chi_max": chi}
+if os.environ.get("SOAK_TRUNC"):
+    trunc["svd_min"] = float(rng.choice([1e-3, 1e-5, 1e-6, 1e-7]))
+    trunc["degeneracy_tol"] = float(rng.choice([1e-12, 1e-9, 1e-6]))
+print(f"seed {seed}: L={L} range={rng_h} complex={cplx} N={N} spinful={spinful} trunc={trunc} oc={oc}")
 C, Np = orc.correlation_matrix(H, N)
 print("particles", Np, "eigenvalues of H closest to 0:", np.sort(np.abs(np.linalg.eigvalsh(H)))[:3])
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
-    cuts, sites = orc.c_to_mps(C, {"chi_max": chi}, ortho_center=oc, spinful=spinful)
+    cuts, sites = orc.c_to_mps(C, dict(trunc), ortho_center=oc, spinful=spinful)
     try:
-        mps = slater.C_to_MPS(C, {"chi_max": chi}, ortho_center=oc, spinful=spinful, as_tenpy=False)
+        mps = slater.C_to_MPS(C, dict(trunc), ortho_center=oc, spinful=spinful, as_tenpy=False)
     except Exception as e:
         print("HIP path raised", type(e).__name__, e)
         for b, c_ in enumerate(cuts):
@@ -45,3 +49,9 @@ for b in range(Lf + 1):
         print("   e oracle", np.array2string(eo, precision=15, max_line_width=250))
 eng = slater._engine("cuda:0")
 print("range finder: width", eng.range_width, "iterations", eng.range_iterations_used, "smallest captured sigma", eng.range_floor)
+occ = oc or Lf // 2
+T1, T2 = orc.dense_tensors(cuts, sites), mps.dense_tensors()
+n1 = orc.mps_overlap(T1, cuts[occ].lam, T1, cuts[occ].lam, occ); n2 = orc.mps_overlap(T2, mps.lam[occ], T2, mps.lam[occ], occ)
+print("norms", abs(n1), abs(n2), "1 - overlap", 1 - abs(orc.mps_overlap(T1, cuts[occ].lam, T2, mps.lam[occ], occ)) / np.sqrt(abs(n1 * n2)))
+for i, (a, b) in enumerate(zip(T1, T2)):
+    print(" site", i, "max | |a| - |b| |", np.abs(np.abs(a) - np.abs(b)).max())
