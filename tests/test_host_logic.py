@@ -325,3 +325,34 @@ def test_dead_states_are_removed_from_the_bonds_of_a_cell():
     np.testing.assert_allclose(w, 1.0, atol=1e-14)                                              # rows rescaled
     same = _drop_dead_boundary_states([b1, b1], [lam[1], lam[1], lam[1]], [ch[1]] * 3)          # nothing to remove
     assert same[0][0] is b1 and len(same[1][0]) == 2
+
+
+def test_tenpy_switch_and_back_reference():
+    """as_tenpy = False / None / True on the entry points (slater._maybe_tenpy) and the reference a TeNPy object returned by the
+    package carries to its device-side container (gutzwiller.native), without TeNPy installed."""
+    import pytest
+
+    from temfpy_amd.gutzwiller import native
+    from temfpy_amd.slater import _maybe_tenpy
+
+    class NoTenpy:
+        L, lam = 3, [np.ones(1), np.ones(2), np.ones(2), np.ones(1)]
+
+        def to_tenpy(self):
+            raise ImportError("No module named 'tenpy'")
+
+    class Fake:
+        def __init__(self, own, L=3, chi=(2, 2)):
+            self._temfpy_amd, self.L, self.chi = own, L, list(chi)
+
+    r = NoTenpy()
+    assert _maybe_tenpy(r, False) is r and _maybe_tenpy(r, None) is r
+    with pytest.raises(ImportError):
+        _maybe_tenpy(r, True)
+    assert native(r) is r and native(Fake(r)) is r
+    with pytest.raises(ValueError, match="modified"):
+        native(Fake(r, L=4))
+    with pytest.raises(ValueError, match="modified"):
+        native(Fake(r, chi=(2, 3)))
+    inf = Fake(r, chi=(1, 2, 2))           # TeNPy lists bonds 0 .. L-1 of an infinite MPS
+    assert native(inf) is r
