@@ -1377,7 +1377,9 @@ def abrikosov(mps, *, inplace: bool = False, return_canonical: bool = True, cuto
               method: Literal["sequential", "parallel"] = "parallel"):
     """Projection from Abrikosov fermions to a spin-1/2 Hilbert space (gutzwiller.py:95-281): sites 2i, 2i+1
     hold f_up, f_down; single occupation of f_up -> up, of f_down -> down, empty and double occupation dropped.
-    No charges survive."""
+    No charges survive.  ``mps``: a finite MPS (``MPSData`` / ``PfMPSData``) or the unit cell of an infinite one
+    (``iMPS.iMPSData``; then ``q_left`` - the charge sector of the leftmost virtual leg that is kept, in the cell's own labels -
+    is required, :197-206, and a :class:`SpiniMPSData` comes back)."""
     assert mps.L % 2 == 0, "Odd-length MPS cannot represent an Abrikosov fermion Hilbert space"   # :158-160
     fer = _as_fermions(mps)
     conserve = fer.conserve
@@ -1429,7 +1431,9 @@ def abrikosov_ph(mps, *, inplace: bool = False, return_canonical: bool = True, c
                  method: Literal["sequential", "parallel"] = "parallel"):
     """Projection from particle-hole rotated Abrikosov fermions (gutzwiller.py:284-486): sites 2i, 2i+1 hold
     f_up, f_down^dagger; zero occupation -> down, double occupation -> up, single occupation dropped.
-    Number-conserving input keeps S^z (2 S^z = number - bond index, :333, :438-441)."""
+    Number-conserving input keeps S^z (2 S^z = number - offset - bond index, :333, :438-441).  ``mps``: a finite MPS or the
+    unit cell of an infinite one (``iMPS.iMPSData``: ``parity`` selects the parity sector of the virtual legs and ``offset`` the
+    label shift, :322-334; a :class:`SpiniMPSData` comes back, its last tensor carrying the cell's 2 S^z, :446-447)."""
     assert mps.L % 2 == 0, "Odd-length MPS cannot represent an Abrikosov fermion Hilbert space"   # :354-356
     fer = _as_fermions(mps)
     conserve = fer.conserve
