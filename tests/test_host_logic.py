@@ -356,3 +356,34 @@ def test_tenpy_switch_and_back_reference():
         native(Fake(r, chi=(2, 3)))
     inf = Fake(r, chi=(1, 2, 2))           # TeNPy lists bonds 0 .. L-1 of an infinite MPS
     assert native(inf) is r
+
+
+def test_infinite_cell_adapter_labels():
+    """gutzwiller._fermions_from_imps (host side): the labels of the closing bond are those of bond 0 plus the charge of one
+    cell (mod 2 for parity labels), so that q_l + p = q_r holds on every site; form and charge kind are checked."""
+    import pytest
+
+    from temfpy_amd.gutzwiller import _fermions_from_imps
+    from temfpy_amd.iMPS import iMPSData
+
+    a = np.arange(1.0, 5.0).reshape(2, 2)
+    lam = [np.ones(2) / np.sqrt(2)] * 3
+    # number labels: bond 0 = [0, 1], bond 1 = [0, 1]; one particle per cell
+    blocks = [[(0, 0, 0, 0, 1, 0, 1, a[:1, :1]), (1, 0, 1, 0, 1, 1, 2, a[:1, 1:]), (0, 1, 1, 1, 2, 1, 2, a[1:, 1:])],
+              [(1, 0, 0, 0, 1, 0, 1, a[:1, :1]), (0, 1, 0, 1, 2, 0, 1, a[1:, :1]), (1, 1, 1, 1, 2, 1, 2, a[1:, 1:])]]
+    cell = iMPSData(blocks, lam, [np.array([0, 1])] * 3, 1, 2, conserve="N")
+    f = _fermions_from_imps(cell)
+    assert f.infinite and f.cell_charge == 1 and f.conserve == "N" and f.L == 2 and f.oc == 2
+    assert [x.tolist() for x in f.charges] == [[0, 1], [0, 1], [1, 2]]
+    for r in f.blocks:                                   # every packed block obeys q_l + p = q_r in these labels
+        assert int(r["cl"]) + int(r["p"]) == int(r["cr"])
+    par = iMPSData(blocks, lam, [np.array([0, 1])] * 3, 1, 2, conserve="parity")
+    g = _fermions_from_imps(par)
+    assert [x.tolist() for x in g.charges] == [[0, 1], [0, 1], [0, 1]] and g.perm[2].tolist() == [1, 0]      # (1, 2) mod 2, sorted
+    for r in g.blocks:
+        assert (int(r["cl"]) + int(r["p"])) % 2 == int(r["cr"])
+    with pytest.raises(ValueError, match="FermionSite must conserve"):
+        _fermions_from_imps(iMPSData(blocks, lam, [np.array([0, 1])] * 3, 1, 2, conserve="spin Sz"))
+    cell.form = ["B", None]
+    with pytest.raises(ValueError, match="right-canonical"):
+        _fermions_from_imps(cell)
