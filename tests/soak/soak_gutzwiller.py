@@ -1,6 +1,6 @@
 """Randomised soak of the Gutzwiller projections of finite chains (both kinds, both methods) against the CPU oracle fed with
 the same fermion MPS, using the acceptance check of tests/test_gpu_gutzwiller.py on random small chains.  Development aid.
-usage: python tests/soak/soak_gutzwiller.py [cases] [first seed]"""
+usage: python tests/soak/soak_gutzwiller.py [cases] [first seed] [largest L, default 12]"""
 import os
 import sys
 import warnings
@@ -15,10 +15,11 @@ from temfpy_amd import gutzwiller, slater  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_L = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 bad = vanish = 0
 for seed in range(first, first + n_cases):
     rng = np.random.default_rng(seed)
-    L = int(rng.integers(2, 13))
+    L = int(rng.integers(2, max_L + 1))
     rng_h = float(rng.choice([0.7, 1.5, 3.0]))
     cplx = bool(rng.integers(0, 2))
     x, y = np.meshgrid(np.arange(L), np.arange(L), indexing="ij")
@@ -26,7 +27,7 @@ for seed in range(first, first + n_cases):
     H = M[0] + (1j * M[1] if cplx else 0)
     H = H + H.conj().T
     kind = ["ph", "std"][int(rng.integers(0, 2))]
-    chi = int(rng.choice([16, 64, 256, 4096]))
+    chi = int(rng.choice([16, 64, 256, 4096] if max_L <= 12 else [16, 64, 256]))
     method = ["parallel", "sequential"][int(rng.integers(0, 2))]
     tag = f"seed {seed}: L={L} range={rng_h} complex={cplx} kind={kind} chi={chi} method={method}"
     try:
