@@ -592,6 +592,10 @@ typedef struct {
   double lu_min_pivot;       /* smallest |pivot| of the block-local elimination of the last sweep (0: method not used) */
   double lu_max_inverse;     /* its largest |entry| of a diagonal-block inverse (fallback above the cap)               */
   int64_t lu_fallbacks;      /* sweeps of this context that had to repeat the LU fully pivoted                */
+  /* the GEMM figures above split by kernel instantiation, so that they can be recomputed from a rocprofv3 kernel
+   * statistic alone: [0] gemm_kernel<T, 0, 64> (A B), [1] gemm_kernel<T, 1, 64> (A^H B), [2] gemm_kernel<T, *, 16> */
+  double gemm_split_ms[3], gemm_split_flops[3];
+  int64_t gemm_split_launches[3];
 } tmf_sweep_info;
 
 int tmf_sweep_begin(tmf_ctx* ctx, const void* C, const tmf_sweep_params* par);

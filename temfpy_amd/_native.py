@@ -129,7 +129,8 @@ class SweepInfo(C.Structure):
                 ("det_flops", C.c_double), ("det_all_ms", C.c_double), ("n_det", C.c_int64), ("n_gemm_launches", C.c_int64),
                 ("det_kind", C.c_int32), ("det_order", C.c_int32), ("range_width", C.c_int32), ("range_iterations", C.c_int32),
                 ("range_floor", C.c_double), ("n_fermion", C.c_int64), ("device_bytes", C.c_int64),
-                ("lu_min_pivot", C.c_double), ("lu_max_inverse", C.c_double), ("lu_fallbacks", C.c_int64)]
+                ("lu_min_pivot", C.c_double), ("lu_max_inverse", C.c_double), ("lu_fallbacks", C.c_int64),
+                ("gemm_split_ms", C.c_double * 3), ("gemm_split_flops", C.c_double * 3), ("gemm_split_launches", C.c_int64 * 3)]
 
 
 class BondView(C.Structure):

@@ -170,9 +170,17 @@ struct OutSlot {
   bool busy = false;      // a download is (or may be) running
   bool reserved = false;  // taken by the sweep in progress
   i64 ticket = -1;
+  bool waited = true;     // tmf_sweep_wait has returned this ticket's self-check deviations
   PinnedBuf checks;  // 8 doubles
   int n_checks = 0;
   int det_off_elems = 0;
+};
+
+// Self-check deviations of a finished download whose output block is reused before anybody waited for it.
+struct FinishedTicket {
+  i64 ticket;
+  int n;
+  double v[8];
 };
 
 struct KernelEvent {
@@ -200,6 +208,7 @@ struct tmf_ctx {
   bool set_used[2] = {false, false};
   int cur = 0;
   std::vector<OutSlot> slots;
+  std::vector<FinishedTicket> finished;   // the last few of them (ring)
   i64 next_ticket = 1;
   PinnedBuf fetch;     // eigenvalues / counts coming down
   PinnedBuf lu_stats;  // verdict of the block-local elimination, written by the kernel itself: 2 x {min pivot, max inverse, flag}
@@ -368,6 +377,7 @@ struct Sweep {
       double fl = 0;
       for (auto& x : g.d) fl += (double)x.M * x.N * x.K;
       ev.flops = fl * (c.cplx ? 8.0 : 2.0);
+      ev.kind = tn == 16 ? 2 : (opA ? 1 : 0);
       c.gemm_events.push_back(ev);
     }
     return TMF_OK;
@@ -1212,8 +1222,15 @@ struct Sweep {
         HIP_TRY(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
         HIP_TRY(hipMalloc((void**)&s->d_chk, 64));
       }
+      if (s->ticket >= 0 && !s->waited && s->checks.p) {   // its download is done (not busy): keep what tmf_sweep_wait reports
+        FinishedTicket f{s->ticket, s->n_checks, {0}};
+        memcpy(f.v, s->checks.p, sizeof(double) * (size_t)std::min(s->n_checks, 8));
+        if (c.finished.size() >= 64) c.finished.erase(c.finished.begin());
+        c.finished.push_back(f);
+      }
       s->reserved = true;
       s->ticket = -1;
+      s->waited = true;
       TMF_TRY(s->checks.ensure(64));
       c.slot = s;
     }
@@ -1656,6 +1673,7 @@ struct Sweep {
     c.slot = nullptr;
     c.have_sites = false;  // one download per sweep
     s->ticket = c.next_ticket++;
+    s->waited = false;
     *ticket = s->ticket;
     tick(ST_DOWNLOAD, t0);
     c.stage_ms[ST_TOTAL] = now_ms() - c.t_begin;
@@ -1768,9 +1786,18 @@ extern "C" int tmf_sweep_query(tmf_ctx* ctx, int64_t ticket) {
 extern "C" int tmf_sweep_wait(tmf_ctx* ctx, int64_t ticket, double* checks, int32_t* n_checks) {
   if (n_checks) *n_checks = 0;
   OutSlot* s = ctx ? find_ticket(ctx, ticket) : nullptr;
-  if (!s) return TMF_OK;
+  if (!s) {   // the output block has been reused: the download finished long ago, its deviations were put aside
+    if (ctx && checks && n_checks)
+      for (const FinishedTicket& f : ctx->finished)
+        if (f.ticket == ticket) {
+          *n_checks = f.n;
+          memcpy(checks, f.v, sizeof(double) * (size_t)f.n);
+        }
+    return TMF_OK;
+  }
   HIP_TRY(hipEventSynchronize(s->done));
   s->busy = false;
+  s->waited = true;
   if (checks && n_checks) {
     *n_checks = s->n_checks;
     memcpy(checks, s->checks.p, (size_t)s->n_checks * 8);
@@ -1814,6 +1841,7 @@ extern "C" int tmf_sweep_info_get(tmf_ctx* ctx, tmf_sweep_info* o) {
       float ms = 0;
       HIP_TRY(hipEventElapsedTime(&ms, e.e0, e.e1));
       o->gemm_ms += ms, o->gemm_flops += e.flops;
+      o->gemm_split_ms[e.kind] += ms, o->gemm_split_flops[e.kind] += e.flops, o->gemm_split_launches[e.kind] += 1;
     }
     o->n_gemm_launches = (int64_t)ctx->gemm_events.size();
     for (auto& e : ctx->det_events) {

@@ -582,12 +582,14 @@ class Engine:
             self._sink = PinnedSink(self.torch)
         return self._sink
 
-    def _gmax(self, values):
+    def _gmax(self, values, err=None):
         """Elementwise maximum over all ranks of a sharded conversion (identity on one rank): decisions that
         change the orbitals of a cut - range-finder width, subspace iteration - must be the same on both
-        ranks that hold a shard-boundary cut, or their copies of it differ by a gauge."""
-        v = np.asarray(values, np.float64)
-        return v if self.coord is None else self.coord.max(v)
+        ranks that hold a shard-boundary cut, or their copies of it differ by a gauge.  ``err``: an exception this
+        rank has run into since the last meeting point; it is raised here - on EVERY rank (the others get
+        ``multi_gpu.RankFailure``) - so that no rank waits in a collective the failing one never enters."""
+        from .multi_gpu import collective_max
+        return collective_max(self.coord, values, err)
 
     def _finish(self, mps):
         mps.info = {"range_finder_iterations": self.range_iterations_used, "range_finder_columns": self.range_width,
@@ -776,6 +778,9 @@ class Engine:
             ctx = ctypes.c_void_p()
             nat.check(lib.tmf_ctx_create(self.device.index or 0, ctypes.byref(ctx)), "tmf_ctx_create")
             self._ctx = ctx
+            import weakref
+            self._ctx_finalizer = weakref.finalize(self, lib.tmf_ctx_destroy, ctypes.c_void_p(ctx.value))
+            self._ctx_finalizer.atexit = False      # at interpreter exit the process gives everything back anyway
         ctx = self._ctx
         self._tickets = [f for f in self._tickets if not self._ticket_done(f[0])]
         flags = 0
@@ -810,26 +815,33 @@ class Engine:
                               ortho_center=int(ortho_center), site_lo=int(s_lo), site_hi=int(s_hi),
                               n_sectors=0 if sec is None else int(sec.size), is_complex=int(cplx),
                               host_threads=int(threads or self.host_threads), flags=flags)
-        nat.check(lib.tmf_sweep_begin(ctx, c_ptr, ctypes.byref(par)), "tmf_sweep_begin")
-
         # ---- entangled stage with the narrowest adequate range finder (see entangled_stage_adaptive_gen): adequacy is
-        # CHECKED, the decisions are taken on the maximum over all ranks ----
+        # CHECKED, the decisions are taken on the maximum over all ranks.  An exception of this rank (bad arguments, out of
+        # memory, the Jacobi sweep cap) is held until the next reduction and raised there on all ranks (_gmax) ----
         worst, sat, weak, sw, bad = (ctypes.c_double(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64())
+
+        def attempt(fn, *args):
+            try:
+                fn(*args)
+            except Exception as exc:
+                return exc
+            return None
 
         def stage(P, its):
             nat.check(lib.tmf_sweep_entangled(ctx, P, its, ctypes.byref(worst), ctypes.byref(sat), ctypes.byref(weak),
                                               ctypes.byref(sw), ctypes.byref(bad)), "tmf_sweep_entangled")
             nat.check_jacobi_sweeps([sw.value], "Jacobi SVD / eigendecomposition of a cut (replaces eigh, slater.py:347)")
 
+        err = attempt(lambda: nat.check(lib.tmf_sweep_begin(ctx, c_ptr, ctypes.byref(par)), "tmf_sweep_begin"))
         reason, accepted = "", False
         for P in self.range_ladder:
-            stage(P, 0)
-            g_worst, any_sat = self._gmax([worst.value, float(sat.value)])
+            err = err or attempt(stage, P, 0)
+            g_worst, any_sat = self._gmax([worst.value, float(sat.value)], err)
             self.range_floor, its = float(g_worst), 0
             if g_worst > self.range_floor_tol:
-                stage(P, 1)
+                err = attempt(stage, P, 1)
                 its = 1
-                any_weak, any_sat = self._gmax([float(weak.value), float(sat.value)])
+                any_weak, any_sat = self._gmax([float(weak.value), float(sat.value)], err)
                 if any_weak:
                     reason = (f"cut {bad.value}: smallest captured singular value {worst.value:.1e} vs threshold "
                               f"{(trunc.svd_min ** 2 * (1 - trunc.svd_min ** 2)) ** 0.5:.1e} with {P} columns" if weak.value
@@ -889,7 +901,19 @@ class Engine:
         return self._finish(res)
 
     def _ticket_done(self, ticket):
-        return self.lib.tmf_sweep_query(self._ctx, ticket) != 0
+        r = self.lib.tmf_sweep_query(self._ctx, ticket)
+        if r < 0:                       # a HIP error of the download, not "done"
+            nat.check(r, "tmf_sweep_query")
+        return r != 0
+
+    def close(self):
+        """Releases the C++ sweep context: its two device memory sets, output blocks, page-locked staging memory and streams
+        (GBs at benchmark size).  Called by a finalizer when the engine is garbage-collected."""
+        fin = getattr(self, "_ctx_finalizer", None)
+        if fin is not None:
+            fin()
+            self._ctx_finalizer = None
+        self._ctx = None
 
     def _stage_timings(self):
         """Host wall time per stage of the last sweep (seconds), and - with ``time_gemm`` - the kernel times measured with

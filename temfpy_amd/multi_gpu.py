@@ -43,6 +43,28 @@ from .mps_data import MPSData, ShardArrays
 
 _LEASE_OFF = ShardArrays.HEADER_ROOM - 16      # uint64 inside the header room: 1 while a reader holds views
 
+CHECK_NAMES = ("vL is not unitary", "vL does not diagonalise C_LL", "vR is not unitary", "vR does not diagonalise C_RR",
+               "vL and vR do not SVD C_LR")      # testing.py:131-177, in the order tmf_sweep_wait reports them
+
+
+class RankFailure(RuntimeError):
+    """Raised on the ranks that did NOT fail when another rank of a sharded conversion did: a failure is made collective
+    at the points where the ranks meet (the decisions of the entangled stage, the exchange of segment names), so every
+    rank leaves the conversion together and the group stays in step for the next one."""
+
+
+def collective_max(coord, values, err=None):
+    """Elementwise maximum over the ranks (``coord.max``; identity without a coordinator) with a failure flag riding along:
+    if any rank passes an exception, every rank raises - the failing one its own exception, the others RankFailure."""
+    v = np.asarray(list(values) + [0.0 if err is None else 1.0], np.float64)
+    if coord is not None:
+        v = coord.max(v)
+    if v[-1] > 0:
+        if err is not None:
+            raise err
+        raise RankFailure("another rank of the sharded conversion failed")
+    return v[:-1]
+
 
 def shard_sites(L, oc, world):
     return list(_shard_sites(int(L), int(oc), int(world)))
@@ -178,25 +200,29 @@ class _Reader:
     def __init__(self, tag):
         self.tag, self.cache = tag, {}
 
-    def shard(self, rank, gen):
+    def segment(self, rank, gen):
         name = f"{self.tag}_r{rank}_g{gen}"
         seg = self.cache.get(name)
         if seg is None:
             seg = self.cache[name] = Segment(name)
-        return ShardArrays.unpack(seg.buf, keepalive=seg), seg
+        return seg
+
+    def shard(self, rank, gen):
+        """Views into the segment, and the lease tied to THEM: every array handed out (``bonds[b].masks``,
+        ``sites[i].blocks`` ...) is a view whose base is the array created here, so the finalizer fires - and the rank may
+        overwrite the segment - only when the result object AND every array taken from it are gone."""
+        seg = self.segment(rank, gen)
+        lease = np.frombuffer(seg.map, np.uint8)
+        weakref.finalize(lease, _release, [seg])
+        return ShardArrays.unpack(lease, keepalive=seg), seg
 
 
 def assemble(reader, infos, ortho_center, unit_cell_width, timings=None):
-    """``MPSData`` over the segments announced by the ranks: infos[r] = (generation, ...).  The segments stay
-    leased until the returned object is garbage-collected."""
-    shards, segs = [], []
-    for r, info in enumerate(infos):
-        sh, seg = reader.shard(r, int(info[0]))
-        shards.append(sh), segs.append(seg)
+    """``MPSData`` over the segments announced by the ranks: infos[r] = (generation, ...).  A segment stays leased
+    until the returned object and every array view taken from it have been garbage-collected (``_Reader.shard``)."""
+    shards = [reader.shard(r, int(info[0]))[0] for r, info in enumerate(infos)]
     shards = [s for s in shards if s.meta["s_hi"] > s.meta["s_lo"] or len(s.arrays["my_cuts"])]
-    mps = MPSData.from_shards(shards, ortho_center, unit_cell_width, timings)
-    weakref.finalize(mps, _release, segs)
-    return mps
+    return MPSData.from_shards(shards, ortho_center, unit_cell_width, timings)
 
 
 def _release(segs):
@@ -226,15 +252,26 @@ class DryEngine:
     def __init__(self, device=None):
         self.coord, self.timings, self.check_results = None, {}, {}
         self.range_iterations_used, self.range_width, self.range_floor = 0, 64, 0.0
+        # failure injection for the tests: "rank:where:n" - rank fails in its n-th conversion (0-based) at the decision
+        # point ("stage", before the collective) or after it ("sites", a failure the other ranks do not see)
+        f = os.environ.get("TMF_DRY_FAIL", "")
+        self._fail = tuple(f.split(":")) if f else None
+        self._count = 0
 
     def run(self, C, trunc, ortho_center, unit_cell_width, threads=None, download=True, site_range=None, sink=None):
         from . import _native as nat
         C = np.asarray(C)
         L = len(C)
         lo, hi = site_range if site_range is not None else (0, L)
+        fail = None
+        if self._fail and int(self._fail[0]) == int(os.environ.get("RANK", 0)) and int(self._fail[2]) == self._count:
+            fail = self._fail[1]
+        self._count += 1
         # a decision that differs between the ranks unless it is reduced: each rank proposes its own range
         v = np.array([float(lo), float(hi)])
-        self.decision = v if self.coord is None else self.coord.max(v)
+        self.decision = collective_max(self.coord, v, ValueError("injected failure before the decision") if fail == "stage" else None)
+        if fail == "sites":
+            raise ValueError("injected failure after the decision")
         cuts = np.arange(lo, hi + 1) if hi > lo else np.zeros(0, np.int64)
         ncut, cap, ns = len(cuts), 3, hi - lo
         src = dict(my_cuts=cuts.astype(np.int64), c_sets=np.zeros((ncut, cap, 2), np.uint64), c_lam=np.zeros((ncut, cap)),
@@ -260,7 +297,9 @@ class DryEngine:
         for k, v_ in src.items():
             sh.arrays[k][...] = v_
         mps = MPSData.from_shards([sh], ortho_center, unit_cell_width, {"total": 1e-3})
-        mps.info = {"checks": {}, "decision": self.decision.tolist()}
+        # the self-check deviations exist on the rank(s) whose range touches the centre cut (csrc/sweep.cpp: has_centre)
+        checks = {nm: 1e-9 * (k + 1) for k, nm in enumerate(CHECK_NAMES)} if lo <= ortho_center <= hi else {}
+        mps.info = {"checks": checks, "decision": self.decision.tolist()}
         return mps
 
 
@@ -282,7 +321,10 @@ class ShardGroup:
         # sit on different streams (tools/shard_inflight_exp.py: 2 - 9 % per conversion).  The second engine is created at
         # the second conversion; a one-off conversion never pays for it.
         self.engines, self._turn = [engine], 0
-        if self.world > 1:
+        # TMF_SHARD_FORCE_COLLECTIVES=1: run the broadcast / all-reduce / all-gather calls at world size 1 too (they are
+        # identities there) - how the RCCL branch is executed on a one-GPU box (tests/test_gpu_multi.py)
+        self.collective = self.world > 1 or os.environ.get("TMF_SHARD_FORCE_COLLECTIVES") == "1"
+        if self.collective:
             engine.coord = GlooMax(dist, torch, self.ctl)
         self.sink = ShmSink(tag, self.rank, getattr(engine, "lib", None))
         self.reader = _Reader(tag) if self.rank == 0 else None
@@ -296,15 +338,23 @@ class ShardGroup:
         caller may begin the next conversion: its kernels overlap this one's download (as on one GPU)."""
         torch, dist = self.torch, self.dist
         t0 = time.perf_counter()
-        hdr = torch.zeros(4, dtype=torch.int64)
+        hdr = torch.zeros(5, dtype=torch.int64)
+        err0 = None
         if self.rank == 0:
-            C = np.asarray(C)
-            cplx = np.iscomplexobj(C)
-            C = np.ascontiguousarray(C, np.complex128 if cplx else np.float64)
-            hdr[:] = torch.tensor([len(C), int(cplx), ortho_center or len(C) // 2, unit_cell_width or len(C)])
-        if self.world > 1:
+            try:
+                C = np.asarray(C)
+                cplx = np.iscomplexobj(C)
+                C = np.ascontiguousarray(C, np.complex128 if cplx else np.float64)
+                if C.ndim != 2 or C.shape[0] != C.shape[1] or len(C) < self.world:
+                    raise ValueError(f"correlation matrix of shape {C.shape} for {self.world} ranks")
+                hdr[:4] = torch.tensor([len(C), int(cplx), ortho_center or len(C) // 2, unit_cell_width or len(C)])
+            except Exception as exc:       # the other ranks wait in the broadcast: tell them instead of leaving them there
+                err0, hdr[4] = exc, 1
+        if self.collective:
             dist.broadcast(hdr, 0, group=self.ctl)
-        L, cplx, oc, ucw = (int(x) for x in hdr)
+        if int(hdr[4]):
+            raise err0 if err0 is not None else RankFailure("rank 0 could not read the correlation matrix")
+        L, cplx, oc, ucw = (int(x) for x in hdr[:4])
         tdt = torch.complex128 if cplx else torch.float64
         if self.data_nccl:
             if self.rank == 0:
@@ -316,53 +366,84 @@ class ShardGroup:
                 d_C = self._c_pin[: L * L].to(self.device, non_blocking=True)
             else:
                 d_C = torch.empty(L * L, dtype=tdt, device=self.device)
-            if self.world > 1:                              # RCCL over xGMI (complex data travels as pairs of doubles)
+            if self.collective:                             # RCCL over xGMI (complex data travels as pairs of doubles)
                 dist.broadcast(torch.view_as_real(d_C) if cplx else d_C, 0)
             mat = d_C
         else:
             h_C = torch.from_numpy(C.reshape(-1)) if self.rank == 0 else torch.empty(L * L, dtype=tdt)
-            if self.world > 1:
+            if self.collective:
                 dist.broadcast(torch.view_as_real(h_C) if cplx else h_C, 0)
             mat = h_C.numpy().reshape(L, L)
         rng = shard_sites(L, oc, self.world)[self.rank]
-        if self._turn == 1 and len(self.engines) == 1 and os.environ.get("TMF_SHARD_CONTEXTS", "2") != "1":
+        # (the second engine only when conversions are actually pipelined: it holds its own device memory sets)
+        if (not wait and self._turn >= 1 and len(self.engines) == 1 and os.environ.get("TMF_SHARD_CONTEXTS", "2") != "1"):
             second = make_engine(self.device, isinstance(self.eng, DryEngine))
             second.coord = self.eng.coord
             self.engines.append(second)
         eng = self.engines[self._turn % len(self.engines)]
         self._turn += 1
-        mps = eng.run(mat, trunc, oc, ucw, threads=self.host_threads, download=True if wait else "async", site_range=rng,
-                      sink=self.sink)
-        seg = self.sink.last
-        seg.lease = 1                      # taken: the next conversion gets another segment
-        return dict(mps=mps, seg=seg, L=L, oc=oc, ucw=ucw, busy=(time.perf_counter() - t0) * 1e3, keep=mat)
+        # A failure inside the entangled stage is collective already (Engine._gmax -> collective_max): every rank arrives
+        # here with an exception.  A failure after it is local; it travels with the handle to the next meeting point
+        # (convert_end's all_gather), so this rank stays in step with the others until then.
+        mps = seg = err = None
+        try:
+            mps = eng.run(mat, trunc, oc, ucw, threads=self.host_threads, download=True if wait else "async", site_range=rng,
+                          sink=self.sink)
+            seg = self.sink.last
+            seg.lease = 1                      # taken: the next conversion gets another segment
+        except Exception as exc:
+            err = exc
+        return dict(mps=mps, seg=seg, err=err, L=L, oc=oc, ucw=ucw, busy=(time.perf_counter() - t0) * 1e3, keep=mat)
 
     def convert_end(self, h):
         """Waits for the tensors of the conversion begun with handle ``h`` and assembles: the ``MPSData`` on rank 0,
         ``None`` elsewhere."""
         torch, dist = self.torch, self.dist
         t0 = time.perf_counter()
-        mps_l, seg = h["mps"], h["seg"]
-        if hasattr(mps_l, "wait"):
-            mps_l.wait()
+        mps_l, seg, err = h["mps"], h["seg"], h["err"]
+        chk = [np.nan] * len(CHECK_NAMES)
+        if err is None:
+            try:
+                if hasattr(mps_l, "wait"):
+                    mps_l.wait()
+                got = mps_l._lazy_checks() if hasattr(mps_l, "_lazy_checks") else getattr(mps_l, "info", {}).get("checks", {})
+                chk = [float(got.get(nm, np.nan)) for nm in CHECK_NAMES]
+            except Exception as exc:
+                err = exc
         busy = h["busy"] + (time.perf_counter() - t0) * 1e3
         self.last_local = mps_l
-        mine = torch.tensor([float(seg.gen), float(seg.size), busy], dtype=torch.float64)
-        infos = [torch.zeros(3, dtype=torch.float64) for _ in range(self.world)]
-        if self.world > 1:
+        # payload of the meeting point: segment (generation, size), busy time, failure flag, the self-check deviations (they
+        # exist only on the rank that owns the centre cut - NaN elsewhere)
+        mine = torch.tensor([float(seg.gen) if seg is not None else -1.0, float(seg.size) if seg is not None else 0.0, busy,
+                             0.0 if err is None else 1.0] + chk, dtype=torch.float64)
+        infos = [torch.zeros(len(mine), dtype=torch.float64) for _ in range(self.world)]
+        if self.collective:
             dist.all_gather(infos, mine, group=self.ctl)     # also orders "segment written" before "segment read"
         else:
             infos = [mine]
         self.last_busy_ms = [float(t[2]) for t in infos]
+        failed = [r for r, t in enumerate(infos) if float(t[3]) > 0]
+        if failed:                         # every rank leaves together; nobody keeps a lease on a result nobody will read
+            if seg is not None:
+                seg.lease = 0
+            if err is not None:
+                raise err
+            raise RankFailure(f"rank {failed[0]} of the sharded conversion failed")
         if self.rank != 0:
             return None                    # the segment stays leased until rank 0 drops the assembled object
         mps = assemble(self.reader, [t.tolist() for t in infos], h["oc"], h["ucw"], {"busy_ms_per_rank": self.last_busy_ms})
         mps.info = dict(getattr(mps_l, "info", {}))
+        allchk = np.array([t[4:].tolist() for t in infos])
+        with np.errstate(all="ignore"):
+            worst = np.where(np.isnan(allchk).all(axis=0), np.nan, np.nanmax(np.where(np.isnan(allchk), -np.inf, allchk), axis=0))
+        mps.info["checks"] = {nm: float(v) for nm, v in zip(CHECK_NAMES, worst) if not np.isnan(v)}
         return mps
 
     def convert_local(self, C, trunc, ortho_center=None, unit_cell_width=None):
         """One conversion of this rank's site range, tensors landed.  Returns (generation, bytes, busy ms, checks)."""
         h = self.convert_begin(C, trunc, ortho_center, unit_cell_width, wait=True)
+        if h["err"] is not None:
+            raise h["err"]
         self.last_local = h["mps"]
         return h["seg"].gen, h["seg"].size, h["busy"], dict(getattr(h["mps"], "info", {}).get("checks", {}))
 
@@ -487,34 +568,81 @@ class DevicePool:
             raise TypeError("the truncation parameters must be picklable to reach the worker processes "
                             f"(a lambda as `sectors`?): {exc}") from exc
         msg = dict(cmd="convert", c_name=self.c_seg.name, L=L, cplx=cplx, trunc=blob, oc=ortho_center, ucw=unit_cell_width)
-        for c in self.conns:
-            _send(c, msg)
-        infos, checks, err = [], {}, None
-        for r, c in enumerate(self.conns):
-            rep = self._recv_alive(r, c)
+        try:
+            for c in self.conns:
+                _send(c, msg)
+            reps = self._collect()
+        except (RuntimeError, TimeoutError, ConnectionError, OSError):
+            self.discard()                 # a worker died or hangs: the ranks are no longer in step, the pool is unusable
+            raise
+        infos, checks, errs = [], {}, []
+        for r, rep in enumerate(reps):
             if rep.get("error"):
-                err = err or rep
+                errs.append(rep)
             else:
-                infos.append((rep["gen"], rep["size"], rep["busy_ms"]))
+                infos.append((r, rep["gen"], rep["size"], rep["busy_ms"]))
                 checks.update(rep["checks"])
-        if err is not None:
-            raise _rebuild_exception(err)
-        mps = assemble(self.reader, infos, ortho_center or L // 2, unit_cell_width or L,
-                       {"busy_ms_per_rank": [i[2] for i in infos]})
+        if errs:
+            # every worker has answered, so the group is in step and stays usable.  The ranks that succeeded hold a lease on
+            # a result nobody will read: give it back.  Raise the real exception, not the RankFailure echo of the others.
+            for r, gen, _size, _busy in infos:
+                self.reader.segment(r, int(gen)).lease = 0
+            real = [e for e in errs if e.get("type") != "RankFailure"] or errs
+            raise _rebuild_exception(real[0])
+        mps = assemble(self.reader, [i[1:] for i in infos], ortho_center or L // 2, unit_cell_width or L,
+                       {"busy_ms_per_rank": [i[3] for i in infos]})
         mps.info = {"checks": checks}
         return mps
 
-    def _recv_alive(self, r, c):
+    def _collect(self):
+        """One reply from every worker, whichever answers first; notices a dead worker or the deadline while waiting."""
+        import select
+        pending, replies = dict(enumerate(self.conns)), {}
         t_end = time.time() + self.timeout
-        c.settimeout(1.0)
-        while True:
-            try:
-                return _recv(c)
-            except socket.timeout:
-                if self.procs[r].poll() is not None:
-                    raise RuntimeError(f"worker of {self.devices[r]} exited with code {self.procs[r].returncode}")
+        while pending:
+            ready, _, _ = select.select(list(pending.values()), [], [], 0.5)
+            for c in ready:
+                r = next(k for k, v in pending.items() if v is c)
+                replies[r] = _recv(c)
+                del pending[r]
+            if pending and not ready:
+                dead = [r for r, p in enumerate(self.procs) if p.poll() is not None]
+                if dead:
+                    raise RuntimeError(f"worker of {self.devices[dead[0]]} exited with code {self.procs[dead[0]].returncode}")
                 if time.time() > t_end:
-                    raise TimeoutError(f"worker of {self.devices[r]} did not answer within {self.timeout} s")
+                    raise TimeoutError(f"worker of {self.devices[min(pending)]} did not answer within {self.timeout} s")
+        return [replies[r] for r in range(self.world)]
+
+    def discard(self):
+        """Ends a pool whose workers are out of step: processes killed, segments removed, no longer handed out by pool()."""
+        for k in [k for k, v in _POOLS.items() if v is self]:
+            del _POOLS[k]
+        for c in getattr(self, "conns", []):
+            if c is not None:
+                try:
+                    c.close()
+                except OSError:
+                    pass
+        self.conns = []
+        for p_ in getattr(self, "procs", []):
+            if p_.poll() is None:
+                p_.terminate()
+        for p_ in getattr(self, "procs", []):
+            try:
+                p_.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                p_.kill()
+        self.procs = []
+        if getattr(self, "c_seg", None) is not None:
+            self.c_seg.unlink()
+            self.c_seg = None
+        if self.tag:                        # the workers' atexit handlers did not run
+            for f in os.listdir("/dev/shm"):
+                if f.startswith(self.tag + "_"):
+                    try:
+                        os.unlink("/dev/shm/" + f)
+                    except OSError:
+                        pass
 
     def close(self):
         for c in getattr(self, "conns", []):
@@ -556,7 +684,8 @@ def _recv(conn):
 
 def _rebuild_exception(rep):
     import builtins
-    cls = getattr(builtins, rep.get("type", ""), None) or getattr(np.linalg, rep.get("type", ""), None)
+    cls = (getattr(builtins, rep.get("type", ""), None) or getattr(np.linalg, rep.get("type", ""), None)
+           or (RankFailure if rep.get("type") == "RankFailure" else None))
     if not (isinstance(cls, type) and issubclass(cls, Exception)):
         cls = RuntimeError
     return cls(f"{rep['error']} (rank {rep.get('rank')})")
