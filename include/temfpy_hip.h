@@ -92,6 +92,14 @@ typedef struct {
   int32_t rows, ld, c_begin, c_end;
 } tmf_bcgs_desc;             /* 40 bytes */
 int64_t tmf_bcgs_work_bytes(const tmf_bcgs_desc* h_desc, int nprob);
+/* One launch for the inner part of tmf_bcgs_batched's Cholesky-QR mode: the columns [c_begin + t, c_begin + t + 64) of
+ * every slab (already projected against all earlier columns) are orthonormalised in themselves - 16-column panels, each
+ * projected against the earlier panels of the block and put through Cholesky-QR twice - by one 1024-thread workgroup per
+ * slab with the panel in registers (csrc/block_orth.hip).  rows <= max_rows <= 960.  Part of the replacement of
+ * numpy.linalg.eigh's orthonormal eigenvector blocks (slater.py:347). */
+int tmf_block_orth_batched(int dtype, const tmf_bcgs_desc* d_desc, int nprob, int t, int max_rows, void* stream);
+/* diagnostics (TMF_BORTH_STAMPS=1): cycles per phase of the first wavefront [0..7], workgroups, panels, rows [8..10], helper wavefront: waiting, factorising [11, 12]; clears */
+int tmf_block_orth_stamps(uint64_t* out16);
 int tmf_bcgs_batched(int dtype, const tmf_bcgs_desc* d_desc, const tmf_bcgs_desc* h_desc, int nprob, int passes,
                      int flags /* bit 0: Cholesky-QR (twice) inside the panels instead of the LDS Gram-Schmidt panel
                                   kernel - for well-conditioned slabs (filled-orbital bases) only;
@@ -245,6 +253,10 @@ int tmf_det_ppt_batched(int dtype, const tmf_det_desc* d_desc, int ntiles, int l
 /* mask_bits = 32: every tile of the launch has sb, sk <= 32 (the occupation masks and the sign bookkeeping then run on 32-bit
  * words and the ket-only part of the sign is computed once per ket set: 2.72 instead of 3.26 ms at the benchmark size); 64: as tmf_det_ppt_batched. */
 int tmf_det_ppt_batched_w(int dtype, const tmf_det_desc* d_desc, int ntiles, int lds_bytes, int mask_bits, void* stream);
+/* Diagnostics (process started with TMF_PPT_STAMPS=1; tools/ppt_probe.py): shader cycles of the four phases of a workgroup
+ * (load, exchange, tables, pairs) per wavefront slot [4 w + phase], summed over all launches since the last call; [16]
+ * workgroups, [17] pairs, [18] sum of n.  Synchronises the device and clears the counters. */
+int tmf_det_ppt_stamps(uint64_t* out32);
 
 /* Batched gathered Pfaffians (pfaffian.py:1429-1479 `_tensor_block` + :1413-1426 `_many_pfaffian`,
  * i.e. pfapack.ctypes.pfaffian in a Python loop).  For every pair (bra row a, ket row b):
@@ -552,6 +564,7 @@ void tmf_ctx_destroy(tmf_ctx* ctx);
 #define TMF_SWEEP_LU_SINGLE 256u   /* Schur complements by tmf_lu_schur_batched (one workgroup per site; A/B)  */
 #define TMF_SWEEP_LU_PIVOTED 2048u /* ... by the fully pivoted blocked LU (tmf_lu_block_batched; A/B).  Default: pivoting inside the
                                     * 64 x 64 diagonal blocks (tmf_diag_inverse_batched), fully pivoted only when a block inverse grows */
+#define TMF_SWEEP_UNFUSED_BCGS 8192u /* filled-basis blocks orthonormalised by the chain of per-panel launches instead of tmf_block_orth_batched (A/B) */
 #define TMF_SWEEP_LU_FORCE_FALLBACK 4096u /* tests: treat every pivot as too small, i.e. run the default and then the fallback */
 
 typedef struct {

@@ -198,6 +198,8 @@ extern "C" int tmf_bcgs_batched(int dtype, const tmf_bcgs_desc* d_desc, const tm
   // products of such a block are ordinary 64-wide MFMA GEMMs; inside it the 16-column panels are projected against
   // the earlier panels of the block only.  Needs c_end x 64 elements of scratch per slab.
   const bool wide = (flags & 2) != 0;
+  // flags & 4: the inner part of a 64-column block (its four panels) in one launch, tmf_block_orth_batched
+  const bool fused = (flags & 4) != 0 && cholqr && wide && max_rows <= 960;
   int w = 16;  // widest panel that fits the LDS of orth_panel_kernel
   while (!cholqr && (size_t)max_rows * w * elem + 1024 > 150 * 1024 && w > 1) w >>= 1;
   char* wk = static_cast<char*>(d_work);
@@ -257,6 +259,11 @@ extern "C" int tmf_bcgs_batched(int dtype, const tmf_bcgs_desc* d_desc, const tm
   for (int t = 0; t < max_span; t += wo) {
     int st = project(t, wo, -1);
     if (st) return st;
+    if (fused) {
+      st = tmf_block_orth_batched(dtype, d_desc, nprob, t, max_rows, stream);
+      if (st) return st;
+      continue;
+    }
     if (w == wo) {  // the block is one LDS panel: the descriptors of `project` are the panel's
       st = orth_panel();
       if (st) return st;

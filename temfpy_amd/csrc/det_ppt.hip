@@ -131,7 +131,14 @@ __device__ inline T wave_lds_det(T* __restrict__ A, const int n, const int lane)
 
 // dynamic LDS: [ G : sb*sk T ][ kmask : nsk u64 ][ amask : na u64 ][ per wave: scratch max(264, n*n) T | queue 72 u32 ]
 template <typename T, typename M>
-__device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det_desc& d, const float boost, unsigned char* __restrict__ smem) {
+__device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det_desc& d, const float boost, unsigned char* __restrict__ smem,
+                                                                    unsigned long long* __restrict__ dbg) {
+  // diagnostic build only (TMF_PPT_STAMPS=1, tools/ppt_probe.py): cycles of the phases of a workgroup, summed over the launch
+  unsigned long long t_s[5] = {0, 0, 0, 0, 0};
+  auto stamp = [&](int i) {
+    if (dbg) t_s[i] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
   __shared__ unsigned red_key[4];
   __shared__ uint8_t row_of[64], col_of[64], invr[64], prow_seq[64], pcol_seq[64];
   __shared__ uint64_t s_PA, s_PB;
@@ -178,6 +185,7 @@ __device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det
   }
   __syncthreads();
 
+  stamp(1);
   // ---------------- n exchange steps with full pivoting over the sector matrix -----------------------
   M usedR = 0, usedC = 0;   // uniform copies
   for (int t = 0; t < n; ++t) {
@@ -237,6 +245,7 @@ __device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det
     usedR |= M(1) << pr, usedC |= M(1) << pc;
     __syncthreads();
   }
+  stamp(2);
   T* __restrict__ out = reinterpret_cast<T*>(d.out);
   if (s_singular) {
     for (int64_t e = tid; e < (int64_t)na * nsk; e += 256) out[(size_t)d.a0 * nsk + e] = sc<T>::zero();
@@ -412,11 +421,18 @@ __device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det
     }
   };
 
+  stamp(3);
+  unsigned long long acc[4] = {0, 0, 0, 0}, hist[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;   // diagnostics
   int qn = 0;  // pairs waiting for the slow path (uniform in the wavefront)
   for (int al = wave; al < na; al += 4) {
+    if (dbg) tq = __builtin_amdgcn_s_memtime();
     const ASide A = a_side(amask[al]);
     const int acm = cm_sum(A);
     T* __restrict__ orow = out + (size_t)(d.a0 + al) * nsk;
+    if (dbg) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      acc[0] += t - tq, tq = t;
+    }
     for (int b0 = 0; b0 < nsk; b0 += 64) {
       const int b = b0 + lane;
       const bool live = b < nsk;
@@ -425,6 +441,11 @@ __device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det
       if (live) {
         par = fast ? pair_fast(A, acm, b, Rm, Cm) : pair(A, kmask[b], Rm, Cm);
         dd = mk<M>::popc(Cm);
+      }
+      if (dbg) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        acc[1] += t - tq, tq = t;
+        for (int k = 0; k < 8; ++k) hist[k] += __popcll(__ballot(live && (k < 7 ? dd == k : dd >= 7)));
       }
       const bool slow = live && dd > 4;
       if (live && !slow) {
@@ -481,6 +502,10 @@ __device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det
         if (par & 1) v = sc<T>::neg(v);
         orow[b] = v;
       }
+      if (dbg) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        acc[2] += t - tq, tq = t;
+      }
       const uint64_t sm = __ballot(slow);
       if (sm) {
         if (slow) queue[qn + __popcll(sm & below(lane))] = ((uint32_t)al << 16) | (uint32_t)b;
@@ -493,21 +518,55 @@ __device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det
           slow_batch(queue[qn + grp], true);
         }
       }
+      if (dbg) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        acc[3] += t - tq, tq = t;
+      }
     }
   }
   if (qn > 0) slow_batch(queue[grp < qn ? grp : 0], grp < qn);
+  if (dbg && lane == 0) {
+    stamp(4);
+    for (int i = 0; i < 4; ++i) atomicAdd(&dbg[19 + i], acc[i]);
+    for (int i = 0; i < 8; ++i) atomicAdd(&dbg[23 + i], hist[i]);
+    for (int i = 0; i < 4; ++i) atomicAdd(&dbg[4 * wave + i], t_s[i + 1] - t_s[i]);
+    if (wave == 0) atomicAdd(&dbg[16], 1ull), atomicAdd(&dbg[17], (unsigned long long)na * nsk), atomicAdd(&dbg[18], (unsigned long long)n);
+  }
 }
 
 
 // Two kernels, not one kernel with a branch: the 64-bit body needs 131 VGPRs (3 wavefronts per SIMD), the 32-bit one fits 4.
 template <typename T, typename M>
-__global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __restrict__ desc, const float boost) {
+__global__ __launch_bounds__(256) void ppt_det_kernel(const tmf_det_desc* __restrict__ desc, const float boost,
+                                                      unsigned long long* __restrict__ dbg) {
   extern __shared__ __align__(16) unsigned char smem[];
   const tmf_det_desc d = desc[blockIdx.x];
-  ppt_det_body<T, M>(d, boost, smem);
+  ppt_det_body<T, M>(d, boost, smem, dbg);
 }
 
 }  // namespace tmf
+
+// Diagnostic counters (TMF_PPT_STAMPS=1): 19 words on the device, read and cleared by tmf_det_ppt_stamps.
+static unsigned long long* ppt_stamps(bool force) {
+  static unsigned long long* p = nullptr;
+  static bool on = getenv("TMF_PPT_STAMPS") != nullptr;
+  if ((on || force) && !p) {
+    if (hipMalloc((void**)&p, 32 * 8) != hipSuccess) return nullptr;
+    (void)hipMemset(p, 0, 32 * 8);
+  }
+  return on ? p : nullptr;
+}
+
+extern "C" int tmf_det_ppt_stamps(uint64_t* out32) {
+  unsigned long long* p = ppt_stamps(false);
+  if (!p) {
+    tmf::set_error("tmf_det_ppt_stamps: set TMF_PPT_STAMPS=1 before the first launch");
+    return TMF_E_ARG;
+  }
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out32, p, 32 * 8, hipMemcpyDeviceToHost) != hipSuccess) return TMF_E_HIP;
+  (void)hipMemset(p, 0, 32 * 8);
+  return TMF_OK;
+}
 
 extern "C" int tmf_det_ppt_batched_w(int dtype, const tmf_det_desc* d_desc, int ntiles, int lds_bytes, int mask_bits, void* stream) {
   using namespace tmf;
@@ -531,10 +590,11 @@ extern "C" int tmf_det_ppt_batched_w(int dtype, const tmf_det_desc* d_desc, int 
   }
   static float boost = getenv("TMF_PPT_BOOST") ? (float)atof(getenv("TMF_PPT_BOOST")) : 10.0f;  // experiment knob
   const dim3 g(ntiles), b(256);
-  if (dtype == TMF_C128 && mask_bits == 32) hipLaunchKernelGGL((ppt_det_kernel<cd, uint32_t>), g, b, lds_bytes, s, d_desc, boost);
-  else if (dtype == TMF_C128) hipLaunchKernelGGL((ppt_det_kernel<cd, uint64_t>), g, b, lds_bytes, s, d_desc, boost);
-  else if (dtype == TMF_F64 && mask_bits == 32) hipLaunchKernelGGL((ppt_det_kernel<double, uint32_t>), g, b, lds_bytes, s, d_desc, boost);
-  else if (dtype == TMF_F64) hipLaunchKernelGGL((ppt_det_kernel<double, uint64_t>), g, b, lds_bytes, s, d_desc, boost);
+  unsigned long long* dbg = ppt_stamps(false);
+  if (dtype == TMF_C128 && mask_bits == 32) hipLaunchKernelGGL((ppt_det_kernel<cd, uint32_t>), g, b, lds_bytes, s, d_desc, boost, dbg);
+  else if (dtype == TMF_C128) hipLaunchKernelGGL((ppt_det_kernel<cd, uint64_t>), g, b, lds_bytes, s, d_desc, boost, dbg);
+  else if (dtype == TMF_F64 && mask_bits == 32) hipLaunchKernelGGL((ppt_det_kernel<double, uint32_t>), g, b, lds_bytes, s, d_desc, boost, dbg);
+  else if (dtype == TMF_F64) hipLaunchKernelGGL((ppt_det_kernel<double, uint64_t>), g, b, lds_bytes, s, d_desc, boost, dbg);
   else {
     set_error("tmf_det_ppt_batched: bad dtype %d", dtype);
     return TMF_E_ARG;

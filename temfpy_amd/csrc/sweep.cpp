@@ -391,7 +391,7 @@ struct Sweep {
   // blocked classical Gram-Schmidt with re-orthogonalisation (tmf_bcgs_batched)
   // `on`: the stream the kernels run on.  Descriptors (and the zeroing of the norms) always go through the launch
   // stream; another stream waits for them by event.
-  int bcgs(std::vector<Slab> s, int passes, bool cholqr, bool wide = false, hipStream_t on = nullptr) {
+  int bcgs(std::vector<Slab> s, int passes, bool cholqr, bool wide = false, hipStream_t on = nullptr, bool fused = false) {
     if (on == nullptr) on = c.s_main;
     s.erase(std::remove_if(s.begin(), s.end(), [](const Slab& x) { return !(x.rows > 0 && x.c1 > x.c0); }), s.end());
     if (s.empty()) return TMF_OK;
@@ -425,8 +425,8 @@ struct Sweep {
       HIP_TRY(hipStreamWaitEvent(on, ev, 0));
     }
     TMF_TRY(tmf_column_norms_batched(c.dtype, (const tmf_norms_desc*)t_nd, (int)s.size(), on));
-    return tmf_bcgs_batched(c.dtype, (const tmf_bcgs_desc*)t_bd, bd.data(), (int)bd.size(), passes, (cholqr ? 1 : 0) | (wide ? 2 : 0), d_work, wb,
-                            on);
+    return tmf_bcgs_batched(c.dtype, (const tmf_bcgs_desc*)t_bd, bd.data(), (int)bd.size(), passes,
+                            (cholqr ? 1 : 0) | (wide ? 2 : 0) | (fused ? 4 : 0), d_work, wb, on);
   }
 
   struct HSlab {
@@ -1101,16 +1101,17 @@ struct Sweep {
       const int passes = (c.par.flags & TMF_SWEEP_TWO_PASSES) ? 2 : 1;
       const bool cholqr = !(c.par.flags & TMF_SWEEP_NO_CHOLQR);
       const bool two_streams = !s[0].empty() && !s[1].empty() && !(c.par.flags & TMF_SWEEP_ONE_STREAM);
+      const bool fused = !(c.par.flags & TMF_SWEEP_UNFUSED_BCGS);
       if (two_streams) {
-        TMF_TRY(bcgs(s[1], passes, cholqr, wide, c.s_up));
-        TMF_TRY(bcgs(s[0], passes, cholqr, wide));
+        TMF_TRY(bcgs(s[1], passes, cholqr, wide, c.s_up, fused));
+        TMF_TRY(bcgs(s[0], passes, cholqr, wide, nullptr, fused));
         hipEvent_t ev;
         TMF_TRY(new_event(&ev));
         HIP_TRY(hipEventRecord(ev, c.s_up));
         HIP_TRY(hipStreamWaitEvent(c.s_main, ev, 0));
       } else {
         s[0].insert(s[0].end(), s[1].begin(), s[1].end());
-        TMF_TRY(bcgs(s[0], passes, cholqr, wide));
+        TMF_TRY(bcgs(s[0], passes, cholqr, wide, nullptr, fused));
       }
     }
     // self-check of the centre cut (testing.py:131-177; slater.py:419-420 runs it only there)

@@ -523,6 +523,7 @@ class Engine:
     # but with a tensor download in flight the second kernel stream ended up behind the 27 ms copy (73 instead of 30 ms
     # per conversion, measured) - the runtime multiplexes streams onto few hardware queues.  Off unless asked for.
     one_stream = os.environ.get("TMF_ONE_STREAM", "1") == "1"
+    filled_fused = os.environ.get("TMF_FILLED_FUSED", "1") == "1"       # 64-column blocks of the filled bases in one launch (A/B: 0)
     # "local": pivoting inside the 64 x 64 diagonal blocks, everything else MFMA GEMMs, fully pivoted fallback when a pivot
     # is small | "blocked": fully pivoted, multi-launch | "single": one workgroup per site | "fallback": local, then
     # always the fallback (tests)
@@ -809,6 +810,7 @@ class Engine:
             self.lu_method, 0)
         flags |= nat.SWEEP_NARROW_BCGS if self.filled_blocks == 16 else 0
         flags |= nat.SWEEP_ONE_STREAM if self.one_stream else 0
+        flags |= 0 if self.filled_fused else nat.SWEEP_UNFUSED_BCGS
         flags |= nat.SWEEP_DET_DIRECT if self.force_direct_det else (nat.SWEEP_DET_REDUCED if self.det_method != "ppt" else 0)
         par = nat.SweepParams(L=L, chi_max=int(trunc.chi_max or 0), svd_min=float(trunc.svd_min),
                               degeneracy_tol=float(trunc.degeneracy_tol), sectors=None if sec is None else sec.ctypes.data,

@@ -16,6 +16,12 @@ equal only up to a diagonal unitary on every bond):
 
 Replays the loop of slater.C_to_MPS (slater.py:1293-1346) exactly as make_golden.replay does.
 
+Pfaffian cases (BASELINE config 4): the cut decomposition only - pfaffian.SchmidtVectors.from_correlation_matrix
+(pfaffian.py:685-920, :1008-1248) for every bond, replayed as pfaffian.C_to_MPS walks the chain (pfaffian.py:1832-1914).
+No sub-Pfaffian is evaluated, so the third-party pfapack (absent here) is not involved: per bond chi, e, the
+vacuum parities pL / pR, normalised Schmidt values, S(b), the occupation patterns (packed + SHA-1, rows in the
+reference's (parity, number) order) and the sector boundaries idx_n.
+
 Usage:  python tests/golden/make_golden_summary.py [case ...]     (writes tests/golden/full/*.npz)
 """
 import hashlib
@@ -137,8 +143,95 @@ def summarise(slater, C, chi_max, ortho_center=None, spinful=None, log=None):
                 reference_cores=np.array(len(os.sched_getaffinity(0))))
 
 
+PF_CASES = {
+    # BASELINE config 4: Majorana-basis Kitaev chain (src/examples/iMPS_pfaffian.py:7-11) and the random BdG
+    # chain (src/examples/pfaffian.py:13-17, seeded) at L = 512, chi_max = 256
+    "cfg4_kitaev_L512_chi256": (lambda g: g.kitaev_majorana_H(512, 1.5j, 1j), dict(chi_max=256)),
+    "cfg4_randbdg_L512_s0_chi256": (lambda g: g.random_majorana_H(512, 0), dict(chi_max=256)),
+    "pf_randbdg_L64_s5_chi64": (lambda g: g.random_majorana_H(64, 5), dict(chi_max=64)),
+}
+
+
+def summarise_pfaffian(pf, C, chi_max, ortho_center=None, log=None):
+    SV = pf.SchmidtVectors
+    trunc = {"chi_max": chi_max}
+    L = len(C) // 2
+    oc = ortho_center or L // 2
+    chi, S, nrm = np.zeros(L + 1, np.int64), np.zeros(L + 1), np.zeros(L + 1)
+    par = np.full((L + 1, 2), -1, np.int64)
+    lam, e, packed, idxn = [None] * (L + 1), [None] * (L + 1), [None] * (L + 1), [None] * (L + 1)
+    h_sets = np.zeros((L + 1, 20), np.uint8)
+
+    def put_bond(b, V):
+        m = V.modes
+        sets = V.left_sets if V.left_sets is not None else V.right_sets[:, ::-1]
+        sv = V.schmidt_values
+        nrm[b] = np.linalg.norm(sv)
+        lam[b] = sv / nrm[b]
+        p = lam[b] ** 2
+        S[b] = -(p[p > 0] * np.log(p[p > 0])).sum()
+        chi[b] = len(sv)
+        e[b] = np.asarray(m.e, np.float64)
+        par[b] = (-1 if m.pL is None else m.pL, -1 if m.pR is None else m.pR)
+        packed[b] = np.packbits(np.asarray(sets, bool), axis=1, bitorder="little").reshape(-1)
+        h_sets[b] = sha(packed[b])
+        ks = sorted(V.idx_n)
+        idxn[b] = np.array([[k, V.idx_n[k].start, V.idx_n[k].stop] for k in ks], np.int64).reshape(-1)
+
+    t0 = time.time()
+    Sc = SV.from_correlation_matrix(C, oc, trunc, basis="M")
+    put_bond(oc, Sc)
+    parity = Sc.parity()
+    for i in range(oc, L):  # pfaffian.py:1861-1881
+        put_bond(i + 1, SV.from_correlation_matrix(C, i + 1, trunc, which="R", basis="M", total_parity=parity))
+        if log and i % 64 == 0:
+            log(f"  bond {i + 1} ({time.time() - t0:.0f} s)")
+    for i in reversed(range(oc)):  # pfaffian.py:1887-1907
+        put_bond(i, SV.from_correlation_matrix(C, i, trunc, which="L", basis="M", total_parity=parity))
+        if log and i % 64 == 0:
+            log(f"  bond {i} ({time.time() - t0:.0f} s)")
+    wall = time.time() - t0
+
+    def flat(lst, dt):
+        off = np.concatenate(([0], np.cumsum([len(x) for x in lst]))).astype(np.int64)
+        return np.concatenate([np.asarray(x, dt) for x in lst]), off
+
+    lam_f, lam_off = flat(lam, np.float64)
+    e_f, e_off = flat(e, np.float64)
+    pk_f, pk_off = flat(packed, np.uint8)
+    in_f, in_off = flat(idxn, np.int64)
+    return dict(L=L, ortho_center=oc, chi_max=chi_max, chi=chi, S=S, lam_norm=nrm, parities=par, total_parity=np.array(parity),
+                lam=lam_f, lam_off=lam_off, e=e_f, e_off=e_off, sets_packed=pk_f, sets_off=pk_off, sets_sha1=h_sets,
+                idx_n=in_f, idx_n_off=in_off, reference_wall_s=np.array(wall),
+                reference_cores=np.array(len(os.sched_getaffinity(0))))
+
+
+def main_pfaffian(names):
+    import make_golden_pfaffian as g
+    pf, testing = g.load_reference_pfaffian()
+    warnings.simplefilter("ignore")
+    os.makedirs(OUT, exist_ok=True)
+    for name in names:
+        builder, kw = PF_CASES[name]
+        C = pf.correlation_matrix(builder(g), "M->M")
+        print(f"{name}: running the reference's cut decomposition ...", flush=True)
+        data = summarise_pfaffian(pf, C, log=lambda s: print(s, flush=True), **kw)
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **data)
+        oc = int(data["ortho_center"])
+        print(f"{name}: L={data['L']} parity={int(data['total_parity'])} chi@centre={data['chi'][oc]} "
+              f"S(centre)={data['S'][oc]:.9f} reference wall {float(data['reference_wall_s']):.1f} s, "
+              f"{os.path.getsize(path) / 1e6:.2f} MB", flush=True)
+
+
 def main():
     names = sys.argv[1:] or list(CASES)
+    pf_names = [n for n in names if n in PF_CASES]
+    if pf_names:
+        main_pfaffian(pf_names)
+    names = [n for n in names if n not in PF_CASES]
+    if not names:
+        return
     slater, testing = load_reference()
     warnings.simplefilter("ignore", testing.ComparisonWarning)
     os.makedirs(OUT, exist_ok=True)

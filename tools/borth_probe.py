@@ -1,0 +1,35 @@
+"""Phases of the fused block orthonormalisation kernel (csrc/block_orth.hip), in-kernel cycle stamps.
+usage: python tools/borth_probe.py [world rank]   (default: the whole benchmark chain)"""
+import ctypes, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("TMF_BORTH_STAMPS", "1")
+import torch
+from tests_inputs import random_hopping
+from temfpy_amd import slater
+from temfpy_amd.engine import Engine
+from temfpy_amd.multi_gpu import shard_sites
+from temfpy_amd.schmidt_utils import to_stopping_condition
+L = 1024
+C, _ = slater.correlation_matrix(random_hopping(L, 0))
+d_C = torch.from_numpy(np.ascontiguousarray(C).reshape(-1)).to("cuda:0")
+tr = to_stopping_condition({"chi_max": 512})
+rng = shard_sites(L, L // 2, int(sys.argv[1]))[int(sys.argv[2])] if len(sys.argv) > 2 else (0, L)
+eng = Engine("cuda:0")
+buf = (ctypes.c_uint64 * 16)()
+for _ in range(2):
+    eng.run(d_C, tr, L // 2, L, download=False, site_range=rng)
+eng.lib.tmf_block_orth_stamps(buf)
+reps = 5
+for _ in range(reps):
+    eng.run(d_C, tr, L // 2, L, download=False, site_range=rng)
+eng.lib.tmf_block_orth_stamps(buf)
+v = np.array(list(buf), float)
+wg, pan, rows = v[8], v[9], v[10]
+names = ("load panel", "coefficients (MFMA)", "reductions", "update (MFMA)", "Gram (MFMA)", "wait for R^-1", "apply (MFMA)", "store")
+print(f"range {rng}: {wg / reps:.0f} workgroups per conversion, {pan / wg:.2f} panels each, mean rows {rows / wg:.0f}; "
+      f"{v[:8].sum() / pan:.0f} cycles per panel")
+for nm, c in zip(names, v[:8]):
+    print(f"  {nm:22s} {c / pan:9.0f} cycles per panel  {100 * c / v[:8].sum():5.1f} %")
+print(f"  helper wavefront: {v[12] / pan / 2:.0f} cycles per factorisation, {v[11] / pan:.0f} cycles per panel waiting")
