@@ -362,4 +362,4 @@ def reduced_det_lds(el, n, sb, sk, nsk, na):
 def ppt_det_lds(el, sb, sk, nsk, na, n):
     """Dynamic LDS bytes of one tmf_det_ppt_batched tile (layout: csrc/det_ppt.hip)."""
     a16 = lambda x: (x + 15) & ~15  # noqa: E731
-    return a16(a16(sb * sk * el) + (nsk + na) * 8) + 4 * (np.maximum(264, n * n) * el + 288)
+    return a16(a16(sb * sk * el) + (nsk + na) * 8) + 4 * (np.maximum(264, n * n) * el + 288) + a16(12 * na + 3 * nsk + 16)

@@ -139,7 +139,6 @@ __device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det
     if (dbg) t_s[i] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
-  __shared__ unsigned red_key[4];
   __shared__ uint8_t row_of[64], col_of[64], invr[64], prow_seq[64], pcol_seq[64];
   __shared__ uint64_t s_PA, s_PB;
   __shared__ int s_singular, s_csector;
@@ -187,28 +186,43 @@ __device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det
 
   stamp(1);
   // ---------------- n exchange steps with full pivoting over the sector matrix -----------------------
+  // The search for the next pivot rides on the rank-1 update of the current step (every thread takes the maximum over the
+  // elements it has just updated), the wavefront maxima go through DPP row operations instead of the LDS crossbar, and
+  // the keys are double buffered: two barriers per step instead of five (the exchange was 20 - 30 % of the kernel).
+  auto wave_max_key = [](unsigned k) -> unsigned {
+    unsigned o;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, 0x111, 0xf, 0xf, false), k = o > k ? o : k;   // row_shr:1
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, 0x112, 0xf, 0xf, false), k = o > k ? o : k;   // row_shr:2
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, 0x114, 0xf, 0xf, false), k = o > k ? o : k;   // row_shr:4
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, 0x118, 0xf, 0xf, false), k = o > k ? o : k;   // row_shr:8
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, 0x142, 0xf, 0xf, false), k = o > k ? o : k;   // row_bcast:15
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, 0x143, 0xf, 0xf, false), k = o > k ? o : k;   // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)k, 63);
+  };
+  // 20 bits of magnitude (sign bit clear), 12 bits of element index (sb * sk <= 4096): ties -> larger index
+  auto key_of = [&](const T v_, const int e, const int r, const int c) -> unsigned {
+    float v = (float)sc<T>::abs2(v_);
+    if ((pref_r >> r) & M(1)) v *= boost;
+    if ((pref_c >> c) & M(1)) v *= boost;
+    const unsigned mag = __float_as_uint(v) & ~4095u;
+    return mag ? (mag | (unsigned)e) : 0u;
+  };
+  __shared__ unsigned red_key2[2][4];
+  const int step_r = 256 % sb, step_c = 256 / sb;
   M usedR = 0, usedC = 0;   // uniform copies
-  for (int t = 0; t < n; ++t) {
+  {
     unsigned key = 0u;
     for (int e = tid; e < sb * sk; e += 256) {
-      const int r = e % sb, c = e / sb;
-      if (((usedR >> r) | (usedC >> c)) & M(1)) continue;
-      float v = (float)sc<T>::abs2(Gm[e]);
-      if ((pref_r >> r) & M(1)) v *= boost;
-      if ((pref_c >> c) & M(1)) v *= boost;
-      // 20 bits of magnitude (sign bit clear), 12 bits of element index (sb * sk <= 4096): ties -> larger index
-      const unsigned mag = __float_as_uint(v) & ~4095u;
-      const unsigned k = mag ? (mag | (unsigned)e) : 0u;
+      const unsigned k = key_of(Gm[e], e, e % sb, e / sb);
       key = k > key ? k : key;
     }
-    for (int o = 32; o > 0; o >>= 1) {
-      const unsigned other = (unsigned)__shfl_xor((int)key, o);
-      key = other > key ? other : key;
-    }
-    if (lane == 0) red_key[wave] = key;
+    key = wave_max_key(key);
+    if (lane == 0) red_key2[0][wave] = key;
     __syncthreads();
-    key = red_key[0];
-    for (int w = 1; w < 4; ++w) key = red_key[w] > key ? red_key[w] : key;
+  }
+  for (int t = 0; t < n; ++t) {
+    unsigned key = red_key2[t & 1][0];
+    for (int w = 1; w < 4; ++w) key = red_key2[t & 1][w] > key ? red_key2[t & 1][w] : key;
     if (key == 0u) {  // nothing left to pivot on: rank(M) < n, every minor of order n vanishes
       if (tid == 0) s_singular = 1;
       __syncthreads();
@@ -217,15 +231,24 @@ __device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det
     const int pe = (int)(key & 4095u), pr = pe % sb, pc = pe / sb;
     const T p = Gm[pe];
     const T pinv = sc<T>::inv_fast(p);
-    __syncthreads();  // everybody has read the pivot (and red_key) before anything is overwritten
-    // rank-1 part on the elements outside the pivot row and column
-    for (int e = tid; e < sb * sk; e += 256) {
-      const int r = e % sb, c = e / sb;
+    usedR |= M(1) << pr, usedC |= M(1) << pc;
+    // rank-1 part on the elements outside the pivot row and column, and the search among what is still free
+    unsigned nkey = 0u;
+    int r = tid % sb, c = tid / sb;            // (row, column) of element e, advanced without divisions
+    for (int e = tid; e < sb * sk; e += 256, r += step_r, c += step_c) {
+      if (r >= sb) r -= sb, ++c;
       if (r == pr || c == pc) continue;
       const T f = sc<T>::mul(Gm[r + pc * sb], pinv);
-      Gm[e] = sc<T>::fms(Gm[e], f, Gm[pr + c * sb]);
+      const T v = sc<T>::fms(Gm[e], f, Gm[pr + c * sb]);
+      Gm[e] = v;
+      if (!(((usedR >> r) | (usedC >> c)) & M(1))) {
+        const unsigned k = key_of(v, e, r, c);
+        nkey = k > nkey ? k : nkey;
+      }
     }
-    __syncthreads();
+    nkey = wave_max_key(nkey);
+    if (lane == 0) red_key2[(t + 1) & 1][wave] = nkey;
+    __syncthreads();   // the pivot row and column have been read by everybody
     for (int e = tid; e < sb + sk; e += 256) {
       if (e < sb) {        // pivot column: G[i, pc] = M[i, pc] / p
         if (e != pr) Gm[e + pc * sb] = sc<T>::mul(Gm[e + pc * sb], pinv);
@@ -242,7 +265,6 @@ __device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det
       const T q = sc<T>::mul(sc<T>::from2(s_prod[0], s_prod[1]), p);
       s_prod[0] = sc<T>::real(q), s_prod[1] = sc<T>::imag(q);
     }
-    usedR |= M(1) << pr, usedC |= M(1) << pc;
     __syncthreads();
   }
   stamp(2);
@@ -421,6 +443,205 @@ __device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det
     }
   };
 
+  // ------------------------------------------------------------------------------------------------------------------
+  // Pair phase, 32-bit masks: pairs grouped by the ORDER d of their small determinant.
+  // d = da + db with da = rows of the bra set outside the pivot rows, db = columns of the ket set outside the pivot
+  // columns.  Bra sets sorted by da and ket sets by db (counting sorts in LDS) make d uniform in a wavefront: a unit of
+  // work is a block of up to 8 bra sets of one da, processed ket class by ket class with the 64 lanes spread over the
+  // (bra, ket) pairs of the class.  The determinant is then ONE straight-line closed form per wavefront instead of a
+  // four-way divergent branch, orders 5 are closed forms too (3 % of the pairs of the benchmark took 45 % of the pair
+  // phase on the queued 8-lane path: measured with the stamps below), and a unit writes all kets of its rows within a
+  // few microseconds (the partial lines merge in L2).  d >= 6 (0.03 %) keeps the queue.
+  // ------------------------------------------------------------------------------------------------------------------
+  if constexpr (FAST) {
+    if (fast) {
+      __shared__ int s_kcnt[33], s_koff[34], s_acnt[33], s_aoff[34], s_uoff[34], s_ticket;   // s_uoff: units (blocks of 8 bra sets) before class da
+      uint32_t* s_ain = reinterpret_cast<uint32_t*>(smem + off + 4 * per_wave);
+      uint32_t* s_acm = s_ain + na;
+      uint16_t* s_ainfo = reinterpret_cast<uint16_t*>(s_acm + na);   // da | parity << 8
+      uint16_t* s_aord = s_ainfo + na;
+      uint16_t* s_kord = s_aord + na;
+      uint8_t* s_kdb = reinterpret_cast<uint8_t*>(s_kord + nsk);
+      if (tid < 33) s_kcnt[tid] = 0, s_acnt[tid] = 0;
+      if (tid == 0) s_ticket = 0;
+      __syncthreads();
+      for (int a = tid; a < na; a += 256) {
+        const ASide A = a_side(amask[a]);
+        s_ain[a] = A.in, s_acm[a] = A.cm;
+        s_ainfo[a] = (uint16_t)(A.da | (((csec + A.par + cm_sum(A)) & 1) << 8));
+        atomicAdd(&s_acnt[A.da], 1);
+      }
+      for (int b = tid; b < nsk; b += 256) {
+        const int db = __popc(kmask[b]);
+        s_kdb[b] = (uint8_t)db;
+        atomicAdd(&s_kcnt[db], 1);
+      }
+      __syncthreads();
+      if (wave == 0) {   // exclusive prefix sums over the 33 classes, one lane per class
+        const int c = lane;
+        const int kc = c < 33 ? s_kcnt[c] : 0, ac = c < 33 ? s_acnt[c] : 0, uc = (ac + 7) >> 3;
+        int ks = kc, as = ac, us = uc;
+        for (int o = 1; o < 64; o <<= 1) {
+          const int k2 = __shfl_up(ks, o), a2 = __shfl_up(as, o), u2 = __shfl_up(us, o);
+          if (lane >= o) ks += k2, as += a2, us += u2;
+        }
+        if (c < 33) s_koff[c] = ks - kc, s_aoff[c] = as - ac, s_uoff[c] = us - uc;
+        if (c == 32) s_koff[33] = ks, s_aoff[33] = as, s_uoff[33] = us;
+      }
+      __syncthreads();
+      // stable scatter into the class order: wavefront 0 the kets, wavefront 1 the bra sets
+      if (wave < 2) {
+        const int cnt = wave == 0 ? nsk : na;
+        for (int c = 0; c < 33; ++c) {
+          const int total = wave == 0 ? s_kcnt[c] : s_acnt[c];
+          if (total == 0) continue;
+          int pos = (wave == 0 ? s_koff[c] : s_aoff[c]);
+          for (int i0 = 0; i0 < cnt; i0 += 64) {
+            const int i = i0 + lane;
+            const int cls = i < cnt ? (wave == 0 ? (int)s_kdb[i] : (int)(s_ainfo[i] & 0xff)) : -1;
+            const uint64_t mk_ = __ballot(cls == c);
+            if (cls == c) (wave == 0 ? s_kord : s_aord)[pos + __popcll(mk_ & below(lane))] = (uint16_t)i;
+            pos += __popcll(mk_);
+          }
+        }
+      }
+      __syncthreads();
+      stamp(3);
+
+      // closed forms on G, one lane per pair, order uniform in the wavefront
+      auto ld = [&](int i, int j) -> T { return Gm[i + j]; };
+      auto det2 = [&](const int* iv, const int* jv) -> T {
+        const T m00 = ld(iv[0], jv[0]), m10 = ld(iv[1], jv[0]), m01 = ld(iv[0], jv[1]), m11 = ld(iv[1], jv[1]);
+        return sc<T>::fms(sc<T>::mul(m00, m11), m01, m10);
+      };
+      auto det3 = [&](const int* iv, const int* jv) -> T {
+        const T m00 = ld(iv[0], jv[0]), m10 = ld(iv[1], jv[0]), m20 = ld(iv[2], jv[0]);
+        const T m01 = ld(iv[0], jv[1]), m11 = ld(iv[1], jv[1]), m21 = ld(iv[2], jv[1]);
+        const T m02 = ld(iv[0], jv[2]), m12 = ld(iv[1], jv[2]), m22 = ld(iv[2], jv[2]);
+        const T c0 = sc<T>::fms(sc<T>::mul(m11, m22), m12, m21);
+        const T c1 = sc<T>::fms(sc<T>::mul(m10, m22), m12, m20);
+        const T c2 = sc<T>::fms(sc<T>::mul(m10, m21), m11, m20);
+        return sc<T>::fmac(sc<T>::fms(sc<T>::mul(m00, c0), m01, c1), m02, c2);
+      };
+      auto det4 = [&](const int* iv, const int* jv) -> T {      // Laplace expansion along the first two columns
+        T p01, p02, p03, p12, p13, p23;
+        {
+          const T a0 = ld(iv[0], jv[0]), a1 = ld(iv[1], jv[0]), a2 = ld(iv[2], jv[0]), a3 = ld(iv[3], jv[0]);
+          const T b0_ = ld(iv[0], jv[1]), b1 = ld(iv[1], jv[1]), b2 = ld(iv[2], jv[1]), b3 = ld(iv[3], jv[1]);
+          p01 = sc<T>::fms(sc<T>::mul(a0, b1), b0_, a1);
+          p02 = sc<T>::fms(sc<T>::mul(a0, b2), b0_, a2);
+          p03 = sc<T>::fms(sc<T>::mul(a0, b3), b0_, a3);
+          p12 = sc<T>::fms(sc<T>::mul(a1, b2), b1, a2);
+          p13 = sc<T>::fms(sc<T>::mul(a1, b3), b1, a3);
+          p23 = sc<T>::fms(sc<T>::mul(a2, b3), b2, a3);
+        }
+        const T c0 = ld(iv[0], jv[2]), c1 = ld(iv[1], jv[2]), c2 = ld(iv[2], jv[2]), c3 = ld(iv[3], jv[2]);
+        const T e0 = ld(iv[0], jv[3]), e1 = ld(iv[1], jv[3]), e2 = ld(iv[2], jv[3]), e3 = ld(iv[3], jv[3]);
+        T det = sc<T>::mul(p01, sc<T>::fms(sc<T>::mul(c2, e3), e2, c3));
+        det = sc<T>::fms(det, p02, sc<T>::fms(sc<T>::mul(c1, e3), e1, c3));
+        det = sc<T>::fmac(det, p03, sc<T>::fms(sc<T>::mul(c1, e2), e1, c2));
+        det = sc<T>::fmac(det, p12, sc<T>::fms(sc<T>::mul(c0, e3), e0, c3));
+        det = sc<T>::fms(det, p13, sc<T>::fms(sc<T>::mul(c0, e2), e0, c2));
+        det = sc<T>::fmac(det, p23, sc<T>::fms(sc<T>::mul(c0, e1), e0, c1));
+        return det;
+      };
+
+      int qn = 0;
+      for (;;) {
+        int u = 0;
+        if (lane == 0) u = atomicAdd(&s_ticket, 1);
+        u = __builtin_amdgcn_readfirstlane(u);
+        if (u >= s_uoff[33]) break;
+        int da = 0;
+        while (s_uoff[da + 1] <= u) ++da;
+        da = __builtin_amdgcn_readfirstlane(da);
+        const int i0 = 8 * (u - __builtin_amdgcn_readfirstlane(s_uoff[da]));
+        const int rows = __builtin_amdgcn_readfirstlane(min(8, s_acnt[da] - i0)), abase = __builtin_amdgcn_readfirstlane(s_aoff[da]) + i0;
+        for (int db = 0; db < 33; ++db) {
+          const int cb = __builtin_amdgcn_readfirstlane(s_kcnt[db]);
+          if (cb == 0) continue;
+          const int dd = da + db, kbase = __builtin_amdgcn_readfirstlane(s_koff[db]), npair = rows * cb;
+          const float rcb = 1.0f / (float)cb;
+          const int base_par = db * (n - da) + dd * (sk - 1) + ((dd * (dd - 1)) >> 1);
+          for (int p0 = 0; p0 < npair; p0 += 64) {
+            const int pidx = p0 + lane;
+            const bool live = pidx < npair;
+            int r = (int)((float)pidx * rcb);                 // pidx / cb for pidx < 2^14: one correction step
+            r -= (r * cb > pidx);
+            r += ((r + 1) * cb <= pidx);
+            const int j = pidx - r * cb;
+            const int al = live ? (int)s_aord[abase + r] : (int)s_aord[abase];
+            const int b = live ? (int)s_kord[kbase + j] : (int)s_kord[kbase];
+            const M ain = s_ain[al], acm = s_acm[al], bin = kmask[b], Rb = rbm[b];
+            int par = base_par + (s_ainfo[al] >> 8) + (int)((parbits[b >> 5] >> (b & 31)) & 1u);
+            {
+              M m1 = ain, m2 = acm;
+              for (int t = 0; t < da; ++t) {                   // (trip count uniform in the wavefront)
+                par += mk<M>::popc(mk<M>::above(Rb, mk<M>::ffs(m1) - 1));
+                par += mk<M>::popc(mk<M>::above(bin, mk<M>::ffs(m2) - 1));
+                m1 &= m1 - 1, m2 &= m2 - 1;
+              }
+            }
+            M Rm = ain | Rb, Cm = bin | acm;
+            if (dd > 5) {                                      // the queued path of the general kernel
+              const uint64_t sm = __ballot(live);
+              if (live) queue[qn + __popcll(sm & below(lane))] = ((uint32_t)al << 16) | (uint32_t)b;
+              qn += __popcll(sm);
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+              while (qn >= 8) {
+                qn -= 8;
+                slow_batch(queue[qn + grp], true);
+              }
+              continue;
+            }
+            int iv[5], jv[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+              iv[t] = 0, jv[t] = 0;
+              if (t < dd) {
+                iv[t] = mk<M>::ffs(Rm) - 1;
+                jv[t] = (mk<M>::ffs(Cm) - 1) * sb;
+                Rm &= Rm - 1, Cm &= Cm - 1;
+              }
+            }
+            T det = sc<T>::one();
+            switch (dd) {
+              case 0: break;
+              case 1: det = ld(iv[0], jv[0]); break;
+              case 2: det = det2(iv, jv); break;
+              case 3: det = det3(iv, jv); break;
+              case 4: det = det4(iv, jv); break;
+              default: {   // 5: expansion along the first column, five minors of order 4
+                det = sc<T>::zero();
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                  int ir[4];
+#pragma unroll
+                  for (int t = 0; t < 4; ++t) ir[t] = iv[t + (t >= i)];
+                  const T mi = sc<T>::mul(ld(iv[i], jv[0]), det4(ir, jv + 1));
+                  det = (i & 1) ? sc<T>::sub(det, mi) : sc<T>::add(det, mi);
+                }
+              }
+            }
+            if (live) {
+              T v = sc<T>::mul(pref_fac, det);
+              if (par & 1) v = sc<T>::neg(v);
+              out[(size_t)(d.a0 + al) * nsk + b] = v;
+            }
+          }
+        }
+      }
+      if (qn > 0) slow_batch(queue[grp < qn ? grp : 0], grp < qn);
+      if (dbg && lane == 0) {
+        stamp(4);
+        for (int i = 0; i < 4; ++i) atomicAdd(&dbg[4 * wave + i], t_s[i + 1] - t_s[i]);
+        if (wave == 0) atomicAdd(&dbg[16], 1ull), atomicAdd(&dbg[17], (unsigned long long)na * nsk), atomicAdd(&dbg[18], (unsigned long long)n);
+      }
+      return;
+    }
+  }
   stamp(3);
   unsigned long long acc[4] = {0, 0, 0, 0}, hist[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;   // diagnostics
   int qn = 0;  // pairs waiting for the slow path (uniform in the wavefront)

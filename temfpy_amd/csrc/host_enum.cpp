@@ -522,18 +522,87 @@ extern "C" int tmf_site_prepare(const tmf_site_in* in, const uint64_t* sets_b, c
 // Batched, multi-threaded variants: one call for all cuts / all sites of a sweep.
 // -------------------------------------------------------------------------------------------
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 namespace {
+
+// Worker threads of the host phase, kept between calls: a site range of a multi-GPU conversion has ~40 cuts, i.e. ~0.35 ms of
+// enumeration on 16 threads, and starting 15 threads per call cost more than that (measured: 1.1 ms per call, on the
+// critical path of a shard).  One job at a time (callers are serialised by the job mutex); the caller works too.
+class HostPool {
+ public:
+  static HostPool& get() {
+    static HostPool* p = new HostPool();   // never destroyed: workers may outlive static destructors at exit
+    return *p;
+  }
+  // runs fn(worker_index) on `want` threads (the caller is one of them)
+  void run(int want, const std::function<void()>& fn) {
+    std::lock_guard<std::mutex> job(job_mutex_);
+    const int helpers = want - 1;
+    grow(helpers);
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn;
+      limit_ = helpers;
+      pending_ = helpers;
+      ++generation_;
+    }
+    if (helpers > 0) cv_.notify_all();
+    fn();
+    if (helpers > 0) {
+      std::unique_lock<std::mutex> lk(m_);
+      done_.wait(lk, [&] { return pending_ == 0; });
+    }
+    fn_ = nullptr;
+  }
+
+ private:
+  void grow(int helpers) {
+    std::lock_guard<std::mutex> lk(m_);
+    while ((int)threads_.size() < helpers) {
+      const int id = (int)threads_.size();
+      threads_.emplace_back([this, id] { loop(id); });
+      threads_.back().detach();
+    }
+  }
+  void loop(int id) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void()>* fn = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (id < limit_) fn = fn_;
+      }
+      if (fn) {
+        (*fn)();
+        std::lock_guard<std::mutex> lk(m_);
+        if (--pending_ == 0) done_.notify_one();
+      }
+    }
+  }
+  std::mutex job_mutex_, m_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> threads_;
+  const std::function<void()>* fn_ = nullptr;
+  uint64_t generation_ = 0;
+  int limit_ = 0, pending_ = 0;
+};
+
 template <typename F>
 int parallel_for(int n, int nthreads, F&& fn) {
   if (nthreads < 1) nthreads = 1;
   if (nthreads > n) nthreads = n > 0 ? n : 1;
+  if (nthreads > 256) nthreads = 256;
   std::atomic<int> next(0), err(0);
   // The error text is thread-local (tmf_last_error): the first failing worker's message is copied out under
   // the same compare-exchange that records its status, and re-set on the CALLING thread before returning.
   char first_msg[512] = "";
-  auto work = [&]() {
+  const std::function<void()> work = [&]() {
     for (;;) {
       const int i = next.fetch_add(1);
       if (i >= n) break;
@@ -544,10 +613,8 @@ int parallel_for(int n, int nthreads, F&& fn) {
       }
     }
   };
-  std::vector<std::thread> th;
-  for (int t = 1; t < nthreads; ++t) th.emplace_back(work);
-  work();
-  for (auto& t : th) t.join();
+  if (nthreads == 1) work();
+  else HostPool::get().run(nthreads, work);
   if (err.load() != 0) tmf::set_error("%s", first_msg);
   return err.load();
 }
@@ -624,7 +691,9 @@ extern "C" int64_t tmf_det_tiles_build(int nsites, const tmf_site_job* jobs, con
         const int64_t a1 = std::min(nsb, a0 + ta);
         refs.push_back(Ref{i, q, (int32_t)a0, (int32_t)a1, (a1 - a0) * nsk});
         const int64_t scr = std::max<int64_t>(264, (int64_t)sc_.n * sc_.n);
-        const int64_t lds = a16(a16((int64_t)o.sb * o.sk * elem_bytes) + (nsk + (a1 - a0)) * 8) + 4 * (scr * elem_bytes + 288);
+        // (+ the class tables of the pair phase: 12 bytes per bra set, 3 per ket set; layout in csrc/det_ppt.hip)
+        const int64_t lds = a16(a16((int64_t)o.sb * o.sk * elem_bytes) + (nsk + (a1 - a0)) * 8) + 4 * (scr * elem_bytes + 288) +
+                            a16(12 * (a1 - a0) + 3 * nsk + 16);
         lmax = std::max<int64_t>(lmax, lds);
       }
       pairs_tot += nsb * nsk;
