@@ -56,6 +56,9 @@ typedef struct {
 int tmf_gemm_batched(int dtype, int opA, double alpha, double beta, const tmf_gemm_desc* d_desc,
                      const int32_t* d_tiles /* [ntiles][4]: problem, tile_m, tile_n, 0 */, int ntiles,
                      int tile_n /* 64 or 16 */, void* stream);
+/* A/B switch (tests): complex products by four real MFMAs per multiply-add (componentwise error bound) instead of the
+ * default three (3M scheme, normwise bound); process-wide, applies to the launches that follow. */
+void tmf_gemm_set_4m(int on);
 
 /* Tall-skinny form of the above for op(A) = A^H, N <= 16 and a long contraction (the coefficient
  * products Q^H P of the blocked Gram-Schmidt): 16 x 16 output tiles, 64 rows of A and B per step.

@@ -24,7 +24,7 @@ constexpr int TM = 64;
 constexpr int KT = 16;
 constexpr int LDT = KT + 1;  // padded k-stride of the LDS tiles (doubles)
 
-template <typename T, int OPA, int TN>
+template <typename T, int OPA, int TN, bool M4 = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const tmf_gemm_desc* __restrict__ desc,
                                                    const int32_t* __restrict__ tiles, double alpha, double beta,
                                                    const int32_t* __restrict__ run_if) {
@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const tmf_gemm_desc* __res
   // v_add_f64 per fragment are free next to a 64-cycle MFMA.  Error bound: normwise the same as the 4M form
   // (eps * sum |a||b| with a constant of 4 instead of 2 on the imaginary part); every product of the sweep is followed
   // by an orthogonalisation or a difference of O(1) quantities, where the normwise bound is the one that matters.
-  constexpr int NACC = CP ? 3 : 1;
+  // M4 (tmf_gemm_set_4m, the A/B switch of tests/test_gpu_fullsize.py): the four-product form, componentwise error bound.
+  constexpr int NACC = CP ? (M4 ? 2 : 3) : 1;
   d4 acc[NACC][MI][NI];
 #pragma unroll
   for (int p = 0; p < NACC; ++p)
@@ -161,7 +162,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const tmf_gemm_desc* __res
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[j], ar[i], acc[0][i][j], 0, 0, 0);
-          if constexpr (CP) {
+          if constexpr (CP && M4) {
+            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bi[j], ai[i], acc[0][i][j], 0, 0, 0);
+            acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[j], ar[i], acc[1][i][j], 0, 0, 0);
+            acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[j], ai[i], acc[1][i][j], 0, 0, 0);
+          } else if constexpr (CP) {
             acc[1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[j], ai[i], acc[1][i][j], 0, 0, 0);
             acc[2][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[j] + bi[j], ar[i] + ai[i], acc[2][i][j], 0, 0, 0);
           }
@@ -186,8 +191,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const tmf_gemm_desc* __res
         if (m < d.M && n < d.N) {
           T* c = C + (size_t)m + (size_t)n * d.ldc;
           if constexpr (CP) {
-            const double p1 = acc[0][i][j][r], p2 = acc[1][i][j][r], p3 = acc[2][i][j][r];
-            cd v = make_cd(alpha * (p1 - p2), alpha * (p3 - p1 - p2));
+            double vre, vim;
+            if constexpr (M4) {
+              vre = acc[0][i][j][r], vim = acc[1][i][j][r];
+            } else {
+              const double p1 = acc[0][i][j][r], p2 = acc[1][i][j][r], p3 = acc[NACC - 1][i][j][r];
+              vre = p1 - p2, vim = p3 - p1 - p2;
+            }
+            cd v = make_cd(alpha * vre, alpha * vim);
             if (beta != 0.0) {
               cd o = *c;
               v.x = fma(beta, o.x, v.x);
@@ -300,11 +311,19 @@ __global__ __launch_bounds__(256) void gemm_tall_kernel(const tmf_gemm_desc* __r
   }
 }
 
+static bool g_four_products = false;
+
 template <typename T>
 static int launch(int opA, double alpha, double beta, const tmf_gemm_desc* d, const int32_t* t, int nt, int tile_n,
                   hipStream_t s) {
   dim3 g(nt), b(256);
-  if (tile_n == 64) {
+  if (g_four_products && tile_n == 64) {
+    if (opA) hipLaunchKernelGGL((gemm_kernel<T, 1, 64, true>), g, b, 0, s, d, t, alpha, beta, launch_condition());
+    else hipLaunchKernelGGL((gemm_kernel<T, 0, 64, true>), g, b, 0, s, d, t, alpha, beta, launch_condition());
+  } else if (g_four_products) {
+    if (opA) hipLaunchKernelGGL((gemm_kernel<T, 1, 16, true>), g, b, 0, s, d, t, alpha, beta, launch_condition());
+    else hipLaunchKernelGGL((gemm_kernel<T, 0, 16, true>), g, b, 0, s, d, t, alpha, beta, launch_condition());
+  } else if (tile_n == 64) {
     if (opA) hipLaunchKernelGGL((gemm_kernel<T, 1, 64>), g, b, 0, s, d, t, alpha, beta, launch_condition());
     else hipLaunchKernelGGL((gemm_kernel<T, 0, 64>), g, b, 0, s, d, t, alpha, beta, launch_condition());
   } else {
@@ -315,6 +334,9 @@ static int launch(int opA, double alpha, double beta, const tmf_gemm_desc* d, co
 }
 
 }  // namespace tmf
+
+// A/B switch: complex products of tmf_gemm_batched by four real MFMAs (componentwise error bound) instead of three.
+extern "C" void tmf_gemm_set_4m(int on) { tmf::g_four_products = on != 0; }
 
 extern "C" int tmf_gemm_batched(int dtype, int opA, double alpha, double beta, const tmf_gemm_desc* d_desc,
                                 const int32_t* d_tiles, int ntiles, int tile_n, void* stream) {

@@ -191,6 +191,46 @@ def test_config3_every_bond_and_site_against_the_reference(name):
           f"threshold events (pattern order undetermined at double precision) at bonds {events}, da <= {worst['tau']:.1e}")
 
 
+def test_config3_three_product_complex_gemm_against_four_products():
+    """A/B of the complex MFMA products at the benchmark size: the default forms a complex multiply-add from three real
+    MFMAs (3M scheme: normwise error bound), `tmf_gemm_set_4m(1)` from four (componentwise bound).  The deviation of the
+    block norms from the REFERENCE's (1.2e-6 relative, attributed to the conditioning of eigenvectors next to the cutoff)
+    must be the same with both, i.e. none of it is the 3M scheme's; bonds (eigenvalues, Schmidt values, patterns) agree with
+    the reference either way, and the two runs agree with each other far below their common distance to the reference."""
+    name = "cfg3_rand_L1024_s0_chi512"
+    if not os.path.exists(os.path.join(FULL, name + ".npz")):
+        pytest.skip("summary not generated")
+    from temfpy_amd import _native as nat
+    lib = nat.load()
+    mps3, ref = convert(name)
+    _, _, ev3 = compare_bonds(mps3, ref)
+    lib.tmf_gemm_set_4m(1)
+    try:
+        mps4, _ = convert(name)
+    finally:
+        lib.tmf_gemm_set_4m(0)
+    _, _, ev4 = compare_bonds(mps4, ref)
+    # (which bonds are threshold events - two patterns whose order is undetermined at double precision - is itself decided
+    # by rounding: the union is left out of the row comparison of both runs)
+    events = sorted(set(ev3) | set(ev4))
+    assert len(events) <= 4, events
+    wb3, wr3 = compare_sites(mps3, ref, rtol=5e-6, events=events)
+    wb4, wr4 = compare_sites(mps4, ref, rtol=5e-6, events=events)
+    # the same distance to the reference (not: one of them closer by what the product scheme would add)
+    assert abs(wb3 - wb4) <= 0.25 * max(wb3, wb4) + 1e-9, (wb3, wb4)
+    # and closer to each other than to the reference (any rounding-level change moves the weakly determined eigenvectors):
+    # block norms of every site
+    worst = 0.0
+    for i in range(0, int(ref["L"])):
+        a, b = mps3.sites[i], mps4.sites[i]
+        assert [x[:5] for x in a.blocks] == [y[:5] for y in b.blocks], i
+        for x, y in zip(a.blocks, b.blocks):
+            nx, ny = np.linalg.norm(x[5]), np.linalg.norm(y[5])
+            worst = max(worst, abs(nx - ny) / max(nx, 1e-300))
+    assert worst <= 0.5 * max(wb3, wb4) + 1e-9, (worst, wb3, wb4)     # measured: 3.6e-7 against 1.5e-6 / 1.7e-6
+    print(f"block norms vs the reference: 3M {wb3:.2e}, 4M {wb4:.2e}; 3M vs 4M {worst:.2e}; lam-weighted rows {wr3:.1e} / {wr4:.1e}")
+
+
 def test_config5_slater_stage_against_the_reference():
     """Uniform chain, spinful "PH" (1024 real-dtype MPS sites): both spin species give the same spectrum, so every
     Schmidt value comes in exactly degenerate multiplets that rounding splits at the 1e-16 level - in the reference

@@ -183,6 +183,53 @@ def test_config4_full_size(kind):
         assert np.all(np.diff(key) >= 0), b
         for par, (a_, b_) in bd.idx_parity.items():
             assert np.all(exc[a_:b_] % 2 == par)
+    # EVERY bond against the reference's own cut decomposition at this size (tests/golden/make_golden_summary.py: pfaffian.
+    # SchmidtVectors.from_correlation_matrix, pfaffian.py:685-920 and :1008-1248, run unmodified; no sub-Pfaffian and hence
+    # no pfapack involved): chi, entangled eigenvalues, vacuum parities, Schmidt values, S(b), occupation patterns.
+    ref = np.load(os.path.join(GOLDEN, "full", "cfg4_kitaev_L512_chi256.npz" if kind == "kitaev"
+                               else "cfg4_randbdg_L512_s0_chi256.npz"))
+    assert int(ref["L"]) == L and int(ref["total_parity"]) == parity
+    S_hip = mps.entanglement_entropy(all_bonds=True)
+    worst = dict(e=0.0, lam=0.0, S=0.0)
+    n_pattern_bonds = 0
+    for b in range(L + 1):
+        bd = mps.bonds[b]
+        e_ref = ref["e"][ref["e_off"][b]: ref["e_off"][b + 1]]
+        lam_ref = ref["lam"][ref["lam_off"][b]: ref["lam_off"][b + 1]]
+        assert bd.chi == int(ref["chi"][b]) and len(bd.e) == len(e_ref), b
+        np.testing.assert_allclose(bd.e, e_ref, rtol=0, atol=1e-13)
+        worst["e"] = max(worst["e"], float(np.abs(bd.e - e_ref).max(initial=0.0)))
+        pL, pR = (int(x) for x in ref["parities"][b])
+        assert (pL < 0 or bd.pL == pL) and (pR < 0 or bd.pR == pR), b
+        worst["S"] = max(worst["S"], abs(S_hip[b] - float(ref["S"][b])))
+        if kind == "kitaev":
+            # exactly degenerate entanglement spectrum (dimerised chain): order and basis inside a multiplet are decided by
+            # rounding, in the reference too - Schmidt values as a sorted list
+            np.testing.assert_allclose(np.sort(bd.lam), np.sort(lam_ref), rtol=0, atol=1e-10)
+            continue
+        k = len(e_ref)
+        packed = ref["sets_packed"][ref["sets_off"][b]: ref["sets_off"][b + 1]].reshape(bd.chi, -1)
+        sets_ref = np.unpackbits(packed, axis=1, bitorder="little")[:, :k].astype(bool)
+        # lam_alpha / lam_0 = exp(-sum of +-a_i over the modes in which pattern alpha differs from the dominant one): a mode
+        # within 1e-11 of the cutoff carries da_i = de / (2 min(e_i, 1 - e_i)) ~ 1e-4 for de ~ 1e-15 of eigenvalue noise
+        da = 1e-14 / (2.0 * np.minimum(e_ref, 1.0 - e_ref)) if k else np.zeros(0)
+        if np.array_equal(bd.sets, sets_ref):
+            n_pattern_bonds += 1
+            cond = (sets_ref != sets_ref[int(np.argmax(lam_ref))]).astype(float) @ da if k else np.zeros(bd.chi)
+            assert np.all(np.abs(bd.lam - lam_ref) <= 1e-10 + 2.0 * lam_ref * cond), (b, np.abs(bd.lam - lam_ref).max())
+            worst["lam"] = max(worst["lam"], float(np.abs(bd.lam - lam_ref).max()))
+        else:
+            # a threshold event: the same set of patterns with two neighbours exchanged whose Schmidt
+            # values differ by less than the noise of the weak modes, or one pattern exchanged at the chi edge
+            ours = {r.tobytes() for r in np.packbits(bd.sets, axis=1, bitorder="little")}
+            theirs = {r.tobytes() for r in packed}
+            assert len(ours ^ theirs) <= 2, (b, len(ours ^ theirs))
+            np.testing.assert_allclose(np.sort(bd.lam), np.sort(lam_ref), rtol=0, atol=1e-9)
+    assert worst["S"] < 1e-9, worst
+    if kind == "random":
+        assert n_pattern_bonds >= L - 4, n_pattern_bonds       # patterns identical except at documented threshold events
+    print(f"config 4 ({kind}) vs the reference on all {L + 1} bonds: max |de| {worst['e']:.1e}, max |dlam| {worst['lam']:.1e}, "
+          f"max |dS| {worst['S']:.1e}, patterns identical on {n_pattern_bonds} bonds")
     # Isometry of the tensors at both ends of the chain, where chi_max does not truncate.  svd_min still does, and not in
     # a nested way: a Schmidt vector kept at one bond with lam ~ 1e-6 may consist mostly of vectors discarded at the
     # neighbouring bond, so its column has norm < 1 (measured: 2e-3 off) - but it enters the state with weight lam.

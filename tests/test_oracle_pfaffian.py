@@ -92,3 +92,36 @@ def test_pfaffian_oracle_canonical_form(name):
         np.testing.assert_allclose(G, np.eye(chi_k), atol=1e-8)
         checked += 1
     assert checked >= 2
+
+
+def test_pfaffian_oracle_cut_decomposition_at_mid_size():
+    """Every bond of a random BdG chain of 64 sites (chi_max = 64, where chi_max truncates most bonds) against the
+    reference's own cut decomposition (tests/golden/make_golden_summary.py pf_randbdg_L64_s5_chi64: pfaffian.py:685-920 and
+    :1008-1248 run unmodified, no sub-Pfaffian involved): chi, eigenvalues, vacuum parities, patterns, Schmidt values, S."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_golden_pfaffian import random_majorana_H
+    ref = np.load(os.path.join(GOLDEN, "full", "pf_randbdg_L64_s5_chi64.npz"))
+    L, oc = int(ref["L"]), int(ref["ortho_center"])
+    C = porc.correlation_matrix(random_majorana_H(L, 5))
+    trunc = porc.as_trunc({"chi_max": int(ref["chi_max"])})
+    centre = porc.cut_vectors(C, oc, trunc, "LR")
+    parity = centre.parity()
+    assert parity == int(ref["total_parity"])
+    for b in range(L + 1):
+        c = centre if b == oc else porc.cut_vectors(C, b, trunc, "L" if b < oc else "R", parity)
+        e_ref = ref["e"][ref["e_off"][b]: ref["e_off"][b + 1]]
+        lam_ref = ref["lam"][ref["lam_off"][b]: ref["lam_off"][b + 1]]
+        assert len(c.lam) == int(ref["chi"][b])
+        np.testing.assert_allclose(c.e, e_ref, rtol=0, atol=1e-13)
+        pL, pR = (int(x) for x in ref["parities"][b])
+        assert (-1 if c.pL is None else c.pL) == pL and (-1 if c.pR is None else c.pR) == pR
+        packed = ref["sets_packed"][ref["sets_off"][b]: ref["sets_off"][b + 1]].reshape(len(lam_ref), -1)
+        sets_ref = np.unpackbits(packed, axis=1, bitorder="little")[:, : len(e_ref)].astype(bool)
+        np.testing.assert_array_equal(c.sets, sets_ref)
+        np.testing.assert_allclose(c.lam, lam_ref, rtol=0, atol=1e-12)
+        p = c.lam ** 2
+        assert abs(-(p[p > 0] * np.log(p[p > 0])).sum() - float(ref["S"][b])) < 1e-12
+        idx = ref["idx_n"][ref["idx_n_off"][b]: ref["idx_n_off"][b + 1]].reshape(-1, 3)
+        assert sorted(c.idx_n) == [int(x) for x in idx[:, 0]]
+        assert [list(c.idx_n[int(k)]) for k in idx[:, 0]] == [[int(a), int(z)] for _, a, z in idx]
