@@ -29,6 +29,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
+#include <memory>
 #include <numeric>
 #include <vector>
 
@@ -107,7 +109,7 @@ struct DeviceArena {
 // asynchronous copy on the launch stream (a pageable copy blocks the host and drains the stream).
 struct StagingArena {
   char *h = nullptr, *d = nullptr;
-  size_t cap = 0, off = 0;
+  size_t cap = 0, off = 0, flushed = 0;  // [flushed, off): written on the host, not yet copied to the device
   std::vector<std::pair<char*, char*>> retired;  // blocks still referenced by queued copies of this sweep
   int reserve(size_t bytes) {
     size_t o = (off + 255) & ~(size_t)255;
@@ -118,6 +120,7 @@ struct StagingArena {
       HIP_TRY(hipMalloc((void**)&d, ncap));
       cap = ncap;
       o = 0;
+      flushed = 0;
     }
     off = o;
     return TMF_OK;
@@ -128,7 +131,7 @@ struct StagingArena {
       (void)hipFree(r.second);
     }
     retired.clear();
-    off = 0;
+    off = flushed = 0;
   }
   void release() {
     reset();
@@ -294,10 +297,38 @@ struct Sweep {
   explicit Sweep(tmf_ctx& ctx) : c(ctx) {}
 
   // ------------------------------------------------------------------ plumbing
+  // Stream operations of a stage are DEFERRED: the helpers below build their descriptors, put them into the page-locked
+  // staging block (`up`) and queue the launch; `run_deferred` copies everything staged so far in ONE transfer and then
+  // issues the queued operations in order.  Issued one by one, every descriptor array was its own 5 us copy kernel on the
+  // launch stream - 74 of them in the conversion of a 38-site shard, 0.37 ms of its critical path
+  // (profiles/r02/shard_8way_rank3_kernel_stats.csv).
+  std::vector<std::function<int()>> dq;
+#define LATER(expr) dq.emplace_back([=]() -> int { return (expr); })
+#define LATER_HIP(expr) dq.emplace_back([=]() -> int { return check_hip((expr), #expr); })
+  int flush_uploads() {
+    StagingArena& a = c.stage_set[c.cur];
+    if (a.off > a.flushed) {
+      HIP_TRY(hipMemcpyAsync(a.d + a.flushed, a.h + a.flushed, a.off - a.flushed, hipMemcpyHostToDevice, c.s_main));
+      a.flushed = a.off;
+    }
+    return TMF_OK;
+  }
+  int run_deferred() {
+    int st = flush_uploads();
+    for (auto& f : dq) {
+      if (st != TMF_OK) break;
+      st = f();
+    }
+    dq.clear();
+    return st;
+  }
   int dalloc(i64 count, i64 elem, void** out, bool zero = false) {
     const size_t bytes = (size_t)std::max<i64>(count, 1) * (size_t)elem;
     TMF_TRY(c.dev_set[c.cur].alloc(bytes, out));
-    if (zero) HIP_TRY(hipMemsetAsync(*out, 0, bytes, c.s_main));
+    if (zero) {
+      void* p_ = *out;
+      LATER_HIP(hipMemsetAsync(p_, 0, bytes, c.s_main));
+    }
     return TMF_OK;
   }
   int alloc_el(i64 count, u64* out, bool zero = false) {  // elements of the sweep's dtype
@@ -308,11 +339,12 @@ struct Sweep {
   }
   int up(const void* host, size_t bytes, u64* dev) {
     if (bytes == 0) bytes = 1;
-    TMF_TRY(c.stage_set[c.cur].reserve(bytes));
-    memcpy(c.stage_set[c.cur].h + c.stage_set[c.cur].off, host, bytes);
-    HIP_TRY(hipMemcpyAsync(c.stage_set[c.cur].d + c.stage_set[c.cur].off, c.stage_set[c.cur].h + c.stage_set[c.cur].off, bytes, hipMemcpyHostToDevice, c.s_main));
-    *dev = (u64)(c.stage_set[c.cur].d + c.stage_set[c.cur].off);
-    c.stage_set[c.cur].off += bytes;
+    StagingArena& a = c.stage_set[c.cur];
+    if (a.h == nullptr || ((a.off + 255) & ~(size_t)255) + bytes > a.cap) TMF_TRY(flush_uploads());   // (a new block follows)
+    TMF_TRY(a.reserve(bytes));
+    memcpy(a.h + a.off, host, bytes);
+    *dev = (u64)(a.d + a.off);
+    a.off += bytes;
     return TMF_OK;
   }
   template <typename T>
@@ -368,12 +400,12 @@ struct Sweep {
     if (timed) {
       TMF_TRY(new_event(&ev.e0));
       TMF_TRY(new_event(&ev.e1));
-      HIP_TRY(hipEventRecord(ev.e0, c.s_main));
+      LATER_HIP(hipEventRecord(ev.e0, c.s_main));
     }
-    TMF_TRY(tmf_gemm_batched(c.dtype, opA, alpha, beta, (const tmf_gemm_desc*)dd, (const int32_t*)dt, (int)tiles.size(), tn,
-                             c.s_main));
+    const int ntile = (int)tiles.size();
+    LATER(tmf_gemm_batched(c.dtype, opA, alpha, beta, (const tmf_gemm_desc*)dd, (const int32_t*)dt, ntile, tn, c.s_main));
     if (timed) {
-      HIP_TRY(hipEventRecord(ev.e1, c.s_main));
+      LATER_HIP(hipEventRecord(ev.e1, c.s_main));
       double fl = 0;
       for (auto& x : g.d) fl += (double)x.M * x.N * x.K;
       ev.flops = fl * (c.cplx ? 8.0 : 2.0);
@@ -421,12 +453,15 @@ struct Sweep {
     if (on != c.s_main) {
       hipEvent_t ev;
       TMF_TRY(new_event(&ev));
-      HIP_TRY(hipEventRecord(ev, c.s_main));
-      HIP_TRY(hipStreamWaitEvent(on, ev, 0));
+      LATER_HIP(hipEventRecord(ev, c.s_main));
+      LATER_HIP(hipStreamWaitEvent(on, ev, 0));
     }
-    TMF_TRY(tmf_column_norms_batched(c.dtype, (const tmf_norms_desc*)t_nd, (int)s.size(), on));
-    return tmf_bcgs_batched(c.dtype, (const tmf_bcgs_desc*)t_bd, bd.data(), (int)bd.size(), passes,
-                            (cholqr ? 1 : 0) | (wide ? 2 : 0) | (fused ? 4 : 0), d_work, wb, on);
+    const int nslab = (int)s.size();
+    LATER(tmf_column_norms_batched(c.dtype, (const tmf_norms_desc*)t_nd, nslab, on));
+    auto bdp = std::make_shared<std::vector<tmf_bcgs_desc>>(std::move(bd));   // host copy of the records, read at launch time
+    const int bflags = (cholqr ? 1 : 0) | (wide ? 2 : 0) | (fused ? 4 : 0);
+    LATER(tmf_bcgs_batched(c.dtype, (const tmf_bcgs_desc*)t_bd, bdp->data(), (int)bdp->size(), passes, bflags, d_work, wb, on));
+    return TMF_OK;
   }
 
   struct HSlab {
@@ -469,7 +504,9 @@ struct Sweep {
     }
     u64 t_d;
     TMF_TRY(up_vec(d, &t_d));
-    return tmf_house_slab_batched(c.dtype, (const tmf_slab_desc*)t_d, (int)d.size(), (int)maxn, (int)maxc, c.s_main);
+    const int nd_ = (int)d.size();
+    LATER(tmf_house_slab_batched(c.dtype, (const tmf_slab_desc*)t_d, nd_, (int)maxn, (int)maxc, c.s_main));
+    return TMF_OK;
   }
 
   // Householder QR of slabs of any width in place (global-memory kernel, one workgroup per slab): the range finders wider
@@ -491,7 +528,9 @@ struct Sweep {
     std::stable_sort(d.begin(), d.end(), [](const tmf_qr_desc& a, const tmf_qr_desc& b) { return (i64)a.m * a.n > (i64)b.m * b.n; });
     u64 t_d;
     TMF_TRY(up_vec(d, &t_d));
-    return tmf_house_qr_batched(c.dtype, (const tmf_qr_desc*)t_d, (int)d.size(), (int)maxm, (int)maxn, c.s_main);
+    const int nd_ = (int)d.size();
+    LATER(tmf_house_qr_batched(c.dtype, (const tmf_qr_desc*)t_d, nd_, (int)maxm, (int)maxn, c.s_main));
+    return TMF_OK;
   }
 
   // One-sided Jacobi per problem (p > 0 only).  left_only: U receives the normalised left singular vectors.
@@ -536,13 +575,16 @@ struct Sweep {
       }
       u64 dd;
       TMF_TRY(up_vec(d, &dd));
-      return tmf_jacobi_block_batched(c.dtype, left_only ? 0 : 1, (const tmf_jacobi_desc*)dd, (int)d.size(), (int)maxp,
-                                      (int32_t*)d_sw, c.s_main);
+      const int nd_ = (int)d.size();
+      LATER(tmf_jacobi_block_batched(c.dtype, left_only ? 0 : 1, (const tmf_jacobi_desc*)dd, nd_, (int)maxp, (int32_t*)d_sw, c.s_main));
+      return TMF_OK;
     }
     u64 dd;
     TMF_TRY(up_vec(d, &dd));
-    return left_only ? tmf_svd_left_batched(c.dtype, (const tmf_jacobi_desc*)dd, (int)d.size(), (int)maxp, (int32_t*)d_sw, c.s_main)
-                     : tmf_jacobi_batched(c.dtype, (const tmf_jacobi_desc*)dd, (int)d.size(), (int)maxp, (int32_t*)d_sw, c.s_main);
+    const int nd_ = (int)d.size();
+    if (left_only) LATER(tmf_svd_left_batched(c.dtype, (const tmf_jacobi_desc*)dd, nd_, (int)maxp, (int32_t*)d_sw, c.s_main));
+    else LATER(tmf_jacobi_batched(c.dtype, (const tmf_jacobi_desc*)dd, nd_, (int)maxp, (int32_t*)d_sw, c.s_main));
+    return TMF_OK;
   }
 
   // Y_i = A_i Omega (kind 'A') or F_i Omega (kind 'F') for all cut sides at once through running sums
@@ -575,7 +617,8 @@ struct Sweep {
     if (nd == 0) return TMF_OK;
     u64 t_desc;
     TMF_TRY(up(descs, nd * sizeof(tmf_nested_desc), &t_desc));
-    return tmf_nested_products_batched(c.dtype, (const tmf_nested_desc*)t_desc, nd, (int)D, maxc_all, c.s_main);
+    LATER(tmf_nested_products_batched(c.dtype, (const tmf_nested_desc*)t_desc, nd, (int)D, maxc_all, c.s_main));
+    return TMF_OK;
   }
 
   // normalised column copies (tmf_normalise_columns_batched)
@@ -584,7 +627,9 @@ struct Sweep {
     if (d.empty()) return TMF_OK;
     u64 dd;
     TMF_TRY(up_vec(d, &dd));
-    return tmf_normalise_columns_batched(c.dtype, (const tmf_colnorm_desc*)dd, (int)d.size(), c.s_main);
+    const int nd_ = (int)d.size();
+    LATER(tmf_normalise_columns_batched(c.dtype, (const tmf_colnorm_desc*)dd, nd_, c.s_main));
+    return TMF_OK;
   }
 
   // ------------------------------------------------------------------ begin
@@ -698,7 +743,7 @@ struct Sweep {
     c.P = P;
     u64 d_Om;
     TMF_TRY(alloc_el(L * P, &d_Om));
-    TMF_TRY(tmf_fill_normal(c.dtype, (void*)d_Om, L * P, 0x5EED1, c.s_main));
+    LATER(tmf_fill_normal(c.dtype, (void*)d_Om, L * P, 0x5EED1, c.s_main));
     std::vector<i64>& p = c.p;
     p.assign(ncs, 0);
     std::vector<char> full(ncs, 0);
@@ -767,7 +812,7 @@ struct Sweep {
       TMF_TRY(gemm(1, 1.0, 0.0, g));
       if (house && iterations == 0) {
         // only R^H = (F^H Q)^H Q2 is needed below: factor B^H in place and take R^H from the kernel
-        HIP_TRY(hipMemsetAsync((void*)d_R, 0, (size_t)std::max<i64>(tR, 1) * el, c.s_main));
+        LATER_HIP(hipMemsetAsync((void*)d_R, 0, (size_t)std::max<i64>(tR, 1) * el, c.s_main));
         std::vector<HSlab> s;
         for (i64 i = 0; i < ncs; ++i)
           if (c.doE[i]) s.push_back(HSlab{(size_t)i, Btp[i], c.m[i], std::max<i64>(c.m[i], 1), p[i], Rp[i], std::max<i64>(p[i], 1)});
@@ -775,7 +820,7 @@ struct Sweep {
         r_from_kernel = true;
         break;
       }
-      HIP_TRY(hipMemcpyAsync((void*)d_Q2, (void*)d_Bt, (size_t)std::max<i64>(tB, 1) * el, hipMemcpyDeviceToDevice, c.s_main));
+      LATER_HIP(hipMemcpyAsync((void*)d_Q2, (void*)d_Bt, (size_t)std::max<i64>(tB, 1) * el, hipMemcpyDeviceToDevice, c.s_main));
       for (i64 i = 0; i < ncs; ++i) Q2p[i] = d_Q2 + (u64)(oB[i] * el);
       TMF_TRY(rqr(Q2p, c.m));
       if (it < iterations) {
@@ -822,14 +867,18 @@ struct Sweep {
     char* h = c.fetch.p;
     // (written by a kernel into the page-locked buffer: a DMA copy here waits for its turn between the 64 MB pieces of the
     // previous conversion's tensor download, several ms per conversion)
-    TMF_TRY(tmf_export_words(h, (const void*)d_sig, (int64_t)b_sig, c.s_main));
-    TMF_TRY(tmf_export_words(h + b_sig, (const void*)d_e, (int64_t)b_sig, c.s_main));
-    TMF_TRY(tmf_export_words(h + 2 * b_sig, (const void*)d_cnt, (int64_t)b_cnt, c.s_main));
+    LATER(tmf_export_words(h, (const void*)d_sig, (int64_t)b_sig, c.s_main));
+    LATER(tmf_export_words(h + b_sig, (const void*)d_e, (int64_t)b_sig, c.s_main));
+    LATER(tmf_export_words(h + 2 * b_sig, (const void*)d_cnt, (int64_t)b_cnt, c.s_main));
     size_t o = 2 * b_sig + ((b_cnt + 7) & ~(size_t)7);
     for (size_t j = 0; j < c.sweep_counters.size(); ++j) {
-      TMF_TRY(tmf_export_words(h + o, c.sweep_counters[j], (int64_t)c.sweep_counts_n[j] * 4, c.s_main));
+      const int32_t* src_ = c.sweep_counters[j];
+      const int64_t nb_ = (int64_t)c.sweep_counts_n[j] * 4;
+      char* dst_ = h + o;
+      LATER(tmf_export_words(dst_, src_, nb_, c.s_main));
       o += (size_t)c.sweep_counts_n[j] * 4;
     }
+    TMF_TRY(run_deferred());
     tick(ST_E, t0);
     const double tw = now_ms();
     HIP_TRY(hipStreamSynchronize(c.s_main));
@@ -1080,7 +1129,7 @@ struct Sweep {
     if (maxnf > 0) {
       u64 d_OmF, d_scr2;
       TMF_TRY(alloc_el(L * maxnf, &d_OmF));
-      TMF_TRY(tmf_fill_normal(c.dtype, (void*)d_OmF, L * maxnf, 0xF111ED, c.s_main));
+      LATER(tmf_fill_normal(c.dtype, (void*)d_OmF, L * maxnf, 0xF111ED, c.s_main));
       std::vector<u64> Vf(ncs);
       for (i64 i = 0; i < ncs; ++i) Vf[i] = Vp[i] + (u64)(c.k[i] * c.ld1[i] * el);
       // one multiplication by A: the filled space has eigenvalue >= 1 - 1e-12, everything that is not projected off
@@ -1107,8 +1156,8 @@ struct Sweep {
         TMF_TRY(bcgs(s[0], passes, cholqr, wide, nullptr, fused));
         hipEvent_t ev;
         TMF_TRY(new_event(&ev));
-        HIP_TRY(hipEventRecord(ev, c.s_up));
-        HIP_TRY(hipStreamWaitEvent(c.s_main, ev, 0));
+        LATER_HIP(hipEventRecord(ev, c.s_up));
+        LATER_HIP(hipStreamWaitEvent(c.s_main, ev, 0));
       } else {
         s[0].insert(s[0].end(), s[1].begin(), s[1].end());
         TMF_TRY(bcgs(s[0], passes, cholqr, wide, nullptr, fused));
@@ -1138,7 +1187,7 @@ struct Sweep {
       // may have been handed to the sweep after next)
       TMF_TRY(acquire_slot(0));
       void* chk = c.slot->d_chk;
-      HIP_TRY(hipMemsetAsync(chk, 0, 64, c.s_main));
+      LATER_HIP(hipMemsetAsync(chk, 0, 64, c.s_main));
       c.d_chk = (char*)chk;
       tmf_recon_desc d[5];
       memset(d, 0, sizeof(d));
@@ -1164,7 +1213,8 @@ struct Sweep {
         u64 t_d, t_t;
         TMF_TRY(up(d, sizeof(d), &t_d));
         TMF_TRY(up_vec(tiles, &t_t));
-        TMF_TRY(tmf_recon_error_batched(c.dtype, (const tmf_recon_desc*)t_d, (const int32_t*)t_t, (int)(tiles.size() / 3), c.s_main));
+        const int ntile = (int)(tiles.size() / 3);
+        LATER(tmf_recon_error_batched(c.dtype, (const tmf_recon_desc*)t_d, (const int32_t*)t_t, ntile, c.s_main));
       }
       c.n_checks = 5;
     }
@@ -1256,10 +1306,14 @@ struct Sweep {
     hipEvent_t ev_main, ev_pool;
     TMF_TRY(new_event(&ev_main));
     TMF_TRY(new_event(&ev_pool));
-    HIP_TRY(hipEventRecord(ev_main, c.s_main));
-    HIP_TRY(hipStreamWaitEvent(c.s_up, ev_main, 0));
-    HIP_TRY(hipMemcpyAsync(t_pool, c.pool_pin.p, (size_t)c.ix_tot + 1, hipMemcpyHostToDevice, c.s_up));
-    HIP_TRY(hipEventRecord(ev_pool, c.s_up));
+    {
+      const void* pool_src = c.pool_pin.p;
+      const size_t pool_bytes = (size_t)c.ix_tot + 1;
+      LATER_HIP(hipEventRecord(ev_main, c.s_main));
+      LATER_HIP(hipStreamWaitEvent(c.s_up, ev_main, 0));
+      LATER_HIP(hipMemcpyAsync(t_pool, pool_src, pool_bytes, hipMemcpyHostToDevice, c.s_up));
+      LATER_HIP(hipEventRecord(ev_pool, c.s_up));
+    }
 
     std::vector<i64> mb(ns), mk(ns), ka(ns), sbv(ns), skv(ns);
     i64 tW = 0, maxmb = 0;
@@ -1309,7 +1363,7 @@ struct Sweep {
     }
     u64 t_gd, t_sd = 0;
     TMF_TRY(up_vec(gd, &t_gd));
-    TMF_TRY(tmf_gather_signed_batched(c.dtype, (const tmf_gather_desc*)t_gd, (int)ns, c.s_main));
+    LATER(tmf_gather_signed_batched(c.dtype, (const tmf_gather_desc*)t_gd, (int)ns, c.s_main));
     // Sites ordered by the size of their always-block so that the sites still active at outer step j0 are a prefix of
     // the descriptor arrays of the blocked methods.
     constexpr i64 WB = 64;
@@ -1345,10 +1399,10 @@ struct Sweep {
           ++nact;
         }
         // (j0 = 0 runs over all sites: a site without always-block gets det = 1)
-        TMF_TRY(tmf_lu_block_batched(c.dtype, (const tmf_lublock_desc*)t_ld, (int)(j0 == 0 ? ns : nact), (int)j0, (int)WB,
-                                     (int)(j0 == 0 ? maxmb : act_mb), c.s_main));
+        LATER(tmf_lu_block_batched(c.dtype, (const tmf_lublock_desc*)t_ld, (int)(j0 == 0 ? ns : nact), (int)j0, (int)WB,
+                                   (int)(j0 == 0 ? maxmb : act_mb), c.s_main));
         if (nact == 0) break;
-        TMF_TRY(tmf_lu_trsm_batched(c.dtype, (const tmf_lublock_desc*)t_ld, (int)nact, (int)j0, (int)WB, (int)max_cols, c.s_main));
+        LATER(tmf_lu_trsm_batched(c.dtype, (const tmf_lublock_desc*)t_ld, (int)nact, (int)j0, (int)WB, (int)max_cols, c.s_main));
         Gemm g;
         for (i64 r = 0; r < nact; ++r) {
           const i64 j = order[r], cend = std::min(ka[j], j0 + WB), ldw = std::max<i64>(mb[j], 1);
@@ -1391,7 +1445,7 @@ struct Sweep {
       for (i64 step = 0; step * WB < std::max<i64>(kmax, 1); ++step) {
         i64 nact = 0;
         while (nact < ns && ka[order[nact]] > step * WB) ++nact;   // cdiv(k, 64) blocks whichever end they are counted from
-        TMF_TRY(tmf_diag_inverse_batched(c.dtype, (const tmf_diaginv_desc*)t_ld, (int)(step == 0 ? ns : nact), (int)step, t_minp, c.s_main));
+        LATER(tmf_diag_inverse_batched(c.dtype, (const tmf_diaginv_desc*)t_ld, (int)(step == 0 ? ns : nact), (int)step, t_minp, c.s_main));
         if (nact == 0) break;
         Gemm g1, g2;
         for (i64 r = 0; r < nact; ++r) {
@@ -1408,10 +1462,14 @@ struct Sweep {
       // verdict -> device flag + summary in page-locked host memory (written by the kernel: no DMA copy on this stream)
       TMF_TRY(c.lu_stats.ensure(64));
       double* summary = (double*)c.lu_stats.p + 3 * c.cur;
-      TMF_TRY(tmf_diag_inverse_verdict(t_minp, (int)ns, c.lu_inverse_cap, (c.par.flags & TMF_SWEEP_LU_FORCE_FALLBACK) ? 1 : 0,
-                                       (int32_t*)t_flag, summary, c.s_main));
+      {
+        const double cap_ = c.lu_inverse_cap;
+        const int force_ = (c.par.flags & TMF_SWEEP_LU_FORCE_FALLBACK) ? 1 : 0;
+        LATER(tmf_diag_inverse_verdict(t_minp, (int)ns, cap_, force_, (int32_t*)t_flag, summary, c.s_main));
+      }
       c.lu_pending[c.cur] = true;
       if (getenv("TMF_LU_DEBUG")) {   // diagnostic (tools/lu_debug.py): per-site statistics, with a synchronisation
+        TMF_TRY(run_deferred());
         std::vector<double> h((size_t)(2 * ns + 2));
         HIP_TRY(hipMemcpyAsync(h.data(), t_minp, (size_t)ns * 16, hipMemcpyDeviceToHost, c.s_main));
         HIP_TRY(hipStreamSynchronize(c.s_main));
@@ -1423,17 +1481,23 @@ struct Sweep {
                     std::sqrt(h[2 * r + 1]));
       }
       // the fallback: gather again (the elimination has overwritten W), fully pivoted blocked LU - all of it conditional
-      tmf_launch_condition((const int32_t*)t_flag);
+      dq.emplace_back([=]() -> int {
+        tmf_launch_condition((const int32_t*)t_flag);
+        return TMF_OK;
+      });
       c.conditional = true;
-      int st = tmf_gather_signed_batched(c.dtype, (const tmf_gather_desc*)t_gd, (int)ns, c.s_main);
-      if (st == TMF_OK) st = lu_pivoted();
+      LATER(tmf_gather_signed_batched(c.dtype, (const tmf_gather_desc*)t_gd, (int)ns, c.s_main));
+      const int st = lu_pivoted();
       c.conditional = false;
-      tmf_launch_condition(nullptr);
+      dq.emplace_back([]() -> int {
+        tmf_launch_condition(nullptr);
+        return TMF_OK;
+      });
       return st;
     };
     if (c.par.flags & TMF_SWEEP_LU_SINGLE) {  // A/B switch: the one-workgroup-per-site kernel
       TMF_TRY(up_vec(sd, &t_sd));
-      TMF_TRY(tmf_lu_schur_batched(c.dtype, (const tmf_schur_desc*)t_sd, (int)ns, (int)maxmb, c.s_main));
+      LATER(tmf_lu_schur_batched(c.dtype, (const tmf_schur_desc*)t_sd, (int)ns, (int)maxmb, c.s_main));
     } else if (c.par.flags & TMF_SWEEP_LU_PIVOTED) {
       TMF_TRY(lu_pivoted());
     } else {
@@ -1443,7 +1507,7 @@ struct Sweep {
 
     // ---- S4: all minors ----
     t0 = now_ms();
-    HIP_TRY(hipStreamWaitEvent(c.s_main, ev_pool, 0));  // the determinant kernels read the pool
+    LATER_HIP(hipStreamWaitEvent(c.s_main, ev_pool, 0));  // the determinant kernels read the pool
     const double flop_per_det = c.cplx ? (8.0 / 3.0) : (2.0 / 3.0);  // LU of an n x n complex / real matrix
     c.n_det = 0;
     std::vector<i64> rest_keys;
@@ -1474,13 +1538,14 @@ struct Sweep {
         if (timing()) {
           TMF_TRY(new_event(&ev.e0));
           TMF_TRY(new_event(&ev.e1));
-          HIP_TRY(hipEventRecord(ev.e0, c.s_main));
+          LATER_HIP(hipEventRecord(ev.e0, c.s_main));
         }
         i64 widest = 0;
         for (i64 j = 0; j < ns; ++j) widest = std::max(widest, std::max(sbv[j], skv[j]));
-        TMF_TRY(tmf_det_ppt_batched_w(c.dtype, (const tmf_det_desc*)t_dd, (int)nt, lds_max, widest <= 32 ? 32 : 64, c.s_main));
+        const int mbits = widest <= 32 ? 32 : 64;
+        LATER(tmf_det_ppt_batched_w(c.dtype, (const tmf_det_desc*)t_dd, (int)nt, lds_max, mbits, c.s_main));
         if (timing()) {
-          HIP_TRY(hipEventRecord(ev.e1, c.s_main));
+          LATER_HIP(hipEventRecord(ev.e1, c.s_main));
           ev.flops = fl3 * flop_per_det, ev.n = npairs, ev.kind = 0, ev.order = 0;
           c.det_events.push_back(ev);
         }
@@ -1583,19 +1648,26 @@ struct Sweep {
         if (timing()) {
           TMF_TRY(new_event(&ev.e0));
           TMF_TRY(new_event(&ev.e1));
-          HIP_TRY(hipEventRecord(ev.e0, c.s_main));
+          LATER_HIP(hipEventRecord(ev.e0, c.s_main));
         }
-        TMF_TRY((gq.red ? tmf_det_reduced_batched : tmf_det_gather_batched)(c.dtype, gq.cls, (const tmf_det_desc*)t_dd, (int)dd.size(),
-                                                                           (int)lmax + 16, c.s_main));
+        {
+          const bool red_ = gq.red;
+          const int cls_ = gq.cls, ndd_ = (int)dd.size(), lds_ = (int)lmax + 16;
+          LATER((red_ ? tmf_det_reduced_batched : tmf_det_gather_batched)(c.dtype, cls_, (const tmf_det_desc*)t_dd, ndd_, lds_, c.s_main));
+        }
         if (timing()) {
-          HIP_TRY(hipEventRecord(ev.e1, c.s_main));
+          LATER_HIP(hipEventRecord(ev.e1, c.s_main));
           ev.flops = fl * flop_per_det, ev.n = pairs, ev.kind = gq.red ? 1 : 2, ev.order = gq.cls;
           c.det_events.push_back(ev);
         }
         c.n_det += pairs;
       }
     }
-    HIP_TRY(hipEventRecord(c.set_done[c.cur], c.s_main));  // every kernel of this sweep is enqueued
+    {
+      hipEvent_t done_ = c.set_done[c.cur];
+      LATER_HIP(hipEventRecord(done_, c.s_main));  // every kernel of this sweep is enqueued
+    }
+    TMF_TRY(run_deferred());
     c.set_used[c.cur] = true;
     tick(ST_DET, t0);
     return TMF_OK;
@@ -1609,6 +1681,7 @@ struct Sweep {
     classify();
     TMF_TRY(filled_stage());
     TMF_TRY(overlap_stage());
+    TMF_TRY(run_deferred());  // one descriptor transfer, then every launch of the two stages
     TMF_TRY(host_phase());  // integer work on host threads while the GPU runs the filled-basis launches
     TMF_TRY(site_stage());
     c.have_sites = c.have_out = true;

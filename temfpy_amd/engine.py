@@ -1359,8 +1359,9 @@ class Engine:
                 t_dd = self._up(tiles[:nt])
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record(torch.cuda.current_stream(self.device))
-                nat.check(self.lib.tmf_det_ppt_batched(self.dtype, t_dd.data_ptr(), nt, int(lds_max[0]), self.stream),
-                          "tmf_det_ppt_batched")
+                widest = int(max(souts["sb"].max(initial=0), souts["sk"].max(initial=0)))    # as csrc/sweep.cpp: mask width of the launch
+                nat.check(self.lib.tmf_det_ppt_batched_w(self.dtype, t_dd.data_ptr(), nt, int(lds_max[0]), 32 if widest <= 32 else 64,
+                                                         self.stream), "tmf_det_ppt_batched")
                 ev1.record(torch.cuda.current_stream(self.device))
                 self.det_events.append(("ppt", ev0, ev1, float(fl3[0]) * flop_per_det, int(npairs[0])))
                 n_det += int(npairs[0])
