@@ -306,6 +306,8 @@ typedef struct {
   int32_t na, nb, lds_, ldn;
 } tmf_pf_matrix_desc;        /* 32 bytes */
 int tmf_pf_matrix_batched(const tmf_pf_matrix_desc* d_desc, int nprob, void* stream);
+/* norm[i] = sqrt(|det[i]|): the Onishi norm sqrt(prod sv(U)) of pfaffian.py:1352-1359 from det(U^*) (complex128 elements) */
+int tmf_onishi_norms(const void* d_det, void* d_norm, int n, void* stream);
 
 /* ---- result path: page-locked host memory ----------------------------------------- */
 /* The reference's tensors are NumPy arrays in host memory (slater.py:1137-1141 fills them in
@@ -489,6 +491,8 @@ int tmf_site_prepare(const tmf_site_in* in, const uint64_t* sets_b, const int32_
 
 /* Batched, multi-threaded forms (one call per sweep).  Per-cut outputs live at stride `cap`
  * (sets: cap*2 words) in the caller's arrays; `chi[i]` receives the number of kept vectors. */
+/* fn(i, arg) for i in [0, n) on the library's persistent worker threads (first non-zero status is returned) */
+int tmf_host_parallel_for(int n, int nthreads, int (*fn)(int, void*), void* arg);
 int tmf_cut_vectors_batch(int ncuts, const double* e_pool, const int64_t* e_off, const int32_t* k,
                           const int32_t* filled_left, int64_t chi_max, double svd_min, double degeneracy_tol,
                           const int64_t* sectors, int n_sectors, int64_t cap, uint64_t* sets, double* lam_raw,
@@ -629,6 +633,72 @@ int tmf_sweep_info_get(tmf_ctx* ctx, tmf_sweep_info* out);
 const char* tmf_sweep_stage_name(int i);
 /* device address / element count of the tensors of the last tmf_sweep_sites (valid until the next one) */
 int tmf_sweep_device_out(tmf_ctx* ctx, uint64_t* d_out, int64_t* elems);
+
+/* ---- Pfaffian (BCS / Nambu mean-field) -> MPS: pfaffian.C_to_MPS (pfaffian.py:1785-1921) in one call ---------------
+ * C: the 2L x 2L Nambu correlation matrix in the MAJORANA basis, row-major complex128 in host memory (pfaffian.py:750-751
+ * converts from the complex-fermion basis); par->L = number of sites L, par->is_complex = 1, par->ortho_center resolved
+ * (pfaffian.py:1843), site_lo / site_hi ignored (whole chain).  Runs the cut decomposition of every bond
+ * (SchmidtModes / SchmidtVectors.from_correlation_matrix, pfaffian.py:685-920, :1008-1248: entangled pairs, vacuum
+ * parities, best-first enumeration, (parity, number) order), `_pfaffian_matrix` of every site (pfaffian.py:1258-1410) and all
+ * sub-Pfaffians (`_tensor_block`, pfaffian.py:1429-1479); with TMF_SWEEP_CHECKS the deviations of
+ * testing.check_schmidt_decomposition for both sides of every cut (pfaffian.py:919).  range_floor_tol <= 0 -> 3e-15.
+ * Returns TMF_E_HALF_MODES when a cut carries eigenvalue-1/2 modes (pfaffian.py:803-816): following the reference there
+ * needs SciPy's seeded ortho_group stream, which the Python driver (temfpy_amd/engine_pf.py, same kernels) has. */
+#define TMF_E_HALF_MODES (-4)
+typedef struct tmf_pf_result tmf_pf_result;
+int tmf_pfaffian_sweep(tmf_ctx* ctx, const void* C, const tmf_sweep_params* par, double range_floor_tol, tmf_pf_result** out);
+typedef struct {
+  int64_t x;
+  int32_t k, chi, p_left, p_right;   /* entangled pairs, kept Schmidt vectors, vacuum parities pL / pR (SchmidtModes) */
+  const double* e;           /* k lower eigenvalues, ascending (pfaffian.py:839)                                    */
+  const uint8_t* sets;       /* chi x k row-major: excitation pattern of every Schmidt vector, rows in (parity, number) order */
+  const double* lam_raw;     /* unnormalised Schmidt values, same order                                            */
+} tmf_pf_bond_view;
+typedef struct {
+  int64_t site;
+  int32_t mode, qtotal;      /* 0: A tensor, 1: B tensor; total parity charge of the tensor (pfaffian.py:1733)      */
+  int32_t chi_bra, chi_ket, n_blocks, pad;
+  double norm;               /* Onishi norm sqrt(prod sv(U)) (pfaffian.py:1352-1359), already multiplied into the blocks */
+  const int32_t* leg_idx_bra; /* 2 chi_bra entries: row of the unsorted (p, bra) pipe for every row of the sorted leg  */
+} tmf_pf_site_view;
+typedef struct {
+  int32_t n_bra, n_ket, r0, r1, c0, c1;   /* excitation numbers of the bra / ket sector; rows of the sorted bra leg, ket columns */
+  const void* data;          /* (r1 - r0) x (c1 - c0) complex128, row-major                                         */
+} tmf_pf_block_view;
+int tmf_pf_result_dims(const tmf_pf_result* r, int64_t* L, int64_t* ortho_center, int64_t* out_elems, int32_t* n_checks,
+                       tmf_sweep_info* info);
+int tmf_pf_result_bond(const tmf_pf_result* r, int64_t b, tmf_pf_bond_view* out);
+int tmf_pf_result_site(const tmf_pf_result* r, int64_t i, tmf_pf_site_view* out);
+int tmf_pf_result_block(const tmf_pf_result* r, int64_t i, int64_t j, tmf_pf_block_view* out);
+/* n_checks entries: deviation, cut, kind (0 "vL is not unitary", 1 "vL does not diagonalise C_LL", 2 / 3 the same for R) */
+int tmf_pf_result_checks(const tmf_pf_result* r, double* values, int32_t* cuts, int32_t* kinds);
+/* The whole result as flat tables (valid until tmf_pf_result_free): what the per-bond / per-site / per-block accessors
+ * return, concatenated.  bond: (k, chi, pL, pR) per bond; e / sets / lam_raw of bond b at [x_off[b], x_off[b + 1]);
+ * site: (mode, qtotal, chi_bra, chi_ket, n_blocks) per site; blk: (n_bra, n_ket, r0, r1, c0, c1, element offset into out)
+ * per block, the blocks of site i at rows [blk_off[i], blk_off[i + 1]). */
+typedef struct {
+  int64_t n_bonds, n_sites, n_blocks, out_elems;
+  const int32_t* bond;
+  const int64_t* e_off;
+  const double* e;
+  const int64_t* sets_off;
+  const uint8_t* sets;
+  const int64_t* lam_off;
+  const double* lam_raw;
+  const int32_t* site;
+  const double* norm;
+  const int64_t* leg_off;
+  const int32_t* leg_idx_bra;
+  const int64_t* blk_off;
+  const int64_t* blk;
+  const void* out;
+} tmf_pf_flat;
+int tmf_pf_result_flat(const tmf_pf_result* r, tmf_pf_flat* out);
+/* Copies the tensors (out_elems complex128 elements) from the context's device memory into `dst` (page-locked memory for
+ * full PCIe speed) and blocks until they are there; call before the context's next sweep.  Afterwards the `data` / `out`
+ * pointers of the accessors point into `dst` (NULL before). */
+int tmf_pf_result_download(tmf_pf_result* r, void* dst);
+void tmf_pf_result_free(tmf_pf_result* r);
 
 /* One call: the whole conversion of sites [site_lo, site_hi) with the adaptive range finder (64, 128, 256
  * columns; one subspace iteration when the smallest captured singular value exceeds range_floor_tol <= 0 ->

@@ -88,7 +88,8 @@ SYMBOLS = [
     "tmf_last_error", "tmf_version", "tmf_device_count", "tmf_gemm_batched", "tmf_gemm_tall_batched", "tmf_orth_panel_batched",
     "tmf_bcgs_work_bytes", "tmf_bcgs_batched", "tmf_jacobi_batched", "tmf_svd_left_batched",
     "tmf_jacobi_block_batched", "tmf_nested_products_batched", "tmf_recon_error_batched", "tmf_lu_schur_batched",
-    "tmf_det_gather_batched", "tmf_det_reduced_batched", "tmf_det_ppt_batched", "tmf_det_ppt_batched_w", "tmf_det_ppt_stamps", "tmf_block_orth_batched", "tmf_gemm_set_4m", "tmf_block_orth_stamps", "tmf_transpose", "tmf_fill_normal",
+    "tmf_det_gather_batched", "tmf_det_reduced_batched", "tmf_det_ppt_batched", "tmf_det_ppt_batched_w", "tmf_det_ppt_stamps", "tmf_block_orth_batched", "tmf_pfaffian_sweep", "tmf_pf_result_dims", "tmf_pf_result_bond", "tmf_pf_result_site",
+    "tmf_pf_result_block", "tmf_pf_result_checks", "tmf_pf_result_flat", "tmf_pf_result_download", "tmf_pf_result_free", "tmf_onishi_norms", "tmf_host_parallel_for", "tmf_gemm_set_4m", "tmf_block_orth_stamps", "tmf_transpose", "tmf_fill_normal",
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_column_norms_batched", "tmf_cut_vectors",
     "tmf_site_prepare", "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_det_tiles_build", "tmf_pf_gather_batched",
     "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched", "tmf_copy_blocks_batched", "tmf_house_qr_batched", "tmf_jacobi_compact_batched", "tmf_house_slab_batched",
@@ -149,6 +150,29 @@ class BlockView(C.Structure):
 
 
 assert C.sizeof(SweepParams) == 80 and C.sizeof(SweepDims) == 64 and C.sizeof(SweepPtrs) == 23 * 8
+
+
+class PfBondView(C.Structure):
+    _fields_ = [("x", C.c_int64), ("k", C.c_int32), ("chi", C.c_int32), ("p_left", C.c_int32), ("p_right", C.c_int32),
+                ("e", C.c_void_p), ("sets", C.c_void_p), ("lam_raw", C.c_void_p)]
+
+
+class PfSiteView(C.Structure):
+    _fields_ = [("site", C.c_int64), ("mode", C.c_int32), ("qtotal", C.c_int32), ("chi_bra", C.c_int32), ("chi_ket", C.c_int32),
+                ("n_blocks", C.c_int32), ("pad", C.c_int32), ("norm", C.c_double), ("leg_idx_bra", C.c_void_p)]
+
+
+class PfBlockView(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_bra", "n_ket", "r0", "r1", "c0", "c1")] + [("data", C.c_void_p)]
+
+
+class PfFlat(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_bonds", "n_sites", "n_blocks", "out_elems")] + \
+               [(n, C.c_void_p) for n in ("bond", "e_off", "e", "sets_off", "sets", "lam_off", "lam_raw", "site", "norm", "leg_off",
+                                          "leg_idx_bra", "blk_off", "blk", "out")]
+
+
+E_HALF_MODES = -4          # tmf_pfaffian_sweep: eigenvalue-1/2 modes at a cut, take the Python driver
 
 
 def sweep_spec(dims, cplx, want_out=True):
@@ -252,6 +276,17 @@ def load():
     lib.tmf_result_checks.argtypes = [vp, C.POINTER(f64), C.POINTER(C.c_int32)]
     lib.tmf_result_free.argtypes = [vp]
     lib.tmf_result_free.restype = None
+    lib.tmf_pfaffian_sweep.argtypes = [vp, vp, C.POINTER(SweepParams), f64, C.POINTER(vp)]
+    lib.tmf_pf_result_dims.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_int32), C.POINTER(SweepInfo)]
+    lib.tmf_pf_result_bond.argtypes = [vp, i64, C.POINTER(PfBondView)]
+    lib.tmf_pf_result_site.argtypes = [vp, i64, C.POINTER(PfSiteView)]
+    lib.tmf_pf_result_block.argtypes = [vp, i64, i64, C.POINTER(PfBlockView)]
+    lib.tmf_pf_result_checks.argtypes = [vp, vp, vp, vp]
+    lib.tmf_pf_result_flat.argtypes = [vp, C.POINTER(PfFlat)]
+    lib.tmf_pf_result_download.argtypes = [vp, vp]
+    lib.tmf_pf_result_free.argtypes = [vp]
+    lib.tmf_pf_result_free.restype = None
+    lib.tmf_onishi_norms.argtypes = [vp, vp, i32, vp]
     lib.tmf_host_register.argtypes = [vp, i64]
     lib.tmf_host_unregister.argtypes = [vp]
     lib.tmf_memcpy_async.argtypes = [vp, vp, i64, i32, vp]

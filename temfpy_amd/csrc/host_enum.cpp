@@ -620,6 +620,11 @@ int parallel_for(int n, int nthreads, F&& fn) {
 }
 }  // namespace
 
+// generic form for the host drivers (csrc/sweep.cpp): fn(i, arg) for i in [0, n) on the library's worker threads
+extern "C" int tmf_host_parallel_for(int n, int nthreads, int (*fn)(int, void*), void* arg) {
+  return parallel_for(n, nthreads, [&](int i) { return fn(i, arg); });
+}
+
 extern "C" int tmf_cut_vectors_batch(int ncuts, const double* e_pool, const int64_t* e_off, const int32_t* k,
                                      const int32_t* filled_left, int64_t chi_max, double svd_min,
                                      double degeneracy_tol, const int64_t* sectors, int n_sectors, int64_t cap,

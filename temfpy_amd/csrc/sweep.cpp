@@ -28,6 +28,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <functional>
 #include <memory>
@@ -1755,6 +1756,8 @@ struct Sweep {
   }
 };
 
+#include "sweep_pf.inc"
+
 }  // namespace
 }  // namespace tmf
 
@@ -2104,3 +2107,5 @@ extern "C" void tmf_result_free(tmf_result* r) {
   r->buf.release();
   delete r;
 }
+
+#include "sweep_pf_abi.inc"

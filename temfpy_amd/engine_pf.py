@@ -204,8 +204,109 @@ class PfEngine(Engine):
                       ldw[:nact], np.full(nact, 64), ldw[:nact])
 
     range_floor_tol = 3e-15  # see Engine.entangled_stage_adaptive
+    pf_sweep_impl = os.environ.get("TMF_PF_SWEEP", "cpp")    # "cpp": tmf_pfaffian_sweep (csrc/sweep_pf.inc); "python": run_py (A/B)
 
     def run(self, C, trunc, ortho_center, unit_cell_width, threads=None):
+        """One Nambu correlation matrix -> MPS conversion.  The sweep runs in C++ behind ``tmf_pfaffian_sweep``; inputs whose
+        cuts carry eigenvalue-1/2 modes (TMF_E_HALF_MODES: following the reference there needs SciPy's seeded ``ortho_group``
+        stream) and ``TMF_PF_SWEEP=python`` take the Python orchestration of the same kernels (:meth:`run_py`)."""
+        if self.pf_sweep_impl == "cpp":
+            res = self.run_cpp(C, trunc, ortho_center, unit_cell_width, threads)
+            if res is not None:
+                return res
+        return self.run_py(C, trunc, ortho_center, unit_cell_width, threads)
+
+    def run_cpp(self, C, trunc, ortho_center, unit_cell_width, threads=None):
+        import ctypes
+        lib = self.lib
+        t_all = time.perf_counter()
+        if self._ctx is None:
+            ctx = ctypes.c_void_p()
+            nat.check(lib.tmf_ctx_create(self.device.index or 0, ctypes.byref(ctx)), "tmf_ctx_create")
+            self._ctx = ctx
+            import weakref
+            self._ctx_finalizer = weakref.finalize(self, lib.tmf_ctx_destroy, ctypes.c_void_p(ctx.value))
+            self._ctx_finalizer.atexit = False
+        C = np.ascontiguousarray(C, np.complex128)
+        L = len(C) // 2
+        sectors = _sector_list(trunc, L)
+        sec = None if sectors is None else np.ascontiguousarray(sectors, np.int64)
+        flags = (nat.SWEEP_CHECKS if self.checks else 0) | (0 if self.filled_cholqr else nat.SWEEP_NO_CHOLQR)
+        par = nat.SweepParams(L=L, chi_max=int(trunc.chi_max or 0), svd_min=float(trunc.svd_min),
+                              degeneracy_tol=float(trunc.degeneracy_tol), sectors=None if sec is None else sec.ctypes.data,
+                              ortho_center=int(ortho_center), site_lo=0, site_hi=L, n_sectors=0 if sec is None else int(sec.size),
+                              is_complex=1, host_threads=int(threads or self.host_threads), flags=flags)
+        res = ctypes.c_void_p()
+        st = lib.tmf_pfaffian_sweep(self._ctx, C.ctypes.data, ctypes.byref(par), self.range_floor_tol, ctypes.byref(res))
+        if st == nat.E_HALF_MODES:
+            return None
+        if st == -2 and "Jacobi iteration did not converge" in lib.tmf_last_error().decode():
+            raise np.linalg.LinAlgError(lib.tmf_last_error().decode())
+        nat.check(st, "tmf_pfaffian_sweep")
+        try:
+            n_out, n_chk, info = ctypes.c_int64(), ctypes.c_int32(), nat.SweepInfo()
+            nat.check(lib.tmf_pf_result_dims(res, None, None, ctypes.byref(n_out), ctypes.byref(n_chk), ctypes.byref(info)), "dims")
+            fl = nat.PfFlat()
+            nat.check(lib.tmf_pf_result_flat(res, ctypes.byref(fl)), "tmf_pf_result_flat")
+
+            def arr(ptr, dtype, count):          # one copy out of the library's memory per table
+                if count == 0:
+                    return np.zeros(0, dtype)
+                nbytes = count * np.dtype(dtype).itemsize
+                return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), (nbytes,)).view(dtype).copy()
+
+            nb, nsite, nblk = int(fl.n_bonds), int(fl.n_sites), int(fl.n_blocks)
+            bond = arr(fl.bond, np.int32, 4 * nb).reshape(nb, 4)
+            e_off, s_off, l_off = (arr(p, np.int64, nb + 1) for p in (fl.e_off, fl.sets_off, fl.lam_off))
+            e_f, s_f, l_f = arr(fl.e, np.float64, int(e_off[-1])), arr(fl.sets, np.uint8, int(s_off[-1])), arr(fl.lam_raw, np.float64, int(l_off[-1]))
+            site = arr(fl.site, np.int32, 5 * nsite).reshape(nsite, 5)
+            norm = arr(fl.norm, np.float64, nsite)
+            leg_off, blk_off = arr(fl.leg_off, np.int64, nsite + 1), arr(fl.blk_off, np.int64, nsite + 1)
+            leg = arr(fl.leg_idx_bra, np.int32, int(leg_off[-1])).astype(np.int64)
+            blk = arr(fl.blk, np.int64, 7 * nblk).reshape(nblk, 7)
+            # the tensors go straight from the device into page-locked memory owned by the result (no copy through the library)
+            buf, keep = self.default_sink().alloc(max(int(fl.out_elems), 1) * 16)
+            nat.check(lib.tmf_pf_result_download(res, buf.ctypes.data), "tmf_pf_result_download")
+            flat = buf[: int(fl.out_elems) * 16].view(np.complex128)
+            flat_keep = keep
+            self.check_results = {}
+            if n_chk.value:
+                vals, cuts, kinds = np.zeros(n_chk.value), np.zeros(n_chk.value, np.int32), np.zeros(n_chk.value, np.int32)
+                nat.check(lib.tmf_pf_result_checks(res, nat._p(vals), nat._p(cuts), nat._p(kinds)), "checks")
+                names = ("vL is not unitary", "vL does not diagonalise C_LL", "vR is not unitary", "vR does not diagonalise C_RR")
+                for kd in range(4):      # one entry per message: the worst cut
+                    m = np.nonzero(kinds == kd)[0]
+                    if m.size:
+                        w = m[int(np.argmax(vals[m]))] if np.all(np.isfinite(vals[m])) else m[int(np.argmax(~np.isfinite(vals[m])))]
+                        self.check_results[f"{names[kd]} (cut {int(cuts[w])})"] = float(vals[w])
+        finally:
+            lib.tmf_pf_result_free(res)
+
+        def make_bond(b):
+            k, chi, pL, pR = (int(x) for x in bond[b])
+            sets = s_f[s_off[b]: s_off[b + 1]].reshape(chi, k).astype(bool)
+            return PfBond(b, e_f[e_off[b]: e_off[b + 1]], pL, pR, sets, l_f[l_off[b]: l_off[b + 1]])
+
+        def make_site(i):
+            mode, qtotal, chi_b, chi_k, _ = (int(x) for x in site[i])
+            blocks = {}
+            for nbq, nkq, r0, r1, c0, c1, o in blk[blk_off[i]: blk_off[i + 1]].tolist():
+                blocks[(nbq, nkq)] = (r0, r1, c0, c1, flat[o: o + (r1 - r0) * (c1 - c0)].reshape(r1 - r0, c1 - c0))
+            return PfSite("left" if mode == 0 else "right", float(norm[i]), qtotal, leg[leg_off[i]: leg_off[i + 1]], blocks, chi_b, chi_k)
+
+        from .mps_data import LazyList
+        bonds, sites = LazyList(L + 1, make_bond), LazyList(L, make_site)
+        sites._keep = flat_keep
+        self.timings = {}
+        for i in range(16):
+            name = lib.tmf_sweep_stage_name(i).decode()
+            if name:
+                self.timings[name] = info.stage_ms[i] * 1e-3
+        self.range_iterations_used, self.range_width, self.range_floor = int(info.range_iterations), int(info.range_width), float(info.range_floor)
+        self.timings["total"] = time.perf_counter() - t_all
+        return self._finish(PfMPSData(bonds, sites, ortho_center, unit_cell_width, dict(self.timings)))
+
+    def run_py(self, C, trunc, ortho_center, unit_cell_width, threads=None):
         torch = self.torch
         t_all = time.perf_counter()
         self.timings = {}
@@ -581,9 +682,7 @@ class PfEngine(Engine):
         t_pd = self._up(pd)
         nat.check(self.lib.tmf_pf_matrix_batched(t_pd.data_ptr(), L, self.stream), "pf_matrix")
         # Onishi norm sqrt(prod sv(U)) = |det U|^(1/2) (pfaffian.py:1352-1359): tiny, on the host
-        h_det = d_det.cpu().numpy()
-        norms = np.sqrt(np.abs(h_det)).astype(np.complex128)
-        d_norm.copy_(torch.from_numpy(norms).to(self.device))
+        nat.check(self.lib.tmf_onishi_norms(d_det.data_ptr(), d_norm.data_ptr(), L, self.stream), "tmf_onishi_norms")
         self._tick("S_overlap_schur", t0)
 
         # ---- all sub-Pfaffians ------------------------------------------------------------------------------
@@ -658,6 +757,7 @@ class PfEngine(Engine):
 
         t0 = time.perf_counter()
         h_out = d_out.cpu().numpy()
+        norms = d_norm.cpu().numpy()
         sites = []
         for i, r in enumerate(prep):
             blocks = {}

@@ -299,3 +299,70 @@ def test_config4_full_size(kind):
     print(f"config 4 ({kind}): L={L} chi={chi} {dt * 1e3:.1f} ms -> {L / dt:.0f} sites/s, S(centre)="
           f"{mps.entanglement_entropy(all_bonds=True)[oc]:.9f}, max k={max(b.k for b in mps.bonds)}, "
           f"sampled sites vs oracle: relative Frobenius deviation of |entries| {worst_frob:.1e}")
+
+
+def test_pfaffian_sweep_c_abi_through_ctypes():
+    """`tmf_pfaffian_sweep` + the `tmf_pf_result_*` accessors as a C caller would use them (include/temfpy_hip.h,
+    INTEGRATION.md level 2): one call per conversion, per-bond / per-site / per-block views, the tensors downloaded into
+    caller memory; everything equal to what `pfaffian.C_to_MPS` returns (which goes through the flat tables) and to the
+    Python orchestration of the same kernels (bit for bit)."""
+    import ctypes
+    from temfpy_amd import _native as nat
+    from temfpy_amd import pfaffian
+    from temfpy_amd.engine_pf import PfEngine
+    from temfpy_amd.schmidt_utils import to_stopping_condition
+
+    g = load("pf_rand_L10_s2_chi24")
+    C = np.ascontiguousarray(g["C"], np.complex128)
+    L, chi = int(g["L"]), int(g["chi_max"])
+    lib = nat.load()
+    ctx, res = ctypes.c_void_p(), ctypes.c_void_p()
+    nat.check(lib.tmf_ctx_create(0, ctypes.byref(ctx)), "ctx")
+    par = nat.SweepParams(L=L, chi_max=chi, svd_min=1e-6, degeneracy_tol=1e-12, sectors=None, ortho_center=L // 2, site_lo=0,
+                          site_hi=L, n_sectors=0, is_complex=1, host_threads=4, flags=nat.SWEEP_CHECKS)
+    nat.check(lib.tmf_pfaffian_sweep(ctx, C.ctypes.data, ctypes.byref(par), 0.0, ctypes.byref(res)), "tmf_pfaffian_sweep")
+    try:
+        n_out, n_chk, Lr, oc = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64()
+        nat.check(lib.tmf_pf_result_dims(res, ctypes.byref(Lr), ctypes.byref(oc), ctypes.byref(n_out), ctypes.byref(n_chk), None), "dims")
+        assert (Lr.value, oc.value) == (L, L // 2) and n_chk.value == 2 * (L + 2) - 4      # both sides of every cut that has rows
+        out = np.zeros(n_out.value, np.complex128)
+        nat.check(lib.tmf_pf_result_download(res, out.ctypes.data), "download")
+        ref = pfaffian.C_to_MPS(g["C"], {"chi_max": chi}, basis="M", as_tenpy=False)
+        py = PfEngine("cuda:0").run_py(C, to_stopping_condition({"chi_max": chi}), L // 2, L)
+        bv, sv, kv = nat.PfBondView(), nat.PfSiteView(), nat.PfBlockView()
+        for b in range(L + 1):
+            nat.check(lib.tmf_pf_result_bond(res, b, ctypes.byref(bv)), "bond")
+            e = np.ctypeslib.as_array(ctypes.cast(bv.e, ctypes.POINTER(ctypes.c_double)), (bv.k,)) if bv.k else np.zeros(0)
+            lam = np.ctypeslib.as_array(ctypes.cast(bv.lam_raw, ctypes.POINTER(ctypes.c_double)), (bv.chi,))
+            sets = (np.ctypeslib.as_array(ctypes.cast(bv.sets, ctypes.POINTER(ctypes.c_uint8)), (bv.chi * bv.k,)) if bv.k
+                    else np.zeros(0, np.uint8))
+            for m in (ref, py):
+                bd = m.bonds[b]
+                assert (bv.k, bv.chi, bv.p_left, bv.p_right) == (bd.k, bd.chi, bd.pL, bd.pR)
+                assert np.array_equal(e, bd.e) and np.array_equal(lam, bd.lam_raw)
+                assert np.array_equal(sets.reshape(bv.chi, bv.k).astype(bool), bd.sets)
+            np.testing.assert_allclose(e, g[f"b{b}_e"], rtol=0, atol=1e-13)                 # and the reference fixture
+            np.testing.assert_array_equal(sets.reshape(bv.chi, bv.k).astype(bool), g[f"b{b}_sets"])
+        assert lib.tmf_pf_result_bond(res, L + 1, ctypes.byref(bv)) == -1
+        for i in range(L):
+            nat.check(lib.tmf_pf_result_site(res, i, ctypes.byref(sv)), "site")
+            for m in (ref, py):
+                s = m.sites[i]
+                assert (("left", "right")[sv.mode], sv.qtotal, sv.chi_bra, sv.chi_ket, sv.n_blocks) == (s.mode, s.qtotal, s.chi_bra, s.chi_ket, len(s.blocks))
+                assert sv.norm == s.norm
+                leg = np.ctypeslib.as_array(ctypes.cast(sv.leg_idx_bra, ctypes.POINTER(ctypes.c_int32)), (2 * sv.chi_bra,))
+                assert np.array_equal(leg, s.leg_idx_bra)
+            for j in range(sv.n_blocks):
+                nat.check(lib.tmf_pf_result_block(res, i, j, ctypes.byref(kv)), "block")
+                o = (kv.data - out.ctypes.data) // 16
+                blk = out[o: o + (kv.r1 - kv.r0) * (kv.c1 - kv.c0)].reshape(kv.r1 - kv.r0, kv.c1 - kv.c0)
+                for m in (ref, py):
+                    r0, r1, c0, c1, want = m.sites[i].blocks[(kv.n_bra, kv.n_ket)]
+                    assert (r0, r1, c0, c1) == (kv.r0, kv.r1, kv.c0, kv.c1) and np.array_equal(blk, want)
+            assert lib.tmf_pf_result_block(res, i, sv.n_blocks, ctypes.byref(kv)) == -1
+        vals, cuts, kinds = np.zeros(n_chk.value), np.zeros(n_chk.value, np.int32), np.zeros(n_chk.value, np.int32)
+        nat.check(lib.tmf_pf_result_checks(res, nat._p(vals), nat._p(cuts), nat._p(kinds)), "checks")
+        assert vals.max() < 1e-10 and set(kinds.tolist()) == {0, 1, 2, 3} and cuts.min() >= 0 and cuts.max() <= L
+    finally:
+        lib.tmf_pf_result_free(res)
+        lib.tmf_ctx_destroy(ctx)
