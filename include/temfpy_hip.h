@@ -376,6 +376,8 @@ typedef struct {
   int32_t n, c, lda, ldq, ldr, flags;
 } tmf_slab_desc;             /* 48 bytes */
 int tmf_house_slab_batched(int dtype, const tmf_slab_desc* d_desc, int nprob, int max_n, int max_c, void* stream);
+/* diagnostics (TMF_SLAB_STAMPS=1): cycles per phase of one wavefront [0..7], workgroups, rows [8, 9]; clears */
+int tmf_house_slab_stamps(uint64_t* out16);
 
 /* Products of nested blocks of one D x D matrix C (column-major) with a shared block Omega whose
  * rows are indexed by the GLOBAL orbital index: for every cut position x with dest[x] != 0

@@ -88,7 +88,7 @@ SYMBOLS = [
     "tmf_last_error", "tmf_version", "tmf_device_count", "tmf_gemm_batched", "tmf_gemm_tall_batched", "tmf_orth_panel_batched",
     "tmf_bcgs_work_bytes", "tmf_bcgs_batched", "tmf_jacobi_batched", "tmf_svd_left_batched",
     "tmf_jacobi_block_batched", "tmf_nested_products_batched", "tmf_recon_error_batched", "tmf_lu_schur_batched",
-    "tmf_det_gather_batched", "tmf_det_reduced_batched", "tmf_det_ppt_batched", "tmf_det_ppt_batched_w", "tmf_det_ppt_stamps", "tmf_block_orth_batched", "tmf_pfaffian_sweep", "tmf_pf_result_dims", "tmf_pf_result_bond", "tmf_pf_result_site",
+    "tmf_det_gather_batched", "tmf_det_reduced_batched", "tmf_det_ppt_batched", "tmf_det_ppt_batched_w", "tmf_det_ppt_stamps", "tmf_block_orth_batched", "tmf_house_slab_stamps", "tmf_pfaffian_sweep", "tmf_pf_result_dims", "tmf_pf_result_bond", "tmf_pf_result_site",
     "tmf_pf_result_block", "tmf_pf_result_checks", "tmf_pf_result_flat", "tmf_pf_result_download", "tmf_pf_result_free", "tmf_onishi_norms", "tmf_host_parallel_for", "tmf_gemm_set_4m", "tmf_block_orth_stamps", "tmf_transpose", "tmf_fill_normal",
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_column_norms_batched", "tmf_cut_vectors",
     "tmf_site_prepare", "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_det_tiles_build", "tmf_pf_gather_batched",

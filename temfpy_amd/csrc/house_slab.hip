@@ -18,6 +18,10 @@
 // (First version with the panel in LDS: 5 LDS accesses per element and reflector, LDS-bandwidth bound at 5.4 ms
 // per launch - no faster than the Gram-Schmidt it replaces.)  HBM traffic: 7 x the slab (PMC: 1.9 GB per launch for
 // 0.27 GB of slabs with Q, the earlier reflectors are re-read by every later panel), 0.8 TB/s: not the bound.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace tmf {
@@ -31,8 +35,16 @@ constexpr int VB = 8;   // reflectors per LDS block
 
 template <typename T, int RMAX>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, (RMAX * sizeof(T) <= 128) ? 8 : 4)))
-void house_slab_kernel(const tmf_slab_desc* __restrict__ desc, int w) {
+void house_slab_kernel(const tmf_slab_desc* __restrict__ desc, int w, unsigned long long* __restrict__ dbg) {
   extern __shared__ __align__(16) unsigned char smem[];
+  // diagnostics (TMF_SLAB_STAMPS=1): cycles per phase of wavefront 1, summed over the launch
+  unsigned long long tq = dbg ? __builtin_amdgcn_s_memtime() : 0ull, tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto lap = [&](int i) {
+    if (dbg) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tacc[i] += now - tq, tq = now;
+    }
+  };
   const tmf_slab_desc d = desc[blockIdx.x];
   const int n = d.n, c = d.c;
   if (n <= 0 || c <= 0) return;
@@ -82,14 +94,17 @@ void house_slab_kernel(const tmf_slab_desc* __restrict__ desc, int w) {
       const int r = lane + 64 * i;
       col[i] = (mine && r < n) ? a[r] : sc<T>::zero();
     }
+    lap(0);
     const int kprev = p0 < K ? p0 : K;
     for (int kb = 0; kb < kprev; kb += VB) {      // reflectors of the earlier panels, VB at a time
       const int nb = (kprev - kb < VB) ? kprev - kb : VB;
       __syncthreads();
       load_block(kb, nb);
       __syncthreads();
+      lap(1);
       if (mine)
         for (int j = 0; j < nb; ++j) apply(kb + j, sc<T>::conj(taus[kb + j]), VBLK + (size_t)j * n);
+      lap(2);
     }
     __syncthreads();
     // The wavefront of column jj builds reflector k = p0 + jj from its registers into an LDS slot; the others
@@ -140,6 +155,7 @@ void house_slab_kernel(const tmf_slab_desc* __restrict__ desc, int w) {
       }
       __syncthreads();
     }
+    lap(3);
     if (mine) {
 #pragma unroll
       for (int i = 0; i < RMAX; ++i) {
@@ -148,6 +164,7 @@ void house_slab_kernel(const tmf_slab_desc* __restrict__ desc, int w) {
       }
     }
     __syncthreads();
+    lap(4);
   }
   // ---------------- R (c x c, zero rows beyond K), optionally as R^H ----------------
   if (R)
@@ -157,7 +174,14 @@ void house_slab_kernel(const tmf_slab_desc* __restrict__ desc, int w) {
       if (d.flags & 1) R[cc + (size_t)r * d.ldr] = sc<T>::conj(v);
       else R[r + (size_t)cc * d.ldr] = v;
     }
-  if (d.flags & 4) return;      // only R wanted: no Q at all (A is left holding the reflectors)
+  if (d.flags & 4) {            // only R wanted: no Q at all (A is left holding the reflectors)
+    if (dbg && tid == 64) {
+      for (int i = 0; i < 8; ++i) atomicAdd(&dbg[i], tacc[i]);
+      atomicAdd(&dbg[8], 1ull), atomicAdd(&dbg[9], (unsigned long long)n);
+    }
+    return;
+  }
+  lap(5);
   // ---------------- phase 2: thin Q, panel by panel, into the scratch ----------------
   for (int p0 = 0; p0 < c; p0 += w) {
     const int wp = (c - p0 < w) ? c - p0 : w;
@@ -176,9 +200,11 @@ void house_slab_kernel(const tmf_slab_desc* __restrict__ desc, int w) {
       __syncthreads();
       load_block(kb, nb);
       __syncthreads();
+      lap(1);
       if (mine)
         for (int j = nb - 1; j >= 0; --j)
           if (kb + j <= jc) apply(kb + j, taus[kb + j], VBLK + (size_t)j * n);      // H_k e_j = e_j for k > j
+      lap(6);
     }
     if (mine) {
       T* __restrict__ q = Q + (size_t)jc * ldq;
@@ -198,7 +224,238 @@ void house_slab_kernel(const tmf_slab_desc* __restrict__ desc, int w) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same factorisation for blocks whose columns ALL fit the registers of one workgroup (n <= 64 RMAX rows, c <= NW CPW
+// columns): wavefront w holds columns w, w + NW, w + 2 NW, ... for the whole factorisation, so there are no panels, no
+// reflector blocks to stream back in, and one barrier per column: the wavefront that owns column k + 1 applies reflector
+// k to it first and builds reflector k + 1 into the other LDS slot while the rest is still applying reflector k.  The dot
+// products of a wavefront's columns with the reflector are formed together and their wave reductions interleaved.
+// Made for the charge blocks of the Gutzwiller canonicalisation sweeps (~220 x 110, two dependent QRs per site:
+// gutzwiller.py:266 / :471, `npc.qr` inside TeNPy's canonical_form_finite), where the panel kernel above took 0.6 - 0.9 ms
+// per launch for at most five blocks: 5 - 7 us per column, 92 % of the projection's GPU time.
+// (A layout with a column in 16 lanes and four columns reduced by one DPP sequence was tried: per step it is bound by the
+// 4x redundant LDS reads of the reflector and by the owner's chain, 271 us against 235 us at 220 x 110.)
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int RMAX, int CPW, int NW>
+__global__ __launch_bounds__(64 * NW) void house_reg_kernel(const tmf_slab_desc* __restrict__ desc) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const tmf_slab_desc d = desc[blockIdx.x];
+  const int n = d.n, c = d.c;
+  if (n <= 0 || c <= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = n < c ? n : c;
+  constexpr int NS = 64 * RMAX;
+  T* slots = reinterpret_cast<T*>(smem);       // two reflectors of 64 RMAX entries (zeros above the diagonal, 1 on it)
+  T* taus = slots + 2 * NS;                    // K scalars
+  T* __restrict__ A = reinterpret_cast<T*>(d.A);
+  T* __restrict__ Q = reinterpret_cast<T*>(d.Q);
+  T* __restrict__ R = reinterpret_cast<T*>(d.R);
+  const size_t lda = d.lda, ldq = d.ldq;
+
+  // col[q][i]: row lane + 64 i of column wave + NW q; rows >= n and columns >= c hold zeros throughout
+  T col[CPW][RMAX];
+#pragma unroll
+  for (int q = 0; q < CPW; ++q) {
+    const int j = wave + NW * q;
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+      const int r = lane + 64 * i;
+      col[q][i] = (j < c && r < n) ? A[r + (size_t)j * lda] : sc<T>::zero();
+    }
+    __builtin_amdgcn_sched_barrier(0);      // (one column's addresses at a time: hoisted together they spill the columns)
+  }
+  // Reflector k from register column QQ of this wavefront (the column's entries above row k are final R entries):
+  // v into `slot` (all 64 RMAX entries), tau into LDS.  One wave reduction (the squared length below the diagonal); the
+  // diagonal entry comes by v_readlane, 1 / b and 1 / (alpha - beta) by v_rcp_f64 + Newton steps.
+  auto build = [&](const int k, auto qq_tag, T* __restrict__ slot) {
+    constexpr int QQ = decltype(qq_tag)::value;
+    double s_ = 0.0;
+    T al = sc<T>::zero();
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+      const int r = lane + 64 * i;
+      if (r > k) s_ += sc<T>::abs2(col[QQ][i]);
+      if ((k >> 6) == i) al = sc<T>::from2(readlane_d(sc<T>::real(col[QQ][i]), k & 63), sc<T>::cplx ? readlane_d(sc<T>::imag(col[QQ][i]), k & 63) : 0.0);
+    }
+    s_ = wave_sum64(s_);
+    const T alpha = al;
+    T tau = sc<T>::zero(), scal = sc<T>::zero(), beta = alpha;
+    if ((s_ > 0.0 || sc<T>::imag(alpha) != 0.0) && sc<T>::abs2(alpha) + s_ > 1e-290) {    // (see the panel kernel)
+      const double nn = sc<T>::abs2(alpha) + s_;
+      double rs = __builtin_amdgcn_rsq(nn);                 // 1 / sqrt(nn), two Newton steps
+      rs = rs * fma(-0.5 * nn * rs, rs, 1.5);
+      rs = rs * fma(-0.5 * nn * rs, rs, 1.5);
+      double b_ = nn * rs, binv = rs;
+      if (sc<T>::real(alpha) > 0.0) b_ = -b_, binv = -binv;
+      beta = sc<T>::from_real(b_);
+      tau = sc<T>::scale(sc<T>::sub(beta, alpha), binv);
+      scal = sc<T>::inv_fast(sc<T>::sub(alpha, beta));
+    }
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+      const int r = lane + 64 * i;
+      T v = sc<T>::zero();
+      if (r == k) v = sc<T>::one();
+      else if (r > k) v = sc<T>::mul(col[QQ][i], scal);
+      slot[r] = v;
+      if (r == k) col[QQ][i] = beta;
+      else if (r > k) col[QQ][i] = v;
+    }
+    if (lane == 0) taus[k] = tau;
+  };
+  // (I - f v v^H) on register column QQ
+  auto apply_one = [&](const T f, const T* __restrict__ v, auto qq_tag) {
+    constexpr int QQ = decltype(qq_tag)::value;
+    T dot = sc<T>::zero();
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) dot = sc<T>::fmacc(dot, v[lane + 64 * i], col[QQ][i]);
+    dot = sc<T>::mul(f, wave_sum64(dot));
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) col[QQ][i] = sc<T>::fms(col[QQ][i], dot, v[lane + 64 * i]);
+  };
+  // ... on every register column of this wavefront whose index lies in [lo, c), except column `skip`; four columns at a
+  // time: their dot products are formed together and the wave reductions interleaved (the DPP latencies overlap)
+  auto apply_range = [&](const T f, const T* __restrict__ v, const int lo, const int skip) {
+    T vr[RMAX];
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) vr[i] = v[lane + 64 * i];
+#pragma unroll
+    for (int q0 = 0; q0 < CPW; q0 += 4) {
+      if (wave + NW * (q0 + 3 < CPW ? q0 + 3 : CPW - 1) < lo) continue;      // (uniform: nothing of this group is left)
+      T dot[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        dot[u] = sc<T>::zero();
+        if (q0 + u < CPW) {
+#pragma unroll
+          for (int i = 0; i < RMAX; ++i) dot[u] = sc<T>::fmacc(dot[u], vr[i], col[q0 + u][i]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (q0 + u < CPW) {
+          const int j = wave + NW * (q0 + u);
+          dot[u] = (j >= lo && j != skip) ? sc<T>::mul(f, wave_sum64(dot[u])) : sc<T>::zero();     // (condition uniform in the wavefront)
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (q0 + u < CPW) {
+#pragma unroll
+          for (int i = 0; i < RMAX; ++i) col[q0 + u][i] = sc<T>::fms(col[q0 + u][i], dot[u], vr[i]);
+        }
+    }
+  };
+  // compile-time dispatch on the register column
+  auto with_q = [&](const int q, auto&& fn) {
+#pragma unroll
+    for (int qq = 0; qq < CPW; ++qq)
+      if (qq == q) {
+        switch (qq) {   // (integral_constant per case keeps the register index static)
+#define TMF_Q(N_) case N_: if constexpr (N_ < CPW) fn(std::integral_constant<int, N_>{}); break;
+          TMF_Q(0) TMF_Q(1) TMF_Q(2) TMF_Q(3) TMF_Q(4) TMF_Q(5) TMF_Q(6) TMF_Q(7) TMF_Q(8) TMF_Q(9) TMF_Q(10) TMF_Q(11)
+          TMF_Q(12) TMF_Q(13) TMF_Q(14) TMF_Q(15) TMF_Q(16) TMF_Q(17) TMF_Q(18) TMF_Q(19)
+#undef TMF_Q
+        }
+      }
+  };
+
+  // ---------------- phase 1 ----------------
+  if (wave == 0) build(0, std::integral_constant<int, 0>{}, slots);
+  __syncthreads();
+  for (int k = 0; k < K; ++k) {
+    const T* cur = slots + (size_t)(k & 1) * NS;
+    const T f = sc<T>::conj(taus[k]);
+    const int k1 = k + 1, q1 = k1 / NW;
+    const bool next_owner = (k1 % NW) == wave && k1 < c;
+    if (next_owner) {      // column k + 1 first, then its reflector into the other slot while the others still apply this one
+      with_q(q1, [&](auto tag) {
+        apply_one(f, cur, tag);
+        if (k1 < K) build(k1, tag, slots + (size_t)(k1 & 1) * NS);
+      });
+    }
+    apply_range(f, cur, k1, next_owner ? k1 : -1);
+    __syncthreads();
+  }
+  // ---------------- R (c x c, zero rows beyond K), optionally as R^H: straight from the registers ----------------
+  if (R) {
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) {
+      const int j = wave + NW * q;
+      if (j >= c) continue;
+#pragma unroll
+      for (int i = 0; i < RMAX; ++i) {
+        const int r = lane + 64 * i;
+        if (r >= c) continue;
+        const T v = (r <= j && r < K) ? col[q][i] : sc<T>::zero();
+        if (d.flags & 1) R[j + (size_t)r * d.ldr] = sc<T>::conj(v);
+        else R[r + (size_t)j * d.ldr] = v;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (d.flags & 4) return;      // only R wanted
+  // the reflectors go to A (below the diagonal), where phase 2 reads them one per step
+#pragma unroll
+  for (int q = 0; q < CPW; ++q) {
+    const int j = wave + NW * q;
+    if (j >= c) continue;
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+      const int r = lane + 64 * i;
+      if (r < n) A[r + (size_t)j * lda] = col[q][i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  // ---------------- phase 2: thin Q = H_0 ... H_{K-1} [1; 0], reflectors applied from the last to the first ----------------
+#pragma unroll
+  for (int q = 0; q < CPW; ++q) {
+    const int j = wave + NW * q;
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) col[q][i] = (j < c && j < K && lane + 64 * i == j) ? sc<T>::one() : sc<T>::zero();
+  }
+  auto load_v = [&](const int k, T* __restrict__ slot) {
+    for (int r = tid; r < NS; r += 64 * NW) slot[r] = (r == k) ? sc<T>::one() : ((r > k && r < n) ? A[r + (size_t)k * lda] : sc<T>::zero());
+  };
+  if (K > 0) load_v(K - 1, slots + (size_t)((K - 1) & 1) * NS);
+  __syncthreads();
+  for (int k = K - 1; k >= 0; --k) {
+    if (k > 0) load_v(k - 1, slots + (size_t)((k - 1) & 1) * NS);
+    apply_range(taus[k], slots + (size_t)(k & 1) * NS, k, -1);          // H_k e_j = e_j for j < k
+    __syncthreads();
+  }
+  T* __restrict__ dst = (d.flags & 2) ? Q : A;
+  const size_t ldd = (d.flags & 2) ? ldq : lda;
+#pragma unroll
+  for (int q = 0; q < CPW; ++q) {
+    const int j = wave + NW * q;
+    if (j >= c) continue;
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+      const int r = lane + 64 * i;
+      if (r < n) dst[r + (size_t)j * ldd] = col[q][i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 }  // namespace tmf
+
+static unsigned long long* slab_stamps() {
+  static unsigned long long* p = nullptr;
+  static bool on = getenv("TMF_SLAB_STAMPS") != nullptr;
+  if (on && !p && hipMalloc((void**)&p, 16 * 8) == hipSuccess) (void)hipMemset(p, 0, 16 * 8);
+  return on ? p : nullptr;
+}
+extern "C" int tmf_house_slab_stamps(uint64_t* out16) {
+  unsigned long long* p = slab_stamps();
+  if (!p) return TMF_E_ARG;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out16, p, 16 * 8, hipMemcpyDeviceToHost) != hipSuccess) return TMF_E_HIP;
+  (void)hipMemset(p, 0, 16 * 8);
+  return TMF_OK;
+}
 
 extern "C" int tmf_house_slab_batched(int dtype, const tmf_slab_desc* d_desc, int nprob, int max_n, int max_c, void* stream) {
   using namespace tmf;
@@ -223,8 +480,26 @@ extern "C" int tmf_house_slab_batched(int dtype, const tmf_slab_desc* d_desc, in
     attr_done = true;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // blocks whose columns all fit the registers of one workgroup: no panels, one barrier per column (house_reg_kernel)
+  static const bool use_reg = !(getenv("TMF_SLAB_REG") && atoi(getenv("TMF_SLAB_REG")) == 0);
+  if (use_reg) {
+#define TMF_REG_TRY(T, RM, CW, NW_)                                                                                         \
+    if (max_n <= 64 * RM && max_c <= NW_ * CW) {                                                                              \
+      const size_t lds_r = ((size_t)2 * 64 * RM + (size_t)max_c + 4) * elem + 64;                                             \
+      hipLaunchKernelGGL((house_reg_kernel<T, RM, CW, NW_>), dim3(nprob), dim3(64 * NW_), lds_r, s, d_desc);                  \
+      return check_hip(hipGetLastError(), "tmf_house_slab_batched (register form)");                                         \
+    }
+    // (16 wavefronts leave 128 registers per lane: RMAX x CPW <= 32 doubles next to ~60 registers of bookkeeping; forms with
+    // 8 wavefronts and twice the columns per wavefront spilled hundreds of registers, complex columns were put into scratch
+    // memory by the compiler: larger and complex blocks stay on the panel kernel)
+    if (dtype == TMF_F64) {
+      TMF_REG_TRY(double, 2, 8, 16) TMF_REG_TRY(double, 4, 7, 16) TMF_REG_TRY(double, 4, 8, 16)
+    }
+#undef TMF_REG_TRY
+  }
   const dim3 g(nprob), b(64 * w);
-#define TMF_SLAB_LAUNCH(T, RM) hipLaunchKernelGGL((house_slab_kernel<T, RM>), g, b, lds, s, d_desc, w)
+  unsigned long long* dbg = slab_stamps();
+#define TMF_SLAB_LAUNCH(T, RM) hipLaunchKernelGGL((house_slab_kernel<T, RM>), g, b, lds, s, d_desc, w, dbg)
   if (dtype == TMF_C128) {
     if (max_n <= 256) TMF_SLAB_LAUNCH(cd, 4);
     else if (max_n <= 512) TMF_SLAB_LAUNCH(cd, 8);
