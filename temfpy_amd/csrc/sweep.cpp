@@ -1058,6 +1058,28 @@ struct Sweep {
     return TMF_OK;
   }
 
+  // new column order of the left orbitals of the centre cut (empty: unchanged), see filled_stage
+  static std::vector<i64> group_order(const std::vector<double>& e, double tol) {
+    const i64 k = (i64)e.size();
+    std::vector<i64> perm(k);
+    std::iota(perm.begin(), perm.end(), 0);
+    bool moved = false;
+    for (i64 a = 0; a < k;) {
+      i64 b = a;
+      while (b + 1 < k && !(fabs(e[b + 1] - e[b]) > tol)) ++b;      // utils.py:71
+      // insertion sort by descending e (1 - e); values equal to rounding (exact multiplets) keep their order
+      for (i64 x = a + 1; x <= b; ++x)
+        for (i64 y = x; y > a; --y) {
+          const double s1 = e[perm[y]] * (1.0 - e[perm[y]]), s0 = e[perm[y - 1]] * (1.0 - e[perm[y - 1]]);
+          if (!(s1 > s0 * (1.0 + 1e-13))) break;
+          std::swap(perm[y], perm[y - 1]), moved = true;
+        }
+      a = b + 1;
+    }
+    if (!moved) perm.clear();
+    return perm;
+  }
+
   // ------------------------------------------------------------------ F: orbital matrices V = [U_E (k) | Q_f (nf)]
   std::vector<i64> ncolV;
   std::vector<u64> Vp;
@@ -1083,7 +1105,23 @@ struct Sweep {
         tmf_colnorm_desc q{};
         q.src = c.UEp[i] + (u64)(c.ent0[i] * c.ld1[i] * el), q.dst = Vp[i];
         q.n = (int32_t)c.n[i], q.c = (int32_t)c.k[i], q.lds_ = (int32_t)c.ld1[i], q.ldd = (int32_t)c.ld1[i];
-        d.push_back(q);
+        // Left orbitals of the centre cut inside a group of eigenvalues closer than degeneracy_tol: the reference takes the
+        // SVD of v_L^H C_LR v_R per group (utils.py:66-94, called at slater.py:407) and keeps e as it is.  For paired
+        // orbitals that block is diagonal with entries sqrt(e (1 - e)), so its SVD is the permutation that sorts them in
+        // descending order: orbitals that are only NEARLY degenerate change places, the right partners follow (they are
+        // computed from these columns below).
+        std::vector<i64> perm;
+        if (c.has_centre && i == c.centre_L) perm = group_order(c.e_side[i], c.par.degeneracy_tol);
+        if (perm.empty()) {
+          d.push_back(q);
+          continue;
+        }
+        q.c = 1;
+        for (i64 j = 0; j < c.k[i]; ++j) {
+          tmf_colnorm_desc qj = q;
+          qj.src = q.src + (u64)(perm[j] * c.ld1[i] * el), qj.dst = q.dst + (u64)(j * c.ld1[i] * el);
+          d.push_back(qj);
+        }
       }
       TMF_TRY(colcopy(d));
     }

@@ -1183,6 +1183,16 @@ class Engine:
         Vp = d_V.data_ptr() + oV * el
         # entangled columns (renormalised copy); centre-right: C_RL U_E(left), reversed, odd columns flipped
         cp = doE.copy()
+        perm = _group_order(e_side[centre_L], trunc.degeneracy_tol) if has_centre and doE[centre_L] else None
+        if perm is not None:
+            # left orbitals of the centre cut inside a group of eigenvalues closer than degeneracy_tol: the SVD the reference
+            # takes of v_L^H C_LR v_R per group (utils.py:66-94) sorts them by descending sqrt(e (1 - e)); e stays
+            cp[centre_L] = False
+            i_ = centre_L
+            src0 = UEp[i_] + ent0[i_] * ld1[i_] * el
+            one = np.ones(len(perm), np.int64)
+            self.colcopy(src0 + perm * ld1[i_] * el, Vp[i_] + np.arange(len(perm)) * ld1[i_] * el, n[i_] * one, one,
+                         ld1[i_] * one, ld1[i_] * one)
         self.colcopy((UEp + ent0 * ld1 * el)[cp], Vp[cp], n[cp], k[cp], ld1[cp], ld1[cp])
         if has_centre and k[centre_L] > 0 and n[centre_R] > 0:
             d_pair = self._alloc(n[centre_R] * k[centre_L])
@@ -1511,6 +1521,32 @@ class Engine:
         self._tick("download", t0)
         res.timings = dict(self.timings, total=time.perf_counter() - t_all)
         return self._finish(res)
+
+
+def _group_order(e, tol):
+    """New column order of the left orbitals of the centre cut, or None if nothing moves (sweep.cpp ``group_order``): inside
+    groups of consecutive eigenvalues not further apart than ``tol`` (utils.py:71) by descending e (1 - e); values equal to
+    rounding keep their order."""
+    e = np.asarray(e, np.float64)
+    k = len(e)
+    perm = np.arange(k)
+    moved = False
+    a = 0
+    while a < k:
+        b = a
+        while b + 1 < k and not abs(e[b + 1] - e[b]) > tol:
+            b += 1
+        for x in range(a + 1, b + 1):
+            y = x
+            while y > a:
+                s1, s0 = e[perm[y]] * (1.0 - e[perm[y]]), e[perm[y - 1]] * (1.0 - e[perm[y - 1]])
+                if not s1 > s0 * (1.0 + 1e-13):
+                    break
+                perm[y], perm[y - 1] = perm[y - 1], perm[y]
+                moved = True
+                y -= 1
+        a = b + 1
+    return perm if moved else None
 
 
 def _sector_list(trunc, L):

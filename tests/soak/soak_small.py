@@ -84,9 +84,9 @@ for seed in range(first, first + n_cases):
         # tests/test_gpu_sweep.py::test_spinful_chain_without_chi_limit_matches_oracle_tightly)
         truncated = spinful is not None and any(len(c_.lam) >= chi for c_ in cuts)
         # (degeneracy_tol: the reference pairs the orbitals of the centre cut by an SVD inside groups of eigenvalues closer than
-        # that, slater.py:400-407, i.e. it rotates orbitals that are not exactly degenerate; here the pairing is C_RL v_L without
-        # a rotation, so the two states differ by what the tolerance allows)
-        if not ties and not truncated and not events and abs(1 - ov) > max(1e-7, 10 * trunc.get("degeneracy_tol", 0.0)):
+        # that, slater.py:400-407, which reorders orbitals that are not exactly degenerate; the device path applies the same
+        # order, csrc/sweep.cpp group_order)
+        if not ties and not truncated and not events and abs(1 - ov) > 1e-9:
             raise AssertionError(f"state overlap 1 - {1 - ov:.2e}" + (f" (ties at bonds {sorted(ties)[:6]})" if ties else ""))
     except Exception as e:          # noqa: BLE001
         same = False

@@ -602,6 +602,32 @@ def test_non_default_truncation_parameters(svd_min, deg_tol):
     assert abs(1 - overlap(cuts, sites, mps, L // 2)) < 1e-9
 
 
+@pytest.mark.parametrize("driver", ["sweep", "python"])
+@pytest.mark.parametrize("L,seed,tol", [(48, 3, 1e-6), (32, 1, 1e-3), (24, 4, 1e-4)])
+def test_centre_pairing_inside_groups_of_close_eigenvalues(L, seed, tol, driver, monkeypatch):
+    """degeneracy_tol larger than the distance of eigenvalues of the centre cut (utils.py:19-96, called at slater.py:400-407):
+    the reference takes the SVD of v_L^H C_LR v_R inside each group of consecutive eigenvalues closer than the tolerance -
+    an ABSOLUTE distance, so all orbitals with 1 - e below it form one group - which reorders the orbitals by descending
+    sqrt(e (1 - e)) while e keeps its order: a different state than with the default 1e-12 (2e-7 ... 1e-3 in overlap for
+    these inputs).  The device path follows: the oracle's state to 1e-9 with the tolerance, measurably not the same
+    without it (the inputs do exercise the rule)."""
+    from tests_inputs import random_hopping
+    from temfpy_amd import slater
+    from temfpy_amd.engine import Engine
+    if driver == "python":
+        monkeypatch.setattr(Engine, "sweep_impl", "python")
+    C, _ = orc.correlation_matrix(random_hopping(L, seed))
+    wide, tight = {"chi_max": 300, "degeneracy_tol": tol}, {"chi_max": 300, "degeneracy_tol": 1e-12}
+    cuts, sites = orc.c_to_mps(C, dict(wide))
+    mps = slater.C_to_MPS(C, dict(wide), as_tenpy=False)
+    for b in range(L + 1):
+        np.testing.assert_array_equal(mps.bonds[b].sets, cuts[b].sets)
+        np.testing.assert_allclose(mps.bonds[b].e, cuts[b].e, rtol=0, atol=1e-13)
+    assert abs(1 - overlap(cuts, sites, mps, L // 2)) < 1e-9
+    other = slater.C_to_MPS(C, dict(tight), as_tenpy=False)
+    assert abs(1 - overlap(cuts, sites, other, L // 2)) > 1e-7
+
+
 @pytest.mark.parametrize("case", ["L2", "empty", "chi1", "L1", "single_particle", "two_filled"])
 def test_edge_cases_match_oracle(case):
     """Degenerate inputs the reference accepts: the smallest chains, an empty band, chi_max = 1, one
