@@ -398,6 +398,22 @@ class PfEngine(Engine):
         d_Vt = self._alloc(tV)
         Vt = d_Vt.data_ptr() + oV * el
         cp = doE.copy()
+        from .engine import _group_order
+        i_ = centre_L
+        nh_ = int(ke[i_] - kh[i_])
+        perm = _group_order(e_cut[i_][:nh_], deg_tol) if doE[i_] and nh_ > 1 else None
+        if perm is not None:
+            # left modes of the centre cut inside a group of eigenvalues closer than degeneracy_tol take the order of the
+            # reference's group SVD (block_svd on the lower modes, pfaffian.py:855; the conjugates follow, :884): lower mode j
+            # (ascending e) is column 2 ke - 1 - j, its conjugate column j
+            k2 = 2 * int(ke[i_])
+            src_col = np.arange(k2)
+            src_col[:nh_] = perm
+            src_col[k2 - 1 - np.arange(nh_)] = k2 - 1 - perm
+            one = np.ones(k2, np.int64)
+            cp[i_] = False
+            self.colcopy(UEp[i_] + src_col * ld1[i_] * el, Vt[i_] + np.arange(k2) * ld1[i_] * el, n[i_] * one, one,
+                         ld1[i_] * one, ld1[i_] * one)
         self.colcopy(UEp[cp], Vt[cp], n[cp], 2 * ke[cp], ld1[cp], ld1[cp])
         # ---- eigenvalue-1/2 modes (pfaffian.py:807-816, :867-874, :883-889) ---------------------------
         # The Ritz vectors of the degenerate 1/2 eigenspace are an arbitrary orthonormal basis; the rest of
