@@ -431,6 +431,20 @@ typedef struct {
 } tmf_colnorm_desc;          /* 40 bytes */
 int tmf_normalise_columns_batched(int dtype, const tmf_colnorm_desc* d_desc, int nprob, void* stream);
 
+/* Canonical gauge of the entangled orbitals of a cut side.  The reference takes whatever phases (and, inside an exactly
+ * degenerate group, whatever basis) LAPACK's eigh returns, slater.py:347; its own example (src/examples/iMPS.py:27-38)
+ * relies on two calls with the same matrix giving the same vectors.  Here the Ritz vectors of two sweeps differ by such a
+ * choice, so it is fixed: inside every group of columns (`start[c]` = first column of the group of column c, at most 8
+ * columns; larger groups are left alone) the basis is rotated until its overlaps with fixed pseudo-random vectors w_0,
+ * w_1, ... form a lower triangular matrix with a positive diagonal; a single column gets the phase that makes <w_0 | v>
+ * positive.  The weights are indexed by the distance of a row from the cut (from_top: row r is r sites away, else row
+ * n - 1 - r is), so the result does not depend on where the chain sits inside a larger matrix. */
+typedef struct {
+  uint64_t V, start;               /* V: n x k, leading dimension ld; start: int32[k] on the device */
+  int32_t n, k, ld, from_top;
+} tmf_gauge_desc;                  /* 32 bytes */
+int tmf_canonical_gauge_batched(int dtype, const tmf_gauge_desc* d_desc, int nprob, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Host: integer / combinatorial part of the sweep (no GPU needed)
  * ---------------------------------------------------------------------------------- */

@@ -318,22 +318,26 @@ def site_tensor(bra: Cut, ket: Cut, mode: str) -> Site:
     v_ket = ket.vL if side == "L" else ket.vR
     occ_bra, occ_ket = bra.occupations(side), ket.occupations(side)
     chi_b, n_b = occ_bra.shape
-    assert n_b + 1 == occ_ket.shape[1], "bra must be one site shorter than ket"
     dt = np.result_type(v_bra.dtype, v_ket.dtype)
-    big = np.zeros((n_b + 1, n_b + 1), dt)
-    z, o = np.zeros((chi_b, 1), bool), np.ones((chi_b, 1), bool)
-    if mode == "left":  # physical orbital appended last (slater.py:1030-1040)
-        big[:n_b, :n_b], big[n_b, n_b] = v_bra, 1
-        occ2 = np.block([[occ_bra, z], [occ_bra, o]])
-        key = occ2.sum(axis=1)
-    else:  # physical orbital first (slater.py:1041-1051)
-        big[1:, 1:], big[0, 0] = v_bra, 1
-        occ2 = np.block([[z, occ_bra], [o, occ_bra]])
-        key = -occ2.sum(axis=1)
-    perm = np.argsort(key, kind="stable")  # slater.py:1053-1058
-    occ2 = occ2[perm]
-    bra_p = (perm >= chi_b).astype(np.int64)
-    bra_alpha = perm % chi_b
+    if n_b == occ_ket.shape[1]:  # slater.py:1023-1024: two bases of the same orbitals, no physical leg, bra order kept
+        big, occ2 = v_bra, occ_bra
+        bra_p, bra_alpha = np.zeros(chi_b, np.int64), np.arange(chi_b)
+    else:
+        assert n_b + 1 == occ_ket.shape[1], "bra must be one site shorter than ket"   # slater.py:1059-1064
+        big = np.zeros((n_b + 1, n_b + 1), dt)
+        z, o = np.zeros((chi_b, 1), bool), np.ones((chi_b, 1), bool)
+        if mode == "left":  # physical orbital appended last (slater.py:1030-1040)
+            big[:n_b, :n_b], big[n_b, n_b] = v_bra, 1
+            occ2 = np.block([[occ_bra, z], [occ_bra, o]])
+            key = occ2.sum(axis=1)
+        else:  # physical orbital first (slater.py:1041-1051)
+            big[1:, 1:], big[0, 0] = v_bra, 1
+            occ2 = np.block([[z, occ_bra], [o, occ_bra]])
+            key = -occ2.sum(axis=1)
+        perm = np.argsort(key, kind="stable")  # slater.py:1053-1058
+        occ2 = occ2[perm]
+        bra_p = (perm >= chi_b).astype(np.int64)
+        bra_alpha = perm % chi_b
 
     sb, vb, kb = _classify_columns(occ2, big, mode)
     sk, vk, kk = _classify_columns(occ_ket, v_ket, mode)
@@ -409,6 +413,37 @@ def c_to_mps(C, trunc, ortho_center=None, spinful=None):
         cuts[i] = cut_vectors(C, i, trunc, "L")
         sites[i] = site_tensor(cuts[i], cuts[i + 1], "left")
     return cuts, sites
+
+
+def c_to_imps(C_short, C_long, trunc, sites_per_cell, cut):
+    """slater.py:1356-1565 (``C_to_iMPS``) without charges, offsets and TeNPy objects: the unit cell as dense B tensors
+    (2, chi_l, chi_r), its Schmidt values (sites_per_cell + 1 entries, first = last) and (left_unitary, left_schmidt).
+    Every tensor is a determinant formula between Schmidt vectors of two cuts (no environments, slater.py:1443-1446)."""
+    from . import imps_oracle
+
+    trunc = as_trunc(trunc)
+    assert len(C_short) + sites_per_cell == len(C_long)                              # slater.py:1486
+    short = cut_vectors(C_short, cut, trunc, "LR")                                   # :1499-1502
+    long_ = cut_vectors(C_long, cut, trunc, "LR")                                    # :1503-1505
+    lams = [short.lam]
+    T, ket = [], long_
+    for i in range(sites_per_cell):                                                  # :1508-1535
+        if i == sites_per_cell - 1:
+            new = short          # compare with the right environment of the short chain
+            lams.append(lams[0])
+        else:
+            new = cut_vectors(C_long, cut + i + 1, trunc, "R")
+            lams.append(new.lam)
+        s_ = site_tensor(new, ket, "right")
+        T.append(dense_site(s_, len(new.lam), len(ket.lam)))
+        ket = new
+    g = site_tensor(short, long_, "left")                                            # :1538-1539, no physical leg
+    G = np.zeros((len(short.lam), len(long_.lam)), complex)
+    for (r0, r1, c0, c1, blk) in g.blocks.values():
+        G[g.bra_alpha[r0:r1], c0:c1] = blk
+    rot, lu, ls = imps_oracle.basis_rotation(G, short.lam_raw, long_.lam_raw, "left")    # :1540-1547 (unnormalised values)
+    T[0] = np.einsum("ab,pbc->pac", rot, T[0])                                       # :1552
+    return T, lams, (lu, ls), G
 
 
 def entropies(cuts):

@@ -195,6 +195,24 @@ extern "C" int tmf_cut_vectors(const double* e, int k, int filled_left, int64_t 
     for (int b = 1; b < 130; ++b) start[b] += start[b - 1];
     for (int64_t i = 0; i < cut; ++i) ord[start[sets[i].count()]++] = i;
   }
+  // Occupation patterns of EQUAL weight (particle-hole symmetric spectra, identical spin species: sums that differ by
+  // rounding only) come out of the heap in an order set by the last bits of the eigenvalues - in the reference as well
+  // (threshold events).  Two sweeps over different matrices that contain the same cut (C_to_MPS of the
+  // short chain and C_to_iMPS, src/examples/iMPS.py:27-38) must still number them alike, so inside a charge sector runs of
+  // patterns whose sums agree to 1e-10 are put in ascending order of their masks.  TMF_TIE_ORDER=0 keeps the heap's order.
+  static const bool tie_order = !(getenv("TMF_TIE_ORDER") && atoi(getenv("TMF_TIE_ORDER")) == 0);
+  if (tie_order)
+    for (int64_t a = 0; a < cut;) {
+      int64_t b = a;
+      while (b + 1 < cut && sets[ord[b + 1]].count() == sets[ord[a]].count() &&
+             fabs(sums[ord[b + 1]] - sums[ord[b]]) <= 1e-10 * std::max(1.0, fabs(sums[ord[b]])))
+        ++b;
+      if (b > a)
+        std::sort(ord.begin() + a, ord.begin() + b + 1, [&](int64_t x, int64_t y) {
+          return sets[x].hi != sets[y].hi ? sets[x].hi < sets[y].hi : sets[x].lo < sets[y].lo;
+        });
+      a = b + 1;
+    }
   double tab[2][128];
   for (int i = 0; i < k; ++i) tab[0][i] = 1.0 - e[i], tab[1][i] = e[i];
   for (int64_t r = 0; r < cut; ++r) {
@@ -235,7 +253,8 @@ extern "C" int tmf_site_prepare(const tmf_site_in* in, const uint64_t* sets_b, c
                                 tmf_sector* sectors, int32_t sector_cap, uint8_t* idx_pool, int64_t idx_cap,
                                 tmf_site_out* out) {
   (void)q_b;
-  const bool right = in->mode == 1;
+  const bool right = (in->mode & 1) != 0;
+  const bool phys = !(in->mode & 2);   // bit 1: overlap of two bases of the SAME orbitals, no physical leg (slater.py:1023-1024)
   Side B{in->k_b, in->nf_b, in->chi_b, sets_b, right};
   Side K{in->k_k, in->nf_k, in->chi_k, sets_k, right};
   if (B.chi <= 0 || K.chi <= 0) {
@@ -300,7 +319,7 @@ extern "C" int tmf_site_prepare(const tmf_site_in* in, const uint64_t* sets_b, c
     }
   };
   std::vector<Orb> ab, sb_, ak, sk_;
-  build(B, cb, true, ab, sb_);
+  build(B, cb, phys, ab, sb_);
   build(K, ck, false, ak, sk_);
   const int kb = (int)ab.size(), kk = (int)ak.size();
   const int k = std::min(kb, kk);  // slater.py:1069
@@ -370,7 +389,7 @@ extern "C" int tmf_site_prepare(const tmf_site_in* in, const uint64_t* sets_b, c
   for (int i = 0; i < mk; ++i) col_sel[i] = cols[i].src, col_sign[i] = (int8_t)cols[i].sign;
 
   // ---- merged bra leg: (p, alpha) sorted stably by the charge to the left (slater.py:1053-1058)
-  const int nb2 = 2 * B.chi;
+  const int nb2 = phys ? 2 * B.chi : B.chi;
   std::vector<int> cnt(nb2), perm(nb2);
   for (int r = 0; r < nb2; ++r) {
     const int p = r >= B.chi, a = r % B.chi;

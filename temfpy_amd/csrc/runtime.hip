@@ -233,6 +233,124 @@ extern "C" int tmf_gather_signed_batched(int dtype, const tmf_gather_desc* d_des
   return check_hip(hipGetLastError(), "tmf_gather_signed_batched");
 }
 
+// ---- canonical gauge of the entangled orbitals (tmf_gauge_desc) --------------------------
+namespace {
+constexpr int GAUGE_DMAX = 8;
+template <typename T>
+__device__ inline T gauge_weight(int t, int j);
+template <>
+__device__ inline double gauge_weight<double>(int t, int j) {
+  const uint64_t a = splitmix(0x6A09E667F3BCC908ull ^ ((uint64_t)t << 40) ^ (uint64_t)j);
+  return (double)(int64_t)(a >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+template <>
+__device__ inline cd gauge_weight<cd>(int t, int j) {
+  const uint64_t a = splitmix(0x6A09E667F3BCC908ull ^ ((uint64_t)t << 40) ^ (uint64_t)j);
+  const uint64_t b = splitmix(a ^ 0xBB67AE8584CAA73Bull);
+  return make_cd((double)(int64_t)(a >> 11) * (2.0 / 9007199254740992.0) - 1.0,
+                 (double)(int64_t)(b >> 11) * (2.0 / 9007199254740992.0) - 1.0);
+}
+}  // namespace
+
+template <typename T>
+__global__ __launch_bounds__(256) void gauge_kernel(const tmf_gauge_desc* __restrict__ desc) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const tmf_gauge_desc d = desc[blockIdx.x];
+  const int n = d.n, k = d.k;
+  if (n <= 0 || k <= 0) return;
+  T* __restrict__ V = reinterpret_cast<T*>(d.V);
+  const int32_t* __restrict__ start = reinterpret_cast<const int32_t*>(d.start);
+  T* M = reinterpret_cast<T*>(smem);                   // [GAUGE_DMAX][k]: <w_t | v_c>, then the rotation of the group of c
+  int* size = reinterpret_cast<int*>(M + (size_t)GAUGE_DMAX * k);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < k; c += 256) {
+    const int s0 = start[c];
+    int e = c;
+    while (e < k && start[e] == s0) ++e;
+    size[c] = e - s0;
+  }
+  __syncthreads();
+  // overlaps with the weight vectors
+  for (int c = wave; c < k; c += 4) {
+    const int dsz = size[c];
+    if (dsz > GAUGE_DMAX) continue;
+    T acc[GAUGE_DMAX];
+#pragma unroll
+    for (int t = 0; t < GAUGE_DMAX; ++t) acc[t] = sc<T>::zero();
+    for (int r = lane; r < n; r += 64) {
+      const T v = V[r + (size_t)c * d.ld];
+      const int j = d.from_top ? r : n - 1 - r;
+#pragma unroll
+      for (int t = 0; t < GAUGE_DMAX; ++t)
+        if (t < dsz) acc[t] = sc<T>::fmacc(acc[t], gauge_weight<T>(t, j), v);
+    }
+#pragma unroll
+    for (int t = 0; t < GAUGE_DMAX; ++t) {
+      if (t >= dsz) continue;                          // (uniform)
+      const T sum = wave_sum64(acc[t]);
+      if (lane == 0) M[(size_t)t * k + c] = sum;
+    }
+  }
+  __syncthreads();
+  // one thread per group: Q = orthonormal factor of B^H (B = the group's d x d block of M), so that B Q is lower
+  // triangular with a positive diagonal; Q overwrites the block (Q[c][s] at M[c - s0][s0 + s] ... stored column-wise)
+  for (int c = tid; c < k; c += 256) {
+    const int s0 = start[c], dsz = size[c];
+    if (c != s0 || dsz > GAUGE_DMAX) continue;
+    T q[GAUGE_DMAX][GAUGE_DMAX];                       // q[s][i]: component i of vector s
+    for (int s = 0; s < dsz; ++s) {
+      for (int i = 0; i < dsz; ++i) q[s][i] = sc<T>::conj(M[(size_t)s * k + s0 + i]);      // b_s = conj(row s of B)
+      for (int pass = 0; pass < 2; ++pass)
+        for (int p = 0; p < s; ++p) {
+          T dot = sc<T>::zero();
+          for (int i = 0; i < dsz; ++i) dot = sc<T>::fmacc(dot, q[p][i], q[s][i]);          // <q_p | b_s>
+          for (int i = 0; i < dsz; ++i) q[s][i] = sc<T>::fms(q[s][i], dot, q[p][i]);
+        }
+      double nn = 0.0;
+      for (int i = 0; i < dsz; ++i) nn += sc<T>::abs2(q[s][i]);
+      if (!(nn > 1e-280)) {                            // (no direction left: keep the basis of this group)
+        for (int a = 0; a < dsz; ++a)
+          for (int i = 0; i < dsz; ++i) q[a][i] = (a == i) ? sc<T>::one() : sc<T>::zero();
+        break;
+      }
+      const double inv = 1.0 / sqrt(nn);
+      for (int i = 0; i < dsz; ++i) q[s][i] = sc<T>::scale(q[s][i], inv);
+    }
+    for (int s = 0; s < dsz; ++s)
+      for (int i = 0; i < dsz; ++i) M[(size_t)i * k + s0 + s] = q[s][i];                     // Q[i][s]
+  }
+  __syncthreads();
+  // V_group <- V_group Q
+  for (int r = tid; r < n; r += 256) {
+    for (int c = 0; c < k;) {
+      const int dsz = size[c];
+      if (dsz <= GAUGE_DMAX) {
+        T v[GAUGE_DMAX], o[GAUGE_DMAX];
+        for (int i = 0; i < dsz; ++i) v[i] = V[r + (size_t)(c + i) * d.ld], o[i] = sc<T>::zero();
+        for (int s = 0; s < dsz; ++s)
+          for (int i = 0; i < dsz; ++i) o[s] = sc<T>::add(o[s], sc<T>::mul(v[i], M[(size_t)i * k + c + s]));
+        for (int s = 0; s < dsz; ++s) V[r + (size_t)(c + s) * d.ld] = o[s];
+      }
+      c += dsz;
+    }
+  }
+}
+
+extern "C" int tmf_canonical_gauge_batched(int dtype, const tmf_gauge_desc* d_desc, int nprob, void* stream) {
+  if (nprob <= 0) return TMF_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t lds = (size_t)GAUGE_DMAX * 256 * 16 + 256 * 4;       // k <= 255 entangled orbitals
+  if (dtype == TMF_C128)
+    hipLaunchKernelGGL(gauge_kernel<cd>, dim3(nprob), dim3(256), lds, s, d_desc);
+  else if (dtype == TMF_F64)
+    hipLaunchKernelGGL(gauge_kernel<double>, dim3(nprob), dim3(256), lds, s, d_desc);
+  else {
+    set_error("tmf_canonical_gauge_batched: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+  return check_hip(hipGetLastError(), "tmf_canonical_gauge_batched");
+}
+
 extern "C" int tmf_normalise_columns_batched(int dtype, const tmf_colnorm_desc* d_desc, int nprob, void* stream) {
   if (nprob <= 0) return TMF_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);

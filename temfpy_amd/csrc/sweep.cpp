@@ -1058,6 +1058,7 @@ struct Sweep {
     return TMF_OK;
   }
 
+  static constexpr double GAUGE_GROUP_TOL = 1e-9;   // eigenvalues closer than this form one group of the canonical gauge
   // new column order of the left orbitals of the centre cut (empty: unchanged), see filled_stage
   static std::vector<i64> group_order(const std::vector<double>& e, double tol) {
     const i64 k = (i64)e.size();
@@ -1098,6 +1099,31 @@ struct Sweep {
     u64 d_V;
     TMF_TRY(alloc_el(tV, &d_V));
     for (i64 i = 0; i < ncs; ++i) Vp[i] = d_V + (u64)(oV[i] * el);
+    {  // canonical gauge of the entangled Ritz vectors (tmf_gauge_desc): phases, and the basis inside groups of eigenvalues
+       // that C does not tell apart, do not depend on the sweep that computed them
+      std::vector<tmf_gauge_desc> gd;
+      for (i64 i = 0; i < ncs; ++i) {
+        if (!c.doE[i] || c.k[i] <= 0) continue;
+        std::vector<int32_t> start((size_t)c.k[i]);
+        const std::vector<double>& e = c.e_side[i];
+        for (i64 j = 0; j < c.k[i]; ++j) {
+          // (a group = eigenvalues C does not tell apart: rounding noise, or 1e-9 of their distance from 0 / 1)
+          const double w = j > 0 ? std::min(std::min(e[(size_t)j], 1.0 - e[(size_t)j]), std::min(e[(size_t)j - 1], 1.0 - e[(size_t)j - 1])) : 0.0;
+          start[(size_t)j] = (j > 0 && !(fabs(e[(size_t)j] - e[(size_t)j - 1]) > 1e-14 + GAUGE_GROUP_TOL * w)) ? start[(size_t)j - 1] : (int32_t)j;
+        }
+        tmf_gauge_desc q{};
+        TMF_TRY(up_vec(start, &q.start));
+        q.V = c.UEp[i] + (u64)(c.ent0[i] * c.ld1[i] * el);
+        q.n = (int32_t)c.n[i], q.k = (int32_t)c.k[i], q.ld = (int32_t)c.ld1[i], q.from_top = c.cs_side[i] == 1 ? 1 : 0;
+        gd.push_back(q);
+      }
+      if (!gd.empty()) {
+        u64 dd;
+        TMF_TRY(up_vec(gd, &dd));
+        const int nd_ = (int)gd.size();
+        LATER(tmf_canonical_gauge_batched(c.dtype, (const tmf_gauge_desc*)dd, nd_, c.s_main));
+      }
+    }
     {  // entangled columns (renormalised copy)
       std::vector<tmf_colnorm_desc> d;
       for (i64 i = 0; i < ncs; ++i) {

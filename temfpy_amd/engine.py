@@ -627,7 +627,7 @@ class Engine:
             nat.check(self.lib.tmf_fill_normal(self.dtype, d_Om.data_ptr(), L * P, 0x5EED1, self.stream), "fill")
             omp = d_Om.data_ptr() + np.where(side == 0, x, 0) * el      # rows of Omega on the other side
             p = np.where(doE, np.minimum(P, np.minimum(n, m)), 0)
-            nest = (x, side, Cp, d_Om.data_ptr())
+            nest = None if Cp is None else (x, side, Cp, d_Om.data_ptr())   # (None: cut sides of several matrices)
             full = doE & (p == P) & (P < np.minimum(n, m))              # cuts the range finder truncates
             st = self.entangled_stage(L, n, m, blk, off, omp, doE, p, thr2, P, iterations=0, nest=nest)
             w_, (h_sig, h_cnt, h_e, h_sw) = self._fetch_async([st["d_sig"], st["d_cnt"], st["d_e"], self._sweeps_tensor()])
@@ -940,7 +940,7 @@ class Engine:
         return p.value, n.value
 
     def run_gen(self, C, trunc, ortho_center, unit_cell_width, threads=None, download=True, site_range=None,
-                diag=None, presynced=False, sink=None):
+                diag=None, presynced=False, sink=None, second=None):
         """One C -> MPS conversion as a generator: yields a wait handle (``ready()`` / ``block()``) at the
         three places where the host has to wait - eigenvalues coming down, the enumeration thread, the
         final results - so that several site ranges can be interleaved (:func:`run_pipelined`).
@@ -954,6 +954,12 @@ class Engine:
         sink         where the host copy of the result lives (default: page-locked memory; the multi-GPU path
                      passes shared-memory segments, multi_gpu.ShmSink)
         site_range   (a, b): only sites a <= i < b and the cuts next to them (one rank's shard)
+        second       a second chain in the same sweep and tensors between cuts of the two (``slater.C_to_iMPS``,
+                     slater.py:1499-1553): ``{"C": (L, L) matrix, "oc": its centre cut, "cross": [...]}``.  A cross site is
+                     ``dict(mode=0|1, phys=bool, bra=(chain, cut), ket=(chain, cut), skip=rows of the bra block that come
+                     before the orbitals it shares with the ket)``; they follow the regular sites in the result (site
+                     numbers s_hi, s_hi + 1, ...), cuts of chain 1 have the bond numbers L + 1 + cut.  ``site_range`` may
+                     then be empty
         """
         torch = self.torch
         t_all = time.perf_counter()
@@ -993,40 +999,67 @@ class Engine:
         d_C = self._alloc(L * L)
         nat.check(self.lib.tmf_transpose(self.dtype, d_Crm.data_ptr(), d_C.data_ptr(), L, self.stream), "tmf_transpose")
         Cp = d_C.data_ptr()
+        Cps, diags, ocs = [Cp], [diag], [oc]
+        cross = []
+        if second is not None:
+            C2 = np.ascontiguousarray(second["C"], np.complex128 if cplx else np.float64)
+            assert C2.shape == (L, L), "the second chain is embedded in a matrix of the same size"
+            d_C2rm = torch.from_numpy(C2.reshape(-1)).to(self.device)
+            d_C2 = self._alloc(L * L)
+            nat.check(self.lib.tmf_transpose(self.dtype, d_C2rm.data_ptr(), d_C2.data_ptr(), L, self.stream), "tmf_transpose")
+            Cps.append(d_C2.data_ptr()), diags.append(np.real(np.diagonal(C2)).astype(np.float64)), ocs.append(int(second["oc"]))
+            cross = list(second["cross"])
+        KEY = L + 1                                   # bond number of cut b of chain c: c * KEY + b
         self._tick("upload", t0)
 
         # ---- cut-side problems --------------------------------------------------------------
-        need = set()
+        need = set()                                  # (chain, cut, side)
         for i in range(s_lo, s_hi):
             sd_ = 0 if i < oc else 1
-            need.add((i, sd_)), need.add((i + 1, sd_))
-        if (oc, 1) in need or (s_lo <= oc <= s_hi):
-            need.add((oc, 0)), need.add((oc, 1))  # the centre's right orbitals are paired with its left ones
-        cs_b, cs_side = [], []
-        for b in range(L + 1):
-            for sd_ in (0, 1):
-                if (b, sd_) in need:
-                    cs_b.append(b), cs_side.append(sd_)
-        cs_b, cs_side = np.array(cs_b), np.array(cs_side)
+            need.add((0, i, sd_)), need.add((0, i + 1, sd_))
+        for x_ in cross:
+            sd_ = int(x_["mode"]) & 1
+            need.add((x_["bra"][0], x_["bra"][1], sd_)), need.add((x_["ket"][0], x_["ket"][1], sd_))
+        for c_, oc_ in enumerate(ocs):
+            if (c_, oc_, 1) in need or (c_, oc_, 0) in need or (c_ == 0 and s_lo < s_hi and s_lo <= oc_ <= s_hi):
+                need.add((c_, oc_, 0)), need.add((c_, oc_, 1))  # the centre's right orbitals are paired with its left ones
+        trip = sorted(need)
+        cs_mat = np.array([t_[0] for t_ in trip], np.int64)
+        cs_b = np.array([t_[1] for t_ in trip], np.int64)
+        cs_side = np.array([t_[2] for t_ in trip], np.int64)
+        cs_key = cs_mat * KEY + cs_b
         ncs = len(cs_b)
         n = np.where(cs_side == 0, cs_b, L - cs_b)
         m = L - n
-        blk = Cp + np.where(cs_side == 0, 0, (cs_b + cs_b * L)) * el      # A = C_LL or C_RR
-        off = Cp + np.where(cs_side == 0, cs_b * L, cs_b) * el            # F (n x m)
-        has_centre = (oc, 0) in need
-        centre_R = np.nonzero((cs_b == oc) & (cs_side == 1))[0][0] if has_centre else -1
-        centre_L = np.nonzero((cs_b == oc) & (cs_side == 0))[0][0] if has_centre else -1
-        # the right side of the centre cut is paired with the left side through C_RL (block_svd, slater.py:407)
+        Cbase = np.array(Cps, np.int64)[cs_mat]
+        blk = Cbase + np.where(cs_side == 0, 0, (cs_b + cs_b * L)) * el      # A = C_LL or C_RR
+        off = Cbase + np.where(cs_side == 0, cs_b * L, cs_b) * el            # F (n x m)
+        # the right side of a centre cut is paired with the left side through C_RL (block_svd, slater.py:407)
         doE = (n > 0) & (m > 0)
-        if has_centre:
-            doE[centre_R] = False
+        centres = []                                  # (left problem, right problem) of every chain's centre cut
+        for c_, oc_ in enumerate(ocs):
+            if (c_, oc_, 0) in need:
+                cl_ = int(np.nonzero((cs_mat == c_) & (cs_b == oc_) & (cs_side == 0))[0][0])
+                cr_ = int(np.nonzero((cs_mat == c_) & (cs_b == oc_) & (cs_side == 1))[0][0])
+                centres.append((cl_, cr_))
+                doE[cr_] = False
+        has_centre = bool(centres)
+        centre_L, centre_R = centres[0] if centres else (-1, -1)
+        # sites: the regular ones of chain 0, then the cross sites; mode bit 1 = no physical leg
+        st_mode = [0 if i < oc else 1 for i in range(s_lo, s_hi)] + [int(x_["mode"]) & 1 for x_ in cross]
+        st_phys = [True] * (s_hi - s_lo) + [bool(x_["phys"]) for x_ in cross]
+        st_bkey = [(i if i < oc else i + 1) for i in range(s_lo, s_hi)] + [x_["bra"][0] * KEY + x_["bra"][1] for x_ in cross]
+        st_kkey = [(i + 1 if i < oc else i) for i in range(s_lo, s_hi)] + [x_["ket"][0] * KEY + x_["ket"][1] for x_ in cross]
+        st_skip = [0] * (s_hi - s_lo) + [int(x_.get("skip", 0)) for x_ in cross]
+        st_mode, st_phys, st_bkey, st_kkey, st_skip = (np.array(v, np.int64) for v in (st_mode, st_phys, st_bkey, st_kkey, st_skip))
 
         def offsets(sizes):
             o = np.concatenate(([0], np.cumsum(sizes)))
             return o[:-1], int(o[-1])
 
         t0 = time.perf_counter()
-        st = yield from self.entangled_stage_adaptive_gen(L, n, m, blk, off, doE, thr2, cs_b, cs_b, cs_side, Cp)
+        st = yield from self.entangled_stage_adaptive_gen(L, n, m, blk, off, doE, thr2, cs_b, cs_b, cs_side,
+                                                          Cp if second is None else None)
         P, p = st["P"], st["p"]
         UEp, oS, ld1 = st["UEp"], st["oS"], st["ld1"]
         self._tick("E_entangled", t0)
@@ -1034,9 +1067,10 @@ class Engine:
         # ---- host round trip 1: eigenvalues -> classification, filled counts ------------------
         t0 = time.perf_counter()
         h_e, h_cnt = st["h_e"], st["h_cnt"]
-        csum = np.concatenate(([0.0], np.cumsum(diag)))
-        n_fermion = int(np.round(csum[-1]))  # slater.py:414
-        tr = np.where(cs_side == 0, csum[cs_b], csum[-1] - csum[cs_b])
+        csums = np.stack([np.concatenate(([0.0], np.cumsum(d_))) for d_ in diags])
+        n_fermions = np.round(csums[:, -1]).astype(np.int64)  # slater.py:414
+        n_fermion = int(n_fermions[0])
+        tr = np.where(cs_side == 0, csums[cs_mat, cs_b], csums[cs_mat, -1] - csums[cs_mat, cs_b])
         # kept Ritz values per cut side as a padded 2-D array (descending inside each row)
         colP = np.arange(P)
         valid = colP[None, :] < h_cnt[:, None]
@@ -1048,10 +1082,10 @@ class Engine:
         e_side = [E2[i, a_: b_] for i, (a_, b_) in enumerate(zip(ent0.tolist(), (ent0 + k).tolist()))]  # views
         esum = np.where((colP[None, :] >= ent0[:, None]) & (colP[None, :] < (ent0 + k)[:, None]), E2, 0.0).sum(axis=1)
         # centre: right-side eigenvalues are 1 - e_L reversed (slater.py:386 convention)
-        if has_centre:
-            k[centre_R] = k[centre_L]
-            e_side[centre_R] = (1.0 - e_side[centre_L])[::-1].copy()
-            esum[centre_R] = e_side[centre_R].sum()
+        for cl_, cr_ in centres:
+            k[cr_] = k[cl_]
+            e_side[cr_] = (1.0 - e_side[cl_])[::-1].copy()
+            esum[cr_] = e_side[cr_].sum()
         nf = np.clip(np.round(tr - esum).astype(np.int64), 0, n - k)
         self._tick("host_classify", t0)
 
@@ -1060,18 +1094,19 @@ class Engine:
             t0 = time.perf_counter()
             sectors = _sector_list(trunc, L)
             # lookup tables: cut-side problem of (cut, side), position of a cut in this rank's list (-1 = absent)
-            side_idx = np.full((L + 1, 2), -1, np.int64)
-            side_idx[cs_b, cs_side] = np.arange(ncs)
-            my_cuts = np.unique(cs_b)
+            nkey = KEY * len(Cps)
+            side_idx = np.full((nkey, 2), -1, np.int64)
+            side_idx[cs_key, cs_side] = np.arange(ncs)
+            my_cuts = np.unique(cs_key)
             ncut = len(my_cuts)
-            cpos = np.full(L + 1, -1, np.int64)
+            cpos = np.full(nkey, -1, np.int64)
             cpos[my_cuts] = np.arange(ncut)
             iL, iR = side_idx[my_cuts, 0], side_idx[my_cuts, 1]
             hasL, hasR = iL >= 0, iR >= 0
             src = np.where(hasL, iL, iR)                       # the side whose eigenvalues define e_left
             kk_cut = k[src].astype(np.int32)
             nf_src = nf[src]
-            other = n_fermion - kk_cut - nf_src                # slater.py:167 / :172
+            other = n_fermions[my_cuts // KEY] - kk_cut - nf_src   # slater.py:167 / :172
             nfl = np.where(hasL, nf_src, np.where(hasR, other, 0)).astype(np.int32)
             nfr = np.where(hasL, np.where(hasR, nf[np.maximum(iR, 0)], other), nf_src).astype(np.int32)
             # left eigenvalues of every cut, flat: from the left block as they are, from the right block as
@@ -1119,16 +1154,15 @@ class Engine:
 
             # ---- host: per-site integer preparation (one threaded C++ call) --------------------------
             t0 = time.perf_counter()
-            my_sites = np.arange(s_lo, s_hi)
-            ns = len(my_sites)
-            mode = (my_sites >= oc).astype(np.int32)
-            bb = np.where(mode == 0, my_sites, my_sites + 1)
-            kb_ = np.where(mode == 0, my_sites + 1, my_sites)
+            ns = len(st_mode)
+            my_sites = s_lo + np.arange(ns)
+            mode = st_mode.astype(np.int32)
+            bb, kb_ = st_bkey, st_kkey
             ib, ik = side_idx[bb, mode], side_idx[kb_, mode]
             cb_i, ck_i = cpos[bb], cpos[kb_]
             chi_b, chi_k = c_chi[cb_i], c_chi[ck_i]
             jobs = np.zeros(ns, nat.site_job)
-            jobs["mode"], jobs["cut_b"], jobs["cut_k"] = mode, cb_i, ck_i
+            jobs["mode"], jobs["cut_b"], jobs["cut_k"] = mode | np.where(st_phys != 0, 0, 2).astype(np.int32), cb_i, ck_i
             jobs["k_b"], jobs["nf_b"], jobs["k_k"], jobs["nf_k"] = k[ib], nf[ib], k[ik], nf[ik]
             mb_cap = k[ib] + nf[ib] + 1
             mk_cap = np.maximum(k[ik] + nf[ik], 1)
@@ -1182,19 +1216,43 @@ class Engine:
         d_V = self._alloc(tV)
         Vp = d_V.data_ptr() + oV * el
         # entangled columns (renormalised copy); centre-right: C_RL U_E(left), reversed, odd columns flipped
+        # canonical gauge of the entangled Ritz vectors (tmf_gauge_desc; csrc/sweep.cpp filled_stage)
+        gsel = np.nonzero(doE & (k > 0))[0]
+        if gsel.size:
+            gdesc = np.zeros(gsel.size, nat.gauge_desc)
+            starts = []
+            for t_, i_ in enumerate(gsel):
+                e_ = np.asarray(e_side[i_], np.float64)
+                st_ = np.arange(len(e_), dtype=np.int32)
+                for j_ in range(1, len(e_)):
+                    w_ = min(min(e_[j_], 1.0 - e_[j_]), min(e_[j_ - 1], 1.0 - e_[j_ - 1]))
+                    if not abs(e_[j_] - e_[j_ - 1]) > 1e-14 + 1e-9 * w_:
+                        st_[j_] = st_[j_ - 1]
+                starts.append(st_)
+            t_st = self._up(np.concatenate(starts))
+            so_ = np.concatenate(([0], np.cumsum([len(x_) for x_ in starts])))[:-1]
+            gdesc["V"] = (UEp + ent0 * ld1 * el)[gsel]
+            gdesc["start"] = t_st.data_ptr() + so_ * 4
+            gdesc["n"], gdesc["k"], gdesc["ld"], gdesc["from_top"] = n[gsel], k[gsel], ld1[gsel], (cs_side[gsel] == 1)
+            t_gd = self._up(gdesc)
+            nat.check(self.lib.tmf_canonical_gauge_batched(self.dtype, t_gd.data_ptr(), int(gsel.size), self.stream),
+                      "tmf_canonical_gauge_batched")
         cp = doE.copy()
-        perm = _group_order(e_side[centre_L], trunc.degeneracy_tol) if has_centre and doE[centre_L] else None
-        if perm is not None:
-            # left orbitals of the centre cut inside a group of eigenvalues closer than degeneracy_tol: the SVD the reference
-            # takes of v_L^H C_LR v_R per group (utils.py:66-94) sorts them by descending sqrt(e (1 - e)); e stays
-            cp[centre_L] = False
-            i_ = centre_L
-            src0 = UEp[i_] + ent0[i_] * ld1[i_] * el
-            one = np.ones(len(perm), np.int64)
-            self.colcopy(src0 + perm * ld1[i_] * el, Vp[i_] + np.arange(len(perm)) * ld1[i_] * el, n[i_] * one, one,
-                         ld1[i_] * one, ld1[i_] * one)
+        for centre_L, centre_R in centres:
+            perm = _group_order(e_side[centre_L], trunc.degeneracy_tol) if doE[centre_L] else None
+            if perm is not None:
+                # left orbitals of the centre cut inside a group of eigenvalues closer than degeneracy_tol: the SVD the
+                # reference takes of v_L^H C_LR v_R per group (utils.py:66-94) sorts them by descending sqrt(e (1 - e)); e stays
+                cp[centre_L] = False
+                i_ = centre_L
+                src0 = UEp[i_] + ent0[i_] * ld1[i_] * el
+                one = np.ones(len(perm), np.int64)
+                self.colcopy(src0 + perm * ld1[i_] * el, Vp[i_] + np.arange(len(perm)) * ld1[i_] * el, n[i_] * one, one,
+                             ld1[i_] * one, ld1[i_] * one)
         self.colcopy((UEp + ent0 * ld1 * el)[cp], Vp[cp], n[cp], k[cp], ld1[cp], ld1[cp])
-        if has_centre and k[centre_L] > 0 and n[centre_R] > 0:
+        for centre_L, centre_R in centres:
+            if not (k[centre_L] > 0 and n[centre_R] > 0):
+                continue
             d_pair = self._alloc(n[centre_R] * k[centre_L])
             self.gemm(0, 1.0, 0.0, [off[centre_R]], [Vp[centre_L]], [d_pair.data_ptr()], [n[centre_R]], [k[centre_L]],
                       [m[centre_R]], [L], [ld1[centre_L]], [ld1[centre_R]])
@@ -1220,6 +1278,7 @@ class Engine:
                        np.array([d_scrc.data_ptr()]))
             self.gemm(0, 1.0, 0.0, [d_T.data_ptr()], [t_S.data_ptr()], [Vp[centre_R]], [nR], [kc], [kc], [ldR], [kc],
                       [ldR])
+        centre_L, centre_R = centres[0] if centres else (-1, -1)
         # filled: Y = A Omega_f, projected off U_E and orthonormalised below
         maxnf = int(nf.max()) if ncs else 0
         if maxnf > 0:
@@ -1228,7 +1287,10 @@ class Engine:
             Vf = Vp + k * ld1 * el
             # one multiplication by A: the filled space has eigenvalue >= 1 - 1e-12, everything that is
             # not projected off with U_E below has eigenvalue <= 1e-12 (the reference's own cutoff)
-            self.nested_products("A", L, Cp, d_OmF.data_ptr(), L, cs_b, cs_side, Vf, nf, ld1)
+            if second is None:
+                self.nested_products("A", L, Cp, d_OmF.data_ptr(), L, cs_b, cs_side, Vf, nf, ld1)
+            else:     # (two matrices: plain products, rows of Omega by global index as in the nested form)
+                self.gemm(0, 1.0, 0.0, blk, d_OmF.data_ptr() + np.where(cs_side == 1, cs_b, 0) * el, Vf, n, nf, n, L, L, ld1)
             d_scr2 = self._alloc(int((ncolV.max() + 1) * PANEL_W) * ncs)
             scr2 = d_scr2.data_ptr() + np.arange(ncs) * int((ncolV.max() + 1) * PANEL_W) * el
             has = nf > 0
@@ -1240,15 +1302,17 @@ class Engine:
                        passes=self.filled_passes)
         # self-check of the centre cut (testing.py:131-177; slater.py:419-420 runs it only there)
         chk_names, d_chk = [], None
-        if self.checks and has_centre and doE[centre_L]:
-            iL, iR = centre_L, centre_R
+        items = []
+        for iL, iR in (centres if self.checks else []):
+            if not doE[iL]:
+                continue
             qL, qR, kc = int(ncolV[iL]), int(ncolV[iR]), int(k[iL])
             wL = np.concatenate((e_side[iL], np.ones(int(nf[iL]))))
             wR = np.concatenate((e_side[iR], np.ones(int(nf[iR]))))
             eL = e_side[iL]
             sv = np.sqrt(eL * (1.0 - eL)) * (-1.0) ** (np.arange(kc)[::-1])  # slater.py:266-268
             mk = lambda **kw: kw  # noqa: E731
-            items = [
+            items += [
                 mk(T=0, X=Vp[iL], Y=Vp[iL], w=None, rows=qL, cols=qL, q=0, inner=int(n[iL]), ldx=int(ld1[iL]),
                    ldy=int(ld1[iL]), mode=1),
                 mk(T=blk[iL], X=Vp[iL], Y=Vp[iL], w=wL, rows=int(n[iL]), cols=int(n[iL]), q=qL, ldt=L,
@@ -1260,27 +1324,30 @@ class Engine:
                 mk(T=off[iL], X=Vp[iL], Y=Vp[iR], w=sv, rows=int(n[iL]), cols=int(n[iR]), q=kc, ldt=L,
                    ldx=int(ld1[iL]), ldy=int(ld1[iR]), mode=0, y_reverse=1),
             ]
+        if items:
             chk_names = ["vL is not unitary", "vL does not diagonalise C_LL", "vR is not unitary",
                          "vR does not diagonalise C_RR", "vL and vR do not SVD C_LR"]
+            if len(items) > 5:    # (second chain: the same five deviations of its centre cut)
+                chk_names = chk_names + [nm + " (second chain)" for nm in chk_names]
             d_chk = self.recon_errors(items)
         self._tick("F_filled", t0)
 
         # ---- S1 ahead of the host results: O = V_bra^H V_ket needs the orbital matrices only ---------
         t0 = time.perf_counter()
-        e_sites = np.arange(s_lo, s_hi)
-        e_mode = (e_sites >= oc).astype(np.int64)
-        e_sidx = np.full((L + 1, 2), -1, np.int64)
-        e_sidx[cs_b, cs_side] = np.arange(ncs)
-        e_ib = e_sidx[np.where(e_mode == 0, e_sites, e_sites + 1), e_mode]
-        e_ik = e_sidx[np.where(e_mode == 0, e_sites + 1, e_sites), e_mode]
+        e_mode = st_mode
+        e_sidx = np.full((KEY * len(Cps), 2), -1, np.int64)
+        e_sidx[cs_key, cs_side] = np.arange(ncs)
+        e_ib = e_sidx[st_bkey, e_mode]
+        e_ik = e_sidx[st_kkey, e_mode]
         cb, ck = ncolV[e_ib], ncolV[e_ik]           # columns of V_bra / V_ket
-        nb_rows = n[e_ib]                            # contraction length = bra orbitals
+        nb_rows = n[e_ib] - st_skip                  # contraction length = bra orbitals (shared with the ket)
         oO, tO = offsets(cb * ck)
         d_O = self._alloc(tO)
         Op = d_O.data_ptr() + oO * el
-        Vk_sub = Vp[e_ik] + np.where(e_mode == 1, 1, 0) * el     # right mode: physical orbital is row 0 of the ket block
+        # right mode: the physical orbital is row 0 of the ket block (none between two bases of the same orbitals)
+        Vk_sub = Vp[e_ik] + np.where((e_mode == 1) & (st_phys != 0), 1, 0) * el
         physp = Vp[e_ik] + np.where(e_mode == 1, 0, nb_rows) * el
-        self.gemm(1, 1.0, 0.0, Vp[e_ib], Vk_sub, Op, cb, ck, nb_rows, ld1[e_ib], ld1[e_ik], np.maximum(cb, 1))
+        self.gemm(1, 1.0, 0.0, Vp[e_ib] + st_skip * el, Vk_sub, Op, cb, ck, nb_rows, ld1[e_ib], ld1[e_ik], np.maximum(cb, 1))
         self._tick("S_overlap_gemm", t0)
 
         yield _ThreadWait(th)
@@ -1457,8 +1524,8 @@ class Engine:
         spec["out"] = (cdt, (int(out_tot) if want_out else 0,))
         entries, total = ShardArrays.plan(spec)
         buf, keep = (sink or self.default_sink()).alloc(total)
-        shard = ShardArrays.create(buf, entries, dict(L=int(L_all), s_lo=int(s_lo), s_hi=int(s_hi), ortho_center=int(oc),
-                                                      complex=bool(cplx)), keepalive=keep)
+        shard = ShardArrays.create(buf, entries, dict(L=int(KEY * len(Cps) - 1), s_lo=int(s_lo), s_hi=int(s_lo + ns),
+                                                      ortho_center=int(oc), complex=bool(cplx)), keepalive=keep)
         for k_, v_ in src.items():
             shard.arrays[k_][...] = v_
         self._tick("host_bonds", t0)

@@ -579,6 +579,80 @@ def MPS_to_iMPS(mps_short, mps_long, sites_per_cell: int, cut: int, unitary_tol:
     return res, iMPSError(left_unitary, left_schmidt, right_unitary, right_schmidt)
 
 
+def cell_from_determinants(shard, L_long: int, cut: int, sites_per_cell: int, offset: int, unit_cell_width: int, *,
+                           unitary_tol: float = _UNITARY_TOL, schmidt_tol: float = _SCHMIDT_TOL, device: str = "cuda:0"):
+    """Unit cell of ``slater.C_to_iMPS`` the reference's way (slater.py:1499-1563) from ONE sweep over the cuts
+    ``cut .. cut + sites_per_cell - 1`` of the long chain and the cut of the short chain (``Engine.run_gen(..., second=...)``):
+    right-canonical tensors of the long chain, the last one with the right Schmidt vectors of the SHORT chain as bra
+    (:1513-1514), and on the first one the Procrustes rotation of the overlaps of the left Schmidt vectors, which are
+    determinants between two bases of the same orbitals - no physical leg (:1538-1553, :1023-1024).  No environments, no
+    full conversion of either chain.  Returns (iMPSData, iMPSError) with zero right-hand errors (:1563)."""
+    KEY = L_long + 1
+    n_reg = sites_per_cell - 1
+    b_short = shard.bond(KEY + cut + sites_per_cell)                     # cut of the short chain (embedded, see C_to_iMPS)
+    b_long = [shard.bond(cut + i) for i in range(sites_per_cell)]
+    bonds = [b_short] + b_long[1:] + [b_short]                            # slater.py:1502, :1515, :1520
+    lam = [np.array(b.lam) for b in bonds]
+    q_b = [np.asarray(b.q_left, np.int64) for b in bonds]
+    n_of = lambda b: int(b.n_filled_left + b.n_filled_right + len(b.e))   # noqa: E731
+    dq = n_of(b_long[0]) - n_of(b_short)                                  # particles per unit cell (qtotal of the last tensor, :1092)
+    site0 = int(shard.meta["s_lo"])
+    sds = [shard.site(site0 + j) for j in range(n_reg + 2)]              # regular sites, last tensor, gauge overlaps
+    gauge = sds[-1]
+
+    def right_blocks(sd, q_l, q_r):
+        """(p, q_l, q_r, l0, l1, r0, r1, (n_l x n_r) array) of a right-mode site: rows of its blocks are the merged (p, vR)
+        leg sorted by charge, columns the vL states."""
+        out = []
+        for (_, r0, r1, c0, c1, arr) in sd.blocks:
+            ps, al = np.asarray(sd.bra_p[r0:r1]), np.asarray(sd.bra_alpha[r0:r1])
+            for p in (0, 1):
+                sel = np.nonzero(ps == p)[0]
+                if sel.size == 0:
+                    continue
+                a0, a1 = int(al[sel[0]]), int(al[sel[-1]]) + 1
+                assert np.array_equal(al[sel], np.arange(a0, a1)), "vR states of a charge block are not contiguous"
+                out.append((p, int(q_l[c0]), int(q_r[a0]), c0, c1, a0, a1, np.ascontiguousarray(arr[sel].T)))
+        return out
+
+    q_long = [np.asarray(b.q_left, np.int64) for b in b_long]
+    cell = [right_blocks(sds[i], q_long[i], q_long[i + 1] if i + 1 < sites_per_cell else q_b[-1]) for i in range(sites_per_cell)]
+    # gauge matrix C[a, b] = <L^short_a | L^long_b> (rows short, columns long; equal charges)
+    gblocks = {}
+    for (_, r0, r1, c0, c1, arr) in gauge.blocks:
+        al = np.asarray(gauge.bra_alpha[r0:r1])
+        assert np.array_equal(al, np.arange(al[0], al[0] + len(al)))
+        gblocks[(int(q_b[0][al[0]]), int(q_long[0][c0]))] = np.array(arr)
+    C0 = BlockMatrix(gblocks, q_b[0], q_long[0])
+    # (the reference passes the unnormalised Schmidt values of the two cuts, slater.py:1542-1543)
+    C, left_unitary, left_schmidt = basis_rotation(C0, b_short.lam_raw, b_long[0].lam_raw, mode="left", unitary_tol=unitary_tol,
+                                                   schmidt_tol=schmidt_tol, device=device)
+    cplx = any(np.iscomplexobj(b[7]) for bl in cell for b in bl) or any(np.iscomplexobj(v) for v in C.blocks.values())
+    dev = _Dev(device, cplx)
+    rt = _sector_table(q_b[0])
+    g, first = [], []
+    for (p, ql, qr, l0, l1, r0, r1, arr) in cell[0]:                      # slater.py:1552: C . B_0 on the vL leg
+        key = (ql, ql)
+        if key not in C.blocks:
+            continue
+        cb = C.blocks[key]
+        ns, nl, nr = cb.shape[0], cb.shape[1], arr.shape[1]
+        assert nl == arr.shape[0]
+        t = dev.zeros(ns * nr)
+        a_ = dev.up(np.asfortranarray(cb).astype(dev.np_dt).reshape(-1, order="F"))
+        b_ = dev.up(np.asfortranarray(arr).astype(dev.np_dt).reshape(-1, order="F"))
+        g.append((a_.data_ptr(), b_.data_ptr(), t.data_ptr(), ns, nr, nl, ns, nl, ns))
+        first.append((p, ql, qr, rt[ql][0], rt[ql][0] + ns, r0, r1, t, ns, nr))
+    dev.gemm(g)
+    dev.torch.cuda.synchronize(dev.device)
+    cell[0] = [(p, ql, qr, l0, l1, r0, r1, t.cpu().numpy()[: ns * nr].reshape(nr, ns).T.copy())
+               for (p, ql, qr, l0, l1, r0, r1, t, ns, nr) in first]
+    blocks = [[(p, ql - offset, qr - offset, l0, l1, r0, r1, a) for (p, ql, qr, l0, l1, r0, r1, a) in bl] for bl in cell]
+    res = iMPSData(blocks, lam, [q - offset for q in q_b], dq, unit_cell_width, conserve="N")
+    res.gauge_overlaps = C0          # <L^short_a | L^long_b> before the rotation (diagnostics, tests)
+    return res, iMPSError(left_unitary, left_schmidt, 0.0, 0.0)
+
+
 def _read(dev, ptr, count):
     """Host copy of `count` elements at device address `ptr` (inside one of the tensors `dev` keeps alive)."""
     for t in dev.keep:
@@ -590,4 +664,4 @@ def _read(dev, ptr, count):
     raise KeyError(ptr)
 
 
-__all__ = ["MPS_to_iMPS", "overlap_schmidt", "basis_rotation", "iMPSError", "iMPSData", "BlockMatrix"]
+__all__ = ["MPS_to_iMPS", "overlap_schmidt", "basis_rotation", "iMPSError", "iMPSData", "BlockMatrix", "cell_from_determinants"]

@@ -174,14 +174,19 @@ def C_to_iMPS(
     """iMPS representation of a Slater determinant from the correlation matrices of two chains that differ by
     one unit cell (slater.py:1356-1565): same arguments, defaults, offset rules and exceptions.
 
-    As in the reference the last tensor of the unit cell is expressed in the right Schmidt vectors of the SHORT chain
-    (slater.py:1508-1518) and no right-hand errors are reported (slater.py:1563); the first tensor carries the Procrustes
-    rotation of the left Schmidt-vector overlaps (slater.py:1538-1553).  Difference in method, stated rather than hidden:
-    the reference gets those overlaps from determinant formulas without environment tensors (slater.py:1443-1446,
-    1023-1024); here both chains are converted in full (30 ms each at L = 1024) with their orthogonality centre at ``cut``
-    and the overlaps come from the transfer matrices of the two MPS (:func:`temfpy_amd.iMPS.MPS_to_iMPS` with
-    ``right="project"``), i.e. they are overlaps of the truncated Schmidt vectors.  Same state up to the truncation
-    (acceptance check of src/examples/iMPS.py:27-38 in tests/test_gpu_imps.py)."""
+    As in the reference every tensor is a determinant formula between the Schmidt vectors of two cuts and no chain is converted
+    in full (slater.py:1443-1446): ONE sweep decomposes the cuts ``cut .. cut + sites_per_cell - 1`` of the long chain and the
+    cut of the short chain, the last tensor of the unit cell takes the right Schmidt vectors of the SHORT chain as its bra
+    (slater.py:1508-1518), the first one carries the Procrustes rotation of the overlaps of the left Schmidt vectors
+    (slater.py:1538-1553; overlaps without a physical leg, :1023-1024), and no right-hand errors are reported (:1563).
+    (``TMF_IMPS=transfer`` keeps the earlier method for A/B: both chains converted in full, overlaps from their transfer
+    matrices, :func:`temfpy_amd.iMPS.MPS_to_iMPS` with ``right="project"`` - the same state up to the truncation.)
+
+    The short chain enters the sweep as ``diag(0, C_short)`` of the long chain's size: ``sites_per_cell`` empty, decoupled
+    sites in front leave its Schmidt decomposition at the cut unchanged and line its right block up with the one of the long
+    chain, so that both chains share one batch of cut problems."""
+    import os
+
     from . import iMPS
 
     trunc_par = to_stopping_condition(trunc_par)
@@ -203,18 +208,42 @@ def C_to_iMPS(
     assert L_short + mult * sites_per_cell == L_long, (
         "The given two MPS must differ by one unit cell, got "
         f"{L_long} - {L_short} != {mult * sites_per_cell}")
+    C2s = np.asarray(C_short) if spinful is None else spinful_correlation_matrix(np.asarray(C_short), spinful == "PH")
     if offset == "auto":                                       # slater.py:1491 (after doubling)
-        C2 = C_short if spinful is None else spinful_correlation_matrix(C_short, spinful == "PH")
-        offset = round(np.trace(C2[: mult * cut, : mult * cut]).real)
-    mps_s = C_to_MPS(C_short, trunc_par, diag_tol=diag_tol, ortho_center=mult * cut, spinful=spinful, device=device,
-                     as_tenpy=False)
-    mps_l = C_to_MPS(C_long, trunc_par, diag_tol=diag_tol, ortho_center=mult * cut, spinful=spinful, device=device,
-                     as_tenpy=False)
-    res, err = iMPS.MPS_to_iMPS(mps_s, mps_l, mult * sites_per_cell, mult * cut, unitary_tol=unitary_tol,
-                                schmidt_tol=schmidt_tol, offset=offset, unit_cell_width=mult * sites_per_cell,
-                                device=device, right="project")
-    res.unit_cell_width = unit_cell_width
-    return _maybe_tenpy(res, as_tenpy), err
+        offset = round(np.trace(C2s[: mult * cut, : mult * cut]).real)
+    # Two identical spin species make every Schmidt value of a cut at least twofold degenerate, and the order inside such a
+    # multiplet is decided by the last bits of the eigenvalues (threshold events) - which two sweeps over
+    # different matrices do not share, while the reference's two calls of LAPACK on the same block do.  The unit cell would
+    # then come in a basis that is a permutation of the one ``C_to_MPS(C_short)`` returns; there it is taken from the two
+    # fully converted chains instead, which keeps it consistent with them (src/examples/iMPS.py:27-38 relies on that).
+    if os.environ.get("TMF_IMPS", "determinants" if spinful is None else "transfer") == "transfer":
+        mps_s = C_to_MPS(C_short, trunc_par, diag_tol=diag_tol, ortho_center=mult * cut, spinful=spinful, device=device,
+                         as_tenpy=False)
+        mps_l = C_to_MPS(C_long, trunc_par, diag_tol=diag_tol, ortho_center=mult * cut, spinful=spinful, device=device,
+                         as_tenpy=False)
+        res, err = iMPS.MPS_to_iMPS(mps_s, mps_l, mult * sites_per_cell, mult * cut, unitary_tol=unitary_tol,
+                                    schmidt_tol=schmidt_tol, offset=offset, unit_cell_width=mult * sites_per_cell,
+                                    device=device, right="project")
+        res.unit_cell_width = unit_cell_width
+        return _maybe_tenpy(res, as_tenpy), err
+    from .engine import _drive
+
+    C2l = np.asarray(C_long) if spinful is None else spinful_correlation_matrix(np.asarray(C_long), spinful == "PH")
+    spc, x = mult * sites_per_cell, mult * cut
+    assert 0 < x < L_short, f"Invalid entanglement cut {x}"
+    dt = np.result_type(C2s.dtype, C2l.dtype, np.float64)
+    emb = np.zeros((L_long, L_long), dt)
+    emb[spc:, spc:] = C2s
+    cross = [dict(mode=1, phys=True, bra=(1, x + spc), ket=(0, x + spc - 1)),         # last tensor (slater.py:1513)
+             dict(mode=0, phys=False, bra=(1, x + spc), ket=(0, x), skip=spc)]         # gauge overlaps (slater.py:1538)
+    eng = _engine(device)
+    eng.checks = testing.TEST_ACTION != "pass"
+    res = _drive(eng.run_gen(np.ascontiguousarray(C2l, dt), trunc_par, x, L_long, site_range=(x, x + spc - 1),
+                             second=dict(C=emb, oc=x + spc, cross=cross)))
+    testing.report_schmidt_checks(res.info["checks"], diag_tol)     # both reference cuts (slater.py:419-420 via :1499-1505)
+    cell, err = iMPS.cell_from_determinants(res.shards[0], L_long, x, spc, int(offset), unit_cell_width,
+                                            unitary_tol=unitary_tol, schmidt_tol=schmidt_tol, device=device)
+    return _maybe_tenpy(cell, as_tenpy), err
 
 
 def H_to_iMPS(

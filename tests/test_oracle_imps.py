@@ -59,3 +59,35 @@ def test_basis_rotation_is_the_polar_factor():
     rot, ue, se = io.basis_rotation(0.9 * U, S, S, "left")
     np.testing.assert_allclose(rot, U, atol=1e-12)
     assert abs(ue - np.sqrt(1 - 0.81)) < 1e-12
+
+
+@pytest.mark.parametrize("L,cut,cell", [(32, 16, 2), (28, 12, 2), (30, 14, 4)])
+def test_c_to_imps_by_determinant_formulas(L, cut, cell):
+    """slater.py:1356-1565 restated (oracle ``c_to_imps``): every tensor is a determinant overlap between Schmidt vectors of
+    two cuts - the gauge matrix without a physical leg (slater.py:1023-1024), the last tensor with the right vectors of the
+    SHORT chain as bra (:1513-1514) - and no chain is converted in full.  Pinned like the rest of this oracle: the short chain
+    with n cells inserted reproduces the directly converted longer chain; and the overlaps agree with those of the
+    transfer-matrix route (``mps_to_imps``), weighted with the Schmidt values of the two bases."""
+    chi = 48
+    Cs, _ = orc.correlation_matrix(ssh(L))
+    Cl, _ = orc.correlation_matrix(ssh(L + cell))
+    B, S, (lu, ls_), G = orc.c_to_imps(Cs, Cl, {"chi_max": chi}, cell, cut)
+    assert lu < 2e-4 and ls_ < 2e-4
+    assert len(B) == cell and len(S) == cell + 1 and S[0] is S[-1]
+    for t, sl in zip(B, S):
+        X = sum(t[p] @ t[p].conj().T for p in range(2)) - np.eye(t.shape[1])
+        assert np.abs(sl[:, None] * X * sl[None, :]).max() < 1e-6
+    Ts, ls, fs = finite(L, chi, cut if cut != L // 2 else None)
+    n_cell = 3
+    Tr, lr, fr = io.insert_cells(Ts, ls, fs, B, S, cut, n_cell)
+    Tv, lv, fv = finite(L + cell * n_cell, chi, cut if cut != L // 2 else None)
+    ov = io.overlap(Tv, lv, fv, Tr, lr, fr)
+    nr = io.overlap(Tr, lr, fr, Tr, lr, fr).real
+    nv = io.overlap(Tv, lv, fv, Tv, lv, fv).real
+    assert abs(abs(ov) / np.sqrt(nr * nv) - 1) < 1e-8
+    # the same gauge overlaps from the transfer matrices of the two fully converted chains
+    Tl, ll, fl = finite(L + cell, chi, cut)
+    bra = [io.get_B(Ts, ls, fs, i, "A") for i in range(cut)]
+    ket = [io.get_B(Tl, ll, fl, i, "A") for i in range(cut)]
+    w = S[0][:, None] * ll[cut][None, :]      # (entries between weakly weighted vectors see the truncation of the chains)
+    assert (np.abs(io.overlap_schmidt(bra, ket, "left") - G) * w).max() < 1e-9
