@@ -184,7 +184,14 @@ def C_to_iMPS(
 
     The short chain enters the sweep as ``diag(0, C_short)`` of the long chain's size: ``sites_per_cell`` empty, decoupled
     sites in front leave its Schmidt decomposition at the cut unchanged and line its right block up with the one of the long
-    chain, so that both chains share one batch of cut problems."""
+    chain, so that both chains share one batch of cut problems.
+
+    The reference's example inserts the unit cell into a SEPARATELY converted short chain (src/examples/iMPS.py:27-38), which
+    works there because LAPACK returns the same eigenvectors for the same block twice.  Two different sweeps do not share
+    rounding, so what rounding decides is fixed by rule in every sweep: the phases of the entangled orbitals and the basis
+    inside groups of eigenvalues C does not tell apart (``tmf_canonical_gauge_batched``), and the order of occupation
+    patterns of equal weight (``tmf_cut_vectors``).  ``C_to_MPS(C_short, ortho_center=cut)`` and this function then number
+    and sign the Schmidt vectors of the cut alike, also for two identical spin species (tests/test_gpu_imps.py)."""
     import os
 
     from . import iMPS
@@ -211,12 +218,7 @@ def C_to_iMPS(
     C2s = np.asarray(C_short) if spinful is None else spinful_correlation_matrix(np.asarray(C_short), spinful == "PH")
     if offset == "auto":                                       # slater.py:1491 (after doubling)
         offset = round(np.trace(C2s[: mult * cut, : mult * cut]).real)
-    # Two identical spin species make every Schmidt value of a cut at least twofold degenerate, and the order inside such a
-    # multiplet is decided by the last bits of the eigenvalues (threshold events) - which two sweeps over
-    # different matrices do not share, while the reference's two calls of LAPACK on the same block do.  The unit cell would
-    # then come in a basis that is a permutation of the one ``C_to_MPS(C_short)`` returns; there it is taken from the two
-    # fully converted chains instead, which keeps it consistent with them (src/examples/iMPS.py:27-38 relies on that).
-    if os.environ.get("TMF_IMPS", "determinants" if spinful is None else "transfer") == "transfer":
+    if os.environ.get("TMF_IMPS", "determinants") == "transfer":
         mps_s = C_to_MPS(C_short, trunc_par, diag_tol=diag_tol, ortho_center=mult * cut, spinful=spinful, device=device,
                          as_tenpy=False)
         mps_l = C_to_MPS(C_long, trunc_par, diag_tol=diag_tol, ortho_center=mult * cut, spinful=spinful, device=device,
