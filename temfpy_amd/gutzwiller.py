@@ -424,12 +424,14 @@ def _dominant_eigenpair(apply, v0, tol=2e-15, krylov=24, restarts=400, stagnatio
         ev, Yv = np.linalg.eig(H[:used, :used])
         i = int(np.argmax(np.abs(ev)))
         theta, y = ev[i], Yv[:, i]
+        res = abs(beta * y[-1]) / max(np.linalg.norm(y), 1e-300)     # Ritz residual (of the complex vector, if it is one)
         if v.dtype.kind != "c":
-            if abs(theta.imag) > 1e-9 * abs(theta):
-                y, theta = y.real, theta.real          # (a complex pair in front: keep iterating with the real part)
-            else:
-                y, theta = y.real, theta.real
-        res = abs(beta * y[-1]) / max(np.linalg.norm(y), 1e-300)
+            # A real map: a real leading Ritz value has a real vector.  A complex PAIR in front has no real eigenvector; its
+            # value is returned as it is (callers demand a real positive dominant eigenvalue and raise), and the restart
+            # vector is the real part, which together with its image spans the plane of the pair.
+            if not abs(theta.imag) > 1e-9 * abs(theta):
+                theta = theta.real
+            y = y.real
         v = y @ V[:used]
         v = v / np.linalg.norm(v)
         # done at `tol`, or when the residual has stopped falling at the rounding level of `apply` (the Schmidt values of

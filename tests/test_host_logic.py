@@ -293,6 +293,15 @@ def test_arnoldi_dominant_eigenpair():
     th, v = _dominant_eigenpair(apply_padded, v0)
     assert abs(th - 3926.9) < 1e-8 and np.linalg.norm(A @ v - th * v) < 1e-8 * np.linalg.norm(v)
     assert calls[0] == n          # stopped when the 13-dimensional space was exhausted, not at the vector length
+    # a REAL map whose dominant eigenvalues are a complex pair: no real eigenvector exists; the pair's value comes back with
+    # its imaginary part (the caller demands a real positive eigenvalue and raises), not silently as its real part
+    n = 40
+    A = np.diag(0.3 * rng.uniform(size=n))
+    A[:2, :2] = 1.1 * np.array([[np.cos(0.7), -np.sin(0.7)], [np.sin(0.7), np.cos(0.7)]])
+    Q = np.linalg.qr(rng.normal(size=(n, n)))[0]
+    A = Q @ A @ Q.T
+    th, v = _dominant_eigenpair(lambda x: A @ x, np.ones(n))
+    assert abs(abs(th) - 1.1) < 1e-9 and abs(abs(th.imag) - 1.1 * np.sin(0.7)) < 1e-9
 
 
 def test_dead_states_are_removed_from_the_bonds_of_a_cell():
