@@ -226,7 +226,7 @@ extern "C" int tmf_svd_left_batched(int dtype, const tmf_jacobi_desc* d_desc, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// Compacting variant for rank-deficient factors (canonicalisation sweeps of projected MPS, p up to 512):
+// Compacting variant for rank-deficient factors (canonicalisation sweeps of projected MPS, p up to 4096):
 // columns whose squared norm is below thresh2 * 1e-4 / p cannot lift a singular value over the threshold
 // (together they perturb the spectrum by < 1e-2 sqrt(thresh2) in absolute terms; the rounding noise of the
 // QR that produced the factor sits at 1e-16, four decades below a 1e-12 cutoff) and take no part; only the nact active
@@ -242,15 +242,19 @@ extern "C" int tmf_svd_left_batched(int dtype, const tmf_jacobi_desc* d_desc, in
 namespace tmf {
 
 template <typename T>
-__global__ __launch_bounds__(512) void jacobi_compact_kernel(const tmf_jacobi_desc* __restrict__ desc, int lds_elems,
+__global__ __launch_bounds__(512) void jacobi_compact_kernel(const tmf_jacobi_desc* __restrict__ desc, int lds_elems, int head_cols,
                                                              int32_t* __restrict__ sweeps_out) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ int act[512];
-  __shared__ double nrm[512];
+  extern __shared__ __align__(16) unsigned char smem_all[];
   __shared__ int s_nact, flag;
   const tmf_jacobi_desc d = desc[blockIdx.x];
   const int p = d.p;
   if (p <= 0) return;
+  // head of the dynamic LDS: column norms, active list and a second list for its reordering (16 B per column of the
+  // LARGEST problem of the launch: `head_cols`), then the columns themselves
+  double* nrm = reinterpret_cast<double*>(smem_all);
+  int* act = reinterpret_cast<int*>(nrm + head_cols);
+  int* act2 = act + head_cols;
+  unsigned char* smem = smem_all + (size_t)head_cols * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   T* Xg = reinterpret_cast<T*>(d.X);
   T* Vg = reinterpret_cast<T*>(d.V);
@@ -275,17 +279,18 @@ __global__ __launch_bounds__(512) void jacobi_compact_kernel(const tmf_jacobi_de
   __syncthreads();
   const int nact = s_nact;
   // de Rijk ordering: active columns by descending norm (fewer sweeps on graded factors)
-  int my_col = -1, my_rank = 0;
-  if (tid < nact) {
-    my_col = act[tid];
+  for (int a = tid; a < nact; a += 512) {
+    const int my_col = act[a];
     const double v = nrm[my_col];
+    int my_rank = 0;
     for (int b = 0; b < nact; ++b) {
       const int cb = act[b];
       my_rank += (nrm[cb] > v) || (nrm[cb] == v && cb < my_col);
     }
+    act2[my_rank] = my_col;
   }
   __syncthreads();
-  if (my_col >= 0) act[my_rank] = my_col;
+  for (int a = tid; a < nact; a += 512) act[a] = act2[a];
   __syncthreads();
   const bool with_v = Vg != nullptr;    // desc.V == 0: left vectors only (no accumulator), see the entry point
   const bool x_lds = (size_t)p * nact <= (size_t)lds_elems;
@@ -422,26 +427,28 @@ extern "C" int tmf_jacobi_compact_batched(int dtype, const tmf_jacobi_desc* d_de
                                           int32_t* d_sweeps, void* stream) {
   using namespace tmf;
   if (nprob <= 0) return TMF_OK;
-  if (max_p <= 0 || max_p > 512) {
-    set_error("tmf_jacobi_compact_batched: p = %d not in 1..512", max_p);
+  if (max_p <= 0 || max_p > 4096) {      // (p > ~100: the columns live in global memory, slow but correct)
+    set_error("tmf_jacobi_compact_batched: p = %d not in 1..4096", max_p);
     return TMF_E_LIMIT;
   }
   const size_t elem = (dtype == TMF_C128) ? 16 : 8;
+  const int head_cols = (max_p + 15) & ~15;
+  const size_t head = (size_t)head_cols * 16;
   size_t lds = 2 * (size_t)max_p * max_p * elem;          // enough for everything active
-  if (lds > 152 * 1024) lds = 152 * 1024;                 // (+ ~6.2 KiB of static LDS)
+  if (lds > 158 * 1024 - head) lds = 158 * 1024 - head;
   if (lds < 1024) lds = 1024;
   hipStream_t s = static_cast<hipStream_t>(stream);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)jacobi_compact_kernel<cd>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-    (void)hipFuncSetAttribute((const void*)jacobi_compact_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    (void)hipFuncSetAttribute((const void*)jacobi_compact_kernel<cd>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    (void)hipFuncSetAttribute((const void*)jacobi_compact_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     attr_done = true;
   }
   const int lds_elems = (int)(lds / elem);
   if (dtype == TMF_C128)
-    hipLaunchKernelGGL(jacobi_compact_kernel<cd>, dim3(nprob), dim3(512), lds, s, d_desc, lds_elems, d_sweeps);
+    hipLaunchKernelGGL(jacobi_compact_kernel<cd>, dim3(nprob), dim3(512), lds + head, s, d_desc, lds_elems, head_cols, d_sweeps);
   else if (dtype == TMF_F64)
-    hipLaunchKernelGGL(jacobi_compact_kernel<double>, dim3(nprob), dim3(512), lds, s, d_desc, lds_elems, d_sweeps);
+    hipLaunchKernelGGL(jacobi_compact_kernel<double>, dim3(nprob), dim3(512), lds + head, s, d_desc, lds_elems, head_cols, d_sweeps);
   else {
     set_error("tmf_jacobi_compact_batched: bad dtype %d", dtype);
     return TMF_E_ARG;

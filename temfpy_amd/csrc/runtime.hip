@@ -236,6 +236,8 @@ extern "C" int tmf_gather_signed_batched(int dtype, const tmf_gather_desc* d_des
 // ---- canonical gauge of the entangled orbitals (tmf_gauge_desc) --------------------------
 namespace {
 constexpr int GAUGE_DMAX = 8;
+constexpr int GAUGE_LDS_FIXED = GAUGE_DMAX * 256 * 16 + 256 * 4;       // k <= 255 entangled orbitals
+constexpr int GAUGE_W0_ROWS = 4096;
 template <typename T>
 __device__ inline T gauge_weight(int t, int j);
 template <>
@@ -262,7 +264,11 @@ __global__ __launch_bounds__(256) void gauge_kernel(const tmf_gauge_desc* __rest
   const int32_t* __restrict__ start = reinterpret_cast<const int32_t*>(d.start);
   T* M = reinterpret_cast<T*>(smem);                   // [GAUGE_DMAX][k]: <w_t | v_c>, then the rotation of the group of c
   int* size = reinterpret_cast<int*>(M + (size_t)GAUGE_DMAX * k);
+  T* w0 = reinterpret_cast<T*>(smem + GAUGE_LDS_FIXED);   // first weight vector by row (n <= GAUGE_W0_ROWS), else recomputed
+  const bool have_w0 = n <= GAUGE_W0_ROWS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (have_w0)
+    for (int r = tid; r < n; r += 256) w0[r] = gauge_weight<T>(0, d.from_top ? r : n - 1 - r);
   for (int c = tid; c < k; c += 256) {
     const int s0 = start[c];
     int e = c;
@@ -277,12 +283,16 @@ __global__ __launch_bounds__(256) void gauge_kernel(const tmf_gauge_desc* __rest
     T acc[GAUGE_DMAX];
 #pragma unroll
     for (int t = 0; t < GAUGE_DMAX; ++t) acc[t] = sc<T>::zero();
-    for (int r = lane; r < n; r += 64) {
-      const T v = V[r + (size_t)c * d.ld];
-      const int j = d.from_top ? r : n - 1 - r;
+    if (dsz == 1 && have_w0) {                          // (the usual case: a phase)
+      for (int r = lane; r < n; r += 64) acc[0] = sc<T>::fmacc(acc[0], w0[r], V[r + (size_t)c * d.ld]);
+    } else {
+      for (int r = lane; r < n; r += 64) {
+        const T v = V[r + (size_t)c * d.ld];
+        const int j = d.from_top ? r : n - 1 - r;
 #pragma unroll
-      for (int t = 0; t < GAUGE_DMAX; ++t)
-        if (t < dsz) acc[t] = sc<T>::fmacc(acc[t], gauge_weight<T>(t, j), v);
+        for (int t = 0; t < GAUGE_DMAX; ++t)
+          if (t < dsz) acc[t] = sc<T>::fmacc(acc[t], gauge_weight<T>(t, j), v);
+      }
     }
 #pragma unroll
     for (int t = 0; t < GAUGE_DMAX; ++t) {
@@ -339,7 +349,13 @@ __global__ __launch_bounds__(256) void gauge_kernel(const tmf_gauge_desc* __rest
 extern "C" int tmf_canonical_gauge_batched(int dtype, const tmf_gauge_desc* d_desc, int nprob, void* stream) {
   if (nprob <= 0) return TMF_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const size_t lds = (size_t)GAUGE_DMAX * 256 * 16 + 256 * 4;       // k <= 255 entangled orbitals
+  const size_t lds = (size_t)GAUGE_LDS_FIXED + (size_t)GAUGE_W0_ROWS * 16;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gauge_kernel<cd>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gauge_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
   if (dtype == TMF_C128)
     hipLaunchKernelGGL(gauge_kernel<cd>, dim3(nprob), dim3(256), lds, s, d_desc);
   else if (dtype == TMF_F64)

@@ -1022,8 +1022,8 @@ class _Projector:
         sec0 = list(self.sect[0])
         secL = [self.end_of[q] for q in sec0]
         n0 = np.array([self.sect[0][q] for q in sec0], np.int64)
-        if int(n0.max()) > 512:
-            raise NotImplementedError(f"a charge sector of the cell boundary holds {int(n0.max())} > 512 states")
+        if int(n0.max()) > 4096:      # (tmf_jacobi_compact_batched; beyond ~100 states per sector its columns live in global memory)
+            raise NotImplementedError(f"a charge sector of the cell boundary holds {int(n0.max())} > 4096 states")
         nsec = len(sec0)
         sq_off = np.concatenate(([0], np.cumsum((n0 * n0 + 1) & ~1)))
         tdt = d_ar.dtype

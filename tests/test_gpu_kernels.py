@@ -885,14 +885,15 @@ def test_jacobi_compact_rank_deficient(eng, cplx):
     """tmf_jacobi_compact_batched against numpy.linalg.svd: singular values (relative 1e-10 above the
     threshold), orthogonal right vectors reproducing X V = U S, zero columns below the threshold; orders beyond
     the plain LDS kernel (real 130, complex 96 with half of the columns at rounding level), a full-rank matrix
-    that does not fit the LDS (global-memory path) and tiny problems."""
+    that does not fit the LDS (global-memory path), a sector of 640 states (round 2 stopped at 512; Gutzwiller at chi = 4096
+    reached 635) and tiny problems."""
     from temfpy_amd import _native as nat
 
     setup(eng, cplx)
     rng = np.random.default_rng(31)
     thr2 = 1e-24
     Xs = []
-    for p, r in [(130, 64), (96, 40), (150, 150), (1, 1), (2, 1), (33, 33), (60, 0)]:
+    for p, r in [(130, 64), (96, 40), (150, 150), (1, 1), (2, 1), (33, 33), (60, 0), (640, 260)]:   # (640: beyond 512 columns, more active ones than threads)
         if r == 0:
             X = np.zeros((p, p), complex if cplx else float)
         else:
