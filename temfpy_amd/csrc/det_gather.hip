@@ -147,6 +147,64 @@ __global__ __launch_bounds__(64) void det_lds_kernel(const tmf_det_desc* __restr
   }
 }
 
+// Slow but general: any sometimes-matrix (read from global memory, not staged), minors of order n with n x n elements in
+// LDS (n <= 97 complex, 138 real) - what the reference's numpy.linalg.det handles without a thought (slater.py:828-869).
+// One determinant at a time per workgroup, one thread per column, partial pivoting.
+// LDS: [ W : n*n T ]
+template <typename T>
+__global__ __launch_bounds__(256) void det_global_kernel(const tmf_det_desc* __restrict__ desc) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ int s_piv;
+  const tmf_det_desc d = desc[blockIdx.x];
+  const int n = d.n, na = d.a1 - d.a0;
+  T* W = reinterpret_cast<T*>(smem);
+  const T* __restrict__ S = reinterpret_cast<const T*>(d.S);
+  const uint8_t* __restrict__ gk = reinterpret_cast<const uint8_t*>(d.ket_idx);
+  const uint8_t* __restrict__ gb = reinterpret_cast<const uint8_t*>(d.bra_idx) + (size_t)d.a0 * n;
+  const T scale = *reinterpret_cast<const T*>(d.scale);
+  T* __restrict__ out = reinterpret_cast<T*>(d.out);
+  const int c = threadIdx.x;
+  for (int p = 0; p < na * d.nsk; ++p) {
+    const int al = p / d.nsk, b = p % d.nsk;
+    if (c < n) {
+      const size_t col = gk[(size_t)b * n + c];
+      for (int r = 0; r < n; ++r) W[r + c * n] = S[(size_t)gb[(size_t)al * n + r] + col * d.lds];
+    }
+    __syncthreads();
+    T det = sc<T>::one();
+    for (int j = 0; j < n; ++j) {
+      if (c == j) {
+        int best = j;
+        double bv = sc<T>::abs2(W[j + j * n]);
+        for (int r = j + 1; r < n; ++r) {
+          const double v = sc<T>::abs2(W[r + j * n]);
+          if (v > bv) bv = v, best = r;
+        }
+        s_piv = best;
+      }
+      __syncthreads();
+      const int piv = s_piv;
+      if (c < n && piv != j) {
+        const T t = W[j + c * n];
+        W[j + c * n] = W[piv + c * n];
+        W[piv + c * n] = t;
+      }
+      __syncthreads();
+      const T p_ = W[j + j * n];
+      det = sc<T>::mul(det, p_);
+      if (piv != j) det = sc<T>::neg(det);
+      const T pinv = sc<T>::abs2(p_) > 0.0 ? sc<T>::inv(p_) : sc<T>::zero();
+      if (c > j && c < n) {
+        const T pc = sc<T>::mul(pinv, W[j + c * n]);
+        for (int r = j + 1; r < n; ++r) W[r + c * n] = sc<T>::fms(W[r + c * n], W[r + j * n], pc);
+      }
+      __syncthreads();
+    }
+    if (c == 0) out[(size_t)(d.a0 + al) * d.nsk + b] = sc<T>::mul(scale, det);
+    __syncthreads();
+  }
+}
+
 template <typename T, int N>
 static void launch_exact(dim3 g, int lds, hipStream_t s, const tmf_det_desc* d) {
   constexpr int G = N <= 8 ? 8 : (N <= 16 ? 16 : 32);
@@ -178,8 +236,17 @@ static int launch_det(int n, const tmf_det_desc* d, int nt, int lds, hipStream_t
       hipLaunchKernelGGL((det_lds_kernel<T>), g, dim3(64), lds, s, d);
       break;
     }
+    case 255: {
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void*)det_global_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);   // (+ 4 B static)
+        attr = true;
+      }
+      hipLaunchKernelGGL((det_global_kernel<T>), g, dim3(256), lds, s, d);
+      break;
+    }
     default:
-      set_error("tmf_det_gather_batched: order must be 0..32 (exact) or 64 (generic), got %d", n);
+      set_error("tmf_det_gather_batched: order must be 0..32 (exact), 64 (generic) or 255 (global memory), got %d", n);
       return TMF_E_ARG;
   }
   return check_hip(hipGetLastError(), "tmf_det_gather_batched launch");

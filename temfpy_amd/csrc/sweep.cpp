@@ -1388,10 +1388,6 @@ struct Sweep {
     for (i64 j = 0; j < ns; ++j) {
       const tmf_site_out& o = c.souts[j];
       mb[j] = o.mb, mk[j] = o.mk, ka[j] = o.k_always, sbv[j] = o.sb, skv[j] = o.sk;
-      if (sbv[j] * skv[j] * el > 64 * 1024) {
-        set_error("sometimes-matrix larger than the 64 KiB LDS stage of the determinant kernel");
-        return TMF_E_LIMIT;
-      }
       oW[j] = tW;
       tW += mb[j] * mk[j];
       maxmb = std::max(maxmb, mb[j]);
@@ -1637,6 +1633,7 @@ struct Sweep {
       };
       std::vector<TileX> tx;
       const bool force_direct = (c.par.flags & TMF_SWEEP_DET_DIRECT) != 0;
+      static const bool force_global = getenv("TMF_DET_GLOBAL") && atoi(getenv("TMF_DET_GLOBAL")) != 0;   // (test switch: class 255 for every sector of the general path)
       for (const Rest& r : rs) {
         const tmf_sector& sec = c.sec_buf[c.jobs[r.site].sec_off + r.loc];
         const i64 nq = sec.n, nsb = sec.r1 - sec.r0, nsk = sec.c1 - sec.c0, j = r.site;
@@ -1667,9 +1664,14 @@ struct Sweep {
           red = red && (lred + 16 <= 160 * 1024);
           x.red = red;
           x.lneed = red ? lred : lneed;
-          if (x.lneed > 160 * 1024) {
-            set_error("determinant tile exceeds the 160 KiB LDS of a CU");
-            return TMF_E_LIMIT;
+          if (x.lneed > 160 * 1024 || nq > 64 || force_global) {
+            // the sometimes-matrix (or the minor) does not fit next to the index lists: class 255 reads the matrix from
+            // global memory and keeps only the minor in LDS (slow, general)
+            x.cls = 255, x.red = false, x.lneed = a16(nq * nq * el) + 64;
+            if (x.lneed > 158 * 1024) {
+              set_error("minors of order %lld exceed the LDS of a CU (%lld B)", (long long)nq, (long long)x.lneed);
+              return TMF_E_LIMIT;
+            }
           }
           tx.push_back(x);
         }

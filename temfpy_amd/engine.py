@@ -1377,8 +1377,6 @@ class Engine:
         t0 = time.perf_counter()
         mb, mk, ka = (souts[f].astype(np.int64) for f in ("mb", "mk", "k_always"))
         sbv, skv = souts["sb"].astype(np.int64), souts["sk"].astype(np.int64)
-        if int((sbv * skv).max()) * el > 64 * 1024:
-            raise NotImplementedError("sometimes-matrix larger than the 64 KiB LDS stage of the determinant kernel")
         assert np.array_equal(ib, e_ib) and np.array_equal(ik, e_ik)
         oW, tW = offsets(mb * mk)
         d_W = self._alloc(tW)
@@ -1484,8 +1482,14 @@ class Engine:
             lneed_red = nat.reduced_det_lds(el, nq[tsec], sbv[tsite], skv[tsite], nsk_[tsec], ta[tsec]) - 16
             use_red &= lneed_red + 16 <= 160 * 1024
             lneed = np.where(use_red, lneed_red, lneed)
-            if int(lneed.max()) > 160 * 1024:
-                raise NotImplementedError("determinant tile exceeds the 160 KiB LDS of a CU")
+            # the sometimes-matrix (or the minor) does not fit next to the index lists: class 255 reads the matrix from global
+            # memory and keeps only the minor in LDS (slow, general); TMF_DET_GLOBAL=1 sends every sector there (test switch)
+            glob = (lneed > 160 * 1024) | (nq[tsec] > 64) | bool(int(os.environ.get("TMF_DET_GLOBAL", "0")))
+            tcls = np.where(glob, 255, tcls)
+            use_red = use_red & ~glob
+            lneed = np.where(glob, a16(nq[tsec] ** 2 * el) + 64, lneed)
+            if int(lneed.max()) > 158 * 1024:
+                raise NotImplementedError(f"minors of order {int(nq[tsec][np.argmax(lneed)])} exceed the LDS of a CU")
             launches = sorted({(int(c_), bool(r_)) for c_, r_ in zip(tcls.tolist(), use_red.tolist())},
                               key=lambda cr: -int(pairs[(tcls == cr[0]) & (use_red == cr[1])].sum()))
             for cls, red in launches:

@@ -387,16 +387,23 @@ def test_block_local_elimination(eng, cplx):
 
 
 @pytest.mark.parametrize("cplx", [True, False])
-@pytest.mark.parametrize("n,cls", [(0, 0), (1, 1), (2, 2), (5, 5), (8, 8), (9, 9), (12, 12), (13, 13), (16, 16), (17, 17), (19, 19), (25, 25), (32, 32), (40, 64)])
+@pytest.mark.parametrize("n,cls", [(0, 0), (1, 1), (2, 2), (5, 5), (8, 8), (9, 9), (12, 12), (13, 13), (16, 16), (17, 17), (19, 19), (25, 25), (32, 32), (40, 64),
+                                   (7, 255), (40, 255), (70, 255), (90, 255)])
 def test_det_gather(eng, cplx, n, cls):
+    """tmf_det_gather_batched against numpy.linalg.det (slater.py:828-869).  Class 255: the sometimes-matrix stays in global
+    memory (here 120 x 110: 211 KB complex, beyond any LDS stage) and only the minor, of order up to 90, is held in LDS."""
     setup(eng, cplx)
     nat = eng.nat
     rng = np.random.default_rng(7 + n)
     sb, sk = max(n + 6, 3), max(n + 4, 2)
-    if sb * sk * eng.elem > 60000:
+    if cls == 255:
+        sb, sk = 120, 110
+    elif sb * sk * eng.elem > 60000:
         sb = sk = n + 2
     S = rnd(rng, (sb, sk), cplx)
     nsb, nsk = 37, 21 if n < 33 else 5
+    if cls == 255:
+        nsb, nsk = 9, 4
     bra = np.stack([np.sort(rng.choice(sb, n, replace=False)) for _ in range(nsb)]).astype(np.uint8).reshape(nsb, n)
     ket = np.stack([np.sort(rng.choice(sk, n, replace=False)) for _ in range(nsk)]).astype(np.uint8).reshape(nsk, n)
     scale = rnd(rng, (1,), cplx)
@@ -411,6 +418,8 @@ def test_det_gather(eng, cplx, n, cls):
     a16 = lambda x: (x + 15) & ~15  # noqa: E731
     gpw = 8 if n <= 8 else 4 if n <= 16 else 2
     lds = a16(sb * sk * eng.elem) + a16(nsk * n) + a16(ta * n) + (n * n * eng.elem if cls == 64 else 4 * ((n | 1) * sk + gpw * (n + 1)) * eng.elem) + 16
+    if cls == 255:
+        lds = a16(n * n * eng.elem) + 64
     t = eng._up(dd)
     nat.check(eng.lib.tmf_det_gather_batched(eng.dtype, cls, t.data_ptr(), len(dd), lds, eng.stream), "det")
     torch.cuda.synchronize()
@@ -419,7 +428,7 @@ def test_det_gather(eng, cplx, n, cls):
     for a in range(nsb):
         for b in range(nsk):
             ref[a, b] = scale[0] * (np.linalg.det(S[np.ix_(bra[a], ket[b])]) if n else 1.0)
-    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
+    np.testing.assert_allclose(got, ref, rtol=1e-9 if n < 64 else 1e-8, atol=1e-12 * np.abs(ref).max())
 
 
 def _cdiv(a, b):

@@ -628,6 +628,39 @@ def test_centre_pairing_inside_groups_of_close_eigenvalues(L, seed, tol, driver,
     assert abs(1 - overlap(cuts, sites, other, L // 2)) > 1e-7
 
 
+@pytest.mark.parametrize("driver", ["cpp", "python"])
+def test_general_determinant_path_through_global_memory(driver):
+    """Sites whose sometimes-matrix does not fit the LDS stage of the determinant kernels (> 64 x 64 complex) or whose
+    minors have more than 64 rows used to raise; they now take class 255 of tmf_det_gather_batched (matrix read from global
+    memory, minor in LDS).  Such sites need ~100 strongly entangled orbitals, so the dispatch is exercised with the test
+    switch TMF_DET_GLOBAL=1, which sends EVERY charge sector there: same MPS as the oracle's."""
+    import subprocess
+    import sys
+    import textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import numpy as np
+        from oracle import slater_oracle as orc
+        from tests_inputs import random_hopping
+        from temfpy_amd import slater
+        from test_gpu_sweep import overlap
+        L = 40
+        C, _ = orc.correlation_matrix(random_hopping(L, 6))
+        cuts, sites = orc.c_to_mps(C, {"chi_max": 48})
+        mps = slater.C_to_MPS(C, {"chi_max": 48}, as_tenpy=False)
+        for b in range(L + 1):
+            assert np.array_equal(mps.bonds[b].sets, cuts[b].sets)
+        assert abs(1 - overlap(cuts, sites, mps, L // 2)) < 1e-9
+        print("ok")
+    """ % (root, os.path.join(root, "tests")))
+    env = dict(os.environ, TMF_DET_GLOBAL="1", TMF_DET_METHOD="reduced", TMF_SWEEP=driver)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("case", ["L2", "empty", "chi1", "L1", "single_particle", "two_filled"])
 def test_edge_cases_match_oracle(case):
     """Degenerate inputs the reference accepts: the smallest chains, an empty band, chi_max = 1, one
