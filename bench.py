@@ -45,7 +45,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix = vector peak (AMD spec; the micro-architecture guide has no fp64 MFMA row)
 PCIE_PEAK_GBS = 63.0      # PCIe Gen5 x16 host link (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
 REF_SUMMARY = os.path.join(ROOT, "tests", "golden", "full", "cfg3_rand_L1024_s0_chi512.npz")
 
 

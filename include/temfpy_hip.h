@@ -443,7 +443,7 @@ typedef struct {
   uint64_t V, start;               /* V: n x k, leading dimension ld; start: int32[k] on the device */
   int32_t n, k, ld, from_top;
 } tmf_gauge_desc;                  /* 32 bytes */
-int tmf_canonical_gauge_batched(int dtype, const tmf_gauge_desc* d_desc, int nprob, void* stream);
+int tmf_canonical_gauge_batched(int dtype, const tmf_gauge_desc* d_desc, int nprob, int max_n, int max_k, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Host: integer / combinatorial part of the sweep (no GPU needed)

@@ -246,7 +246,7 @@ def load():
     lib.tmf_fill_normal.argtypes = [i32, vp, i64, u64, vp]
     lib.tmf_gather_signed_batched.argtypes = [i32, vp, i32, vp]
     lib.tmf_normalise_columns_batched.argtypes = [i32, vp, i32, vp]
-    lib.tmf_canonical_gauge_batched.argtypes = [i32, vp, i32, vp]
+    lib.tmf_canonical_gauge_batched.argtypes = [i32, vp, i32, i32, i32, vp]
     lib.tmf_column_norms_batched.argtypes = [i32, vp, i32, vp]
     _set_host_argtypes(lib)
     lib.tmf_lu_block_batched.argtypes = [i32, vp, i32, i32, i32, i32, vp]

@@ -236,8 +236,6 @@ extern "C" int tmf_gather_signed_batched(int dtype, const tmf_gather_desc* d_des
 // ---- canonical gauge of the entangled orbitals (tmf_gauge_desc) --------------------------
 namespace {
 constexpr int GAUGE_DMAX = 8;
-constexpr int GAUGE_LDS_FIXED = GAUGE_DMAX * 256 * 16 + 256 * 4;       // k <= 255 entangled orbitals
-constexpr int GAUGE_W0_ROWS = 4096;
 template <typename T>
 __device__ inline T gauge_weight(int t, int j);
 template <>
@@ -255,17 +253,18 @@ __device__ inline cd gauge_weight<cd>(int t, int j) {
 }  // namespace
 
 template <typename T>
-__global__ __launch_bounds__(256) void gauge_kernel(const tmf_gauge_desc* __restrict__ desc) {
+__global__ __launch_bounds__(256) void gauge_kernel(const tmf_gauge_desc* __restrict__ desc, int kcap, int w0_rows) {
   extern __shared__ __align__(16) unsigned char smem[];
   const tmf_gauge_desc d = desc[blockIdx.x];
   const int n = d.n, k = d.k;
   if (n <= 0 || k <= 0) return;
   T* __restrict__ V = reinterpret_cast<T*>(d.V);
   const int32_t* __restrict__ start = reinterpret_cast<const int32_t*>(d.start);
+  // LDS (sized for the largest problem of the launch: kcap columns, w0_rows rows)
   T* M = reinterpret_cast<T*>(smem);                   // [GAUGE_DMAX][k]: <w_t | v_c>, then the rotation of the group of c
-  int* size = reinterpret_cast<int*>(M + (size_t)GAUGE_DMAX * k);
-  T* w0 = reinterpret_cast<T*>(smem + GAUGE_LDS_FIXED);   // first weight vector by row (n <= GAUGE_W0_ROWS), else recomputed
-  const bool have_w0 = n <= GAUGE_W0_ROWS;
+  int* size = reinterpret_cast<int*>(smem + (size_t)GAUGE_DMAX * kcap * sizeof(T));
+  T* w0 = reinterpret_cast<T*>(smem + (size_t)GAUGE_DMAX * kcap * sizeof(T) + (((size_t)kcap * 4 + 15) & ~(size_t)15));
+  const bool have_w0 = n <= w0_rows;                   // first weight vector by row, else recomputed
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (have_w0)
     for (int r = tid; r < n; r += 256) w0[r] = gauge_weight<T>(0, d.from_top ? r : n - 1 - r);
@@ -346,20 +345,33 @@ __global__ __launch_bounds__(256) void gauge_kernel(const tmf_gauge_desc* __rest
   }
 }
 
-extern "C" int tmf_canonical_gauge_batched(int dtype, const tmf_gauge_desc* d_desc, int nprob, void* stream) {
+extern "C" int tmf_canonical_gauge_batched(int dtype, const tmf_gauge_desc* d_desc, int nprob, int max_n, int max_k, void* stream) {
   if (nprob <= 0) return TMF_OK;
+  if (max_k <= 0 || max_k > 4096 || max_n <= 0) {
+    set_error("tmf_canonical_gauge_batched: bad sizes (%d rows, %d columns)", max_n, max_k);
+    return TMF_E_ARG;
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const size_t lds = (size_t)GAUGE_LDS_FIXED + (size_t)GAUGE_W0_ROWS * 16;
+  const size_t elem = (dtype == TMF_C128) ? 16 : 8;
+  const int kcap = (max_k + 3) & ~3;
+  const size_t head = (size_t)GAUGE_DMAX * kcap * elem + (((size_t)kcap * 4 + 15) & ~(size_t)15);
+  int w0_rows = max_n;
+  if (head + (size_t)w0_rows * elem > 60 * 1024) w0_rows = head < 60 * 1024 ? (int)((60 * 1024 - head) / elem) : 0;
+  const size_t lds = head + (size_t)w0_rows * elem;     // <= 60 KiB: two or more workgroups per CU
+  if (lds > 150 * 1024) {
+    set_error("tmf_canonical_gauge_batched: %d columns need %zu B of LDS", max_k, lds);
+    return TMF_E_LIMIT;
+  }
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gauge_kernel<cd>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gauge_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gauge_kernel<cd>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)gauge_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr = true;
   }
   if (dtype == TMF_C128)
-    hipLaunchKernelGGL(gauge_kernel<cd>, dim3(nprob), dim3(256), lds, s, d_desc);
+    hipLaunchKernelGGL(gauge_kernel<cd>, dim3(nprob), dim3(256), lds, s, d_desc, kcap, w0_rows);
   else if (dtype == TMF_F64)
-    hipLaunchKernelGGL(gauge_kernel<double>, dim3(nprob), dim3(256), lds, s, d_desc);
+    hipLaunchKernelGGL(gauge_kernel<double>, dim3(nprob), dim3(256), lds, s, d_desc, kcap, w0_rows);
   else {
     set_error("tmf_canonical_gauge_batched: bad dtype %d", dtype);
     return TMF_E_ARG;

@@ -1121,7 +1121,9 @@ struct Sweep {
         u64 dd;
         TMF_TRY(up_vec(gd, &dd));
         const int nd_ = (int)gd.size();
-        LATER(tmf_canonical_gauge_batched(c.dtype, (const tmf_gauge_desc*)dd, nd_, c.s_main));
+        int gmax_n = 1, gmax_k = 1;
+        for (const tmf_gauge_desc& q : gd) gmax_n = std::max(gmax_n, (int)q.n), gmax_k = std::max(gmax_k, (int)q.k);
+        LATER(tmf_canonical_gauge_batched(c.dtype, (const tmf_gauge_desc*)dd, nd_, gmax_n, gmax_k, c.s_main));
       }
     }
     {  // entangled columns (renormalised copy)

@@ -1235,7 +1235,8 @@ class Engine:
             gdesc["start"] = t_st.data_ptr() + so_ * 4
             gdesc["n"], gdesc["k"], gdesc["ld"], gdesc["from_top"] = n[gsel], k[gsel], ld1[gsel], (cs_side[gsel] == 1)
             t_gd = self._up(gdesc)
-            nat.check(self.lib.tmf_canonical_gauge_batched(self.dtype, t_gd.data_ptr(), int(gsel.size), self.stream),
+            nat.check(self.lib.tmf_canonical_gauge_batched(self.dtype, t_gd.data_ptr(), int(gsel.size), int(n[gsel].max()),
+                                                           int(k[gsel].max()), self.stream),
                       "tmf_canonical_gauge_batched")
         cp = doE.copy()
         for centre_L, centre_R in centres:
