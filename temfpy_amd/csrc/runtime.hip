@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void gather_kernel(const tmf_gather_desc* __re
   const int8_t* rg = reinterpret_cast<const int8_t*>(d.row_sign);
   const int8_t* cg = reinterpret_cast<const int8_t*>(d.col_sign);
   const int total = d.rows * d.cols;
-  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+  // (gridDim.y workgroups share one problem: a shard of 38 sites would otherwise copy 10 MB per site through 38 CUs)
+  for (int e = threadIdx.x + blockIdx.y * blockDim.x; e < total; e += blockDim.x * gridDim.y) {
     const int r = e % d.rows, c = e / d.rows;
     const int sr = rs[r], sc_ = cs[c];
     T v = (sr < 0) ? phys[(size_t)(-sr - 1) + (size_t)sc_ * d.ldp] : src[(size_t)sr + (size_t)sc_ * d.lds_];
@@ -222,10 +223,12 @@ extern "C" int tmf_fill_normal(int dtype, void* d_out, int64_t count, uint64_t s
 extern "C" int tmf_gather_signed_batched(int dtype, const tmf_gather_desc* d_desc, int nprob, void* stream) {
   if (nprob <= 0) return TMF_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  int gy = 2048 / nprob;
+  gy = gy < 1 ? 1 : (gy > 32 ? 32 : gy);
   if (dtype == TMF_C128)
-    hipLaunchKernelGGL(gather_kernel<cd>, dim3(nprob), dim3(256), 0, s, d_desc, tmf::launch_condition());
+    hipLaunchKernelGGL(gather_kernel<cd>, dim3(nprob, gy), dim3(256), 0, s, d_desc, tmf::launch_condition());
   else if (dtype == TMF_F64)
-    hipLaunchKernelGGL(gather_kernel<double>, dim3(nprob), dim3(256), 0, s, d_desc, tmf::launch_condition());
+    hipLaunchKernelGGL(gather_kernel<double>, dim3(nprob, gy), dim3(256), 0, s, d_desc, tmf::launch_condition());
   else {
     set_error("tmf_gather_signed_batched: bad dtype %d", dtype);
     return TMF_E_ARG;

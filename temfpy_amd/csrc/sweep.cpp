@@ -266,6 +266,7 @@ struct tmf_ctx {
   // device results
   OutSlot* slot = nullptr;
   char *d_out = nullptr, *d_det = nullptr, *d_chk = nullptr;
+  hipEvent_t chk_done = nullptr;   // the self-check of this sweep has run (it is launched on the upload stream)
   int n_checks = 0;
   std::vector<int32_t*> sweep_counters;  // device arrays of Jacobi sweep counts
   std::vector<i64> sweep_counts_n;
@@ -378,7 +379,8 @@ struct Sweep {
     }
   };
   // C = alpha op(A) B + beta C over a list of problems (tile table: longest contractions first)
-  int gemm(int opA, double alpha, double beta, const Gemm& g) {
+  int gemm(int opA, double alpha, double beta, const Gemm& g, hipStream_t on = nullptr) {
+    if (on == nullptr) on = c.s_main;
     const size_t np = g.d.size();
     if (np == 0) return TMF_OK;
     int maxN = 0;
@@ -401,12 +403,12 @@ struct Sweep {
     if (timed) {
       TMF_TRY(new_event(&ev.e0));
       TMF_TRY(new_event(&ev.e1));
-      LATER_HIP(hipEventRecord(ev.e0, c.s_main));
+      LATER_HIP(hipEventRecord(ev.e0, on));
     }
     const int ntile = (int)tiles.size();
-    LATER(tmf_gemm_batched(c.dtype, opA, alpha, beta, (const tmf_gemm_desc*)dd, (const int32_t*)dt, ntile, tn, c.s_main));
+    LATER(tmf_gemm_batched(c.dtype, opA, alpha, beta, (const tmf_gemm_desc*)dd, (const int32_t*)dt, ntile, tn, on));
     if (timed) {
-      LATER_HIP(hipEventRecord(ev.e1, c.s_main));
+      LATER_HIP(hipEventRecord(ev.e1, on));
       double fl = 0;
       for (auto& x : g.d) fl += (double)x.M * x.N * x.K;
       ev.flops = fl * (c.cplx ? 8.0 : 2.0);
@@ -650,6 +652,7 @@ struct Sweep {
     c.sweep_counters.clear();
     c.sweep_counts_n.clear();
     c.begun = c.have_sites = c.have_out = false;
+    c.chk_done = nullptr;
     if (c.slot) c.slot->reserved = false;  // (a sweep that was never downloaded)
     c.slot = nullptr;
     c.par = *par;
@@ -1153,15 +1156,26 @@ struct Sweep {
       }
       TMF_TRY(colcopy(d));
     }
-    // centre-right: C_RL U_E(left), reversed, odd columns flipped (slater.py:407-410)
+    // centre-right: C_RL U_E(left), reversed, odd columns flipped (slater.py:407-410).  A chain of seven small launches on
+    // ONE cut (0.34 ms): it runs on the upload stream, next to the products of the filled bases of all cuts, and the launch
+    // stream waits for it before the Gram-Schmidt that reads these columns.
+    hipEvent_t centre_done = nullptr;
     if (c.has_centre && c.k[c.centre_L] > 0 && c.n[c.centre_R] > 0) {
       const i64 cl = c.centre_L, cr = c.centre_R;
       const i64 kc = c.k[cl], nR = c.n[cr], ldR = c.ld1[cr];
       u64 d_pair, d_T, d_scrc;
       TMF_TRY(alloc_el(nR * kc, &d_pair));
+      const bool side = !(c.par.flags & TMF_SWEEP_ONE_STREAM);
+      hipStream_t cs_ = side ? c.s_up : c.s_main;
+      if (side) {
+        hipEvent_t ev;
+        TMF_TRY(new_event(&ev));
+        LATER_HIP(hipEventRecord(ev, c.s_main));
+        LATER_HIP(hipStreamWaitEvent(c.s_up, ev, 0));
+      }
       Gemm g;
       g.add(c.off[cr], Vp[cl], d_pair, nR, kc, c.m[cr], L, c.ld1[cl], ldR);
-      TMF_TRY(gemm(0, 1.0, 0.0, g));
+      TMF_TRY(gemm(0, 1.0, 0.0, g, cs_));
       // The partners of weak orbitals (sigma -> 1e-6) carry errors ~1e-7 from the division by sigma, so they are
       // Gram-Schmidt orthonormalised in order of DECREASING sigma: strong partners stay as computed, weak ones are
       // corrected against them.  Column permutations are k x k (signed) permutation GEMMs.
@@ -1183,13 +1197,24 @@ struct Sweep {
       TMF_TRY(alloc_el(nR * kc, &d_T));
       Gemm g1;
       g1.add(d_pair, t_P, d_T, nR, kc, kc, ldR, kc, ldR);
-      TMF_TRY(gemm(0, 1.0, 0.0, g1));
+      TMF_TRY(gemm(0, 1.0, 0.0, g1, cs_));
       TMF_TRY(alloc_el((kc + 1) * PANEL_W, &d_scrc));
-      TMF_TRY(bcgs({Slab{d_T, nR, ldR, 0, kc, d_scrc}}, 2, false));
+      TMF_TRY(bcgs({Slab{d_T, nR, ldR, 0, kc, d_scrc}}, 2, false, false, cs_));
       Gemm g2;
       g2.add(d_T, t_S, Vp[cr], nR, kc, kc, ldR, kc, ldR);
-      TMF_TRY(gemm(0, 1.0, 0.0, g2));
+      TMF_TRY(gemm(0, 1.0, 0.0, g2, cs_));
+      if (side) {
+        TMF_TRY(new_event(&centre_done));
+        LATER_HIP(hipEventRecord(centre_done, c.s_up));
+      }
     }
+    auto join_centre = [&]() {
+      if (centre_done) {
+        hipEvent_t ev = centre_done;
+        LATER_HIP(hipStreamWaitEvent(c.s_main, ev, 0));
+        centre_done = nullptr;
+      }
+    };
     // filled: Y = A Omega_f, projected off U_E and orthonormalised
     i64 maxnf = 0, maxcol = 0;
     for (i64 i = 0; i < ncs; ++i) maxnf = std::max(maxnf, c.nf[i]), maxcol = std::max(maxcol, ncolV[i]);
@@ -1218,6 +1243,7 @@ struct Sweep {
       const bool cholqr = !(c.par.flags & TMF_SWEEP_NO_CHOLQR);
       const bool two_streams = !s[0].empty() && !s[1].empty() && !(c.par.flags & TMF_SWEEP_ONE_STREAM);
       const bool fused = !(c.par.flags & TMF_SWEEP_UNFUSED_BCGS);
+      join_centre();
       if (two_streams) {
         TMF_TRY(bcgs(s[1], passes, cholqr, wide, c.s_up, fused));
         TMF_TRY(bcgs(s[0], passes, cholqr, wide, nullptr, fused));
@@ -1230,6 +1256,7 @@ struct Sweep {
         TMF_TRY(bcgs(s[0], passes, cholqr, wide, nullptr, fused));
       }
     }
+    join_centre();
     // self-check of the centre cut (testing.py:131-177; slater.py:419-420 runs it only there)
     c.n_checks = 0;
     c.d_chk = nullptr;
@@ -1254,7 +1281,17 @@ struct Sweep {
       // may have been handed to the sweep after next)
       TMF_TRY(acquire_slot(0));
       void* chk = c.slot->d_chk;
-      LATER_HIP(hipMemsetAsync(chk, 0, 64, c.s_main));
+      // (0.19 ms on ONE cut: on the upload stream, beside the overlap products of all sites; the download and the reuse of
+      // this memory set wait for it)
+      const bool chk_side = !(c.par.flags & TMF_SWEEP_ONE_STREAM);
+      hipStream_t ks_ = chk_side ? c.s_up : c.s_main;
+      if (chk_side) {
+        hipEvent_t ev;
+        TMF_TRY(new_event(&ev));
+        LATER_HIP(hipEventRecord(ev, c.s_main));
+        LATER_HIP(hipStreamWaitEvent(c.s_up, ev, 0));
+      }
+      LATER_HIP(hipMemsetAsync(chk, 0, 64, ks_));
       c.d_chk = (char*)chk;
       tmf_recon_desc d[5];
       memset(d, 0, sizeof(d));
@@ -1281,7 +1318,12 @@ struct Sweep {
         TMF_TRY(up(d, sizeof(d), &t_d));
         TMF_TRY(up_vec(tiles, &t_t));
         const int ntile = (int)(tiles.size() / 3);
-        LATER(tmf_recon_error_batched(c.dtype, (const tmf_recon_desc*)t_d, (const int32_t*)t_t, ntile, c.s_main));
+        LATER(tmf_recon_error_batched(c.dtype, (const tmf_recon_desc*)t_d, (const int32_t*)t_t, ntile, ks_));
+      }
+      if (chk_side) {
+        TMF_TRY(new_event(&c.chk_done));
+        hipEvent_t ev = c.chk_done;
+        LATER_HIP(hipEventRecord(ev, c.s_up));
       }
       c.n_checks = 5;
     }
@@ -1733,6 +1775,10 @@ struct Sweep {
       }
     }
     {
+      if (c.chk_done) {
+        hipEvent_t ev = c.chk_done;
+        LATER_HIP(hipStreamWaitEvent(c.s_main, ev, 0));   // (long finished: the memory set is not reused under the self-check)
+      }
       hipEvent_t done_ = c.set_done[c.cur];
       LATER_HIP(hipEventRecord(done_, c.s_main));  // every kernel of this sweep is enqueued
     }

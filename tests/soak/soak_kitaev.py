@@ -38,11 +38,24 @@ for seed in range(first, first + n_cases):
                 refused += 1
                 continue
             mps = pfaffian.C_to_MPS(C, {"chi_max": chi}, basis="M", ortho_center=oc)
-            cuts, _sites = tp.porc.c_to_mps(C, {"chi_max": chi}, oc)
+            try:
+                cuts, _sites = tp.porc.c_to_mps(C, {"chi_max": chi}, oc)
+            except AssertionError:      # the reference's own consistency assertions (pfaffian.py:795-805) fail on an eigenvalue
+                refused += 1            # within rounding of the cutoff: it refuses the input, nothing to compare with
+                continue
+            event = False
             for b in range(L + 1):
                 ea, eo = np.asarray(mps.bonds[b].e), np.asarray(cuts[b].e)
+                if ea.shape != eo.shape:
+                    # threshold event (i) of DESIGN section 2: an eigenvalue within rounding of the cutoff svd_min^2 = 1e-12
+                    big = eo if len(eo) > len(ea) else ea
+                    if np.abs(big - 1e-12).min() < 1e-15:
+                        event = True
+                        continue
                 if ea.shape != eo.shape or np.abs(ea - eo).max(initial=0) > 1e-12:
                     raise AssertionError(f"bond {b}: eigenvalues differ ({ea.shape} vs {eo.shape})")
+                if event:
+                    continue
                 if (mps.bonds[b].pL + mps.bonds[b].pR) % 2 != (cuts[b].pL + cuts[b].pR) % 2:
                     raise AssertionError(f"bond {b}: total parity differs")
                 la, lo = np.sort(mps.bonds[b].lam), np.sort(cuts[b].lam)
