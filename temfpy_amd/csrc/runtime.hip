@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256) void norms_kernel(const tmf_norms_desc* __rest
   const T* __restrict__ src = reinterpret_cast<const T*>(d.src);
   double* __restrict__ out = reinterpret_cast<double*>(d.out);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = wave; c < d.c; c += 4) {  // one wavefront per column
+  // one wavefront per column; gridDim.y workgroups share the columns of a problem (few problems: a rank's shard)
+  for (int c = wave + 4 * blockIdx.y; c < d.c; c += 4 * gridDim.y) {
     double s = 0.0;
     for (int r = lane; r < d.n; r += 64) s += sc<T>::abs2(src[(size_t)r + (size_t)c * d.lds_]);
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -399,10 +400,12 @@ extern "C" int tmf_normalise_columns_batched(int dtype, const tmf_colnorm_desc* 
 extern "C" int tmf_column_norms_batched(int dtype, const tmf_norms_desc* d_desc, int nprob, void* stream) {
   if (nprob <= 0) return TMF_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  int gy = 2048 / nprob;
+  gy = gy < 1 ? 1 : (gy > 32 ? 32 : gy);
   if (dtype == TMF_C128)
-    hipLaunchKernelGGL(norms_kernel<cd>, dim3(nprob), dim3(256), 0, s, d_desc);
+    hipLaunchKernelGGL(norms_kernel<cd>, dim3(nprob, gy), dim3(256), 0, s, d_desc);
   else if (dtype == TMF_F64)
-    hipLaunchKernelGGL(norms_kernel<double>, dim3(nprob), dim3(256), 0, s, d_desc);
+    hipLaunchKernelGGL(norms_kernel<double>, dim3(nprob, gy), dim3(256), 0, s, d_desc);
   else {
     set_error("tmf_column_norms_batched: bad dtype %d", dtype);
     return TMF_E_ARG;
