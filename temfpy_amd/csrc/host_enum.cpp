@@ -200,13 +200,27 @@ extern "C" int tmf_cut_vectors(const double* e, int k, int filled_left, int64_t 
   // (threshold events).  Two sweeps over different matrices that contain the same cut (C_to_MPS of the
   // short chain and C_to_iMPS, src/examples/iMPS.py:27-38) must still number them alike, so inside a charge sector runs of
   // patterns whose sums agree to 1e-10 are put in ascending order of their masks.  TMF_TIE_ORDER=0 keeps the heap's order.
+  // "Agree" is meant up to what the eigenvalues themselves carry: e is known to ~4e-15 absolutely, so
+  // a_i = ln((1 - e_i) / e_i) / 2 to da_i = 2e-15 / min(e_i, 1 - e_i), and two patterns are tied when their sums differ by
+  // less than the da of the orbitals in which they differ (an orbital of weight 1e-10 and its particle-hole partner give
+  // partner patterns whose weights differ by 5e-6 relatively - by rounding alone, and differently in every sweep).
   static const bool tie_order = !(getenv("TMF_TIE_ORDER") && atoi(getenv("TMF_TIE_ORDER")) == 0);
+  double da[128];
+  for (int i = 0; i < k; ++i) da[i] = 2e-15 / std::max(std::min(e[i], 1.0 - e[i]), 1e-300);
+  auto tied = [&](int64_t x, int64_t y) {
+    const Mask& p = sets[x];
+    const Mask& q = sets[y];
+    if (p.count() != q.count()) return false;
+    uint64_t dl = p.lo ^ q.lo, dh = p.hi ^ q.hi;
+    double tol = 1e-10 * std::max(1.0, fabs(sums[x]));
+    for (; dl; dl &= dl - 1) tol += da[__builtin_ctzll(dl)];
+    for (; dh; dh &= dh - 1) tol += da[64 + __builtin_ctzll(dh)];
+    return fabs(sums[y] - sums[x]) <= tol;
+  };
   if (tie_order)
     for (int64_t a = 0; a < cut;) {
       int64_t b = a;
-      while (b + 1 < cut && sets[ord[b + 1]].count() == sets[ord[a]].count() &&
-             fabs(sums[ord[b + 1]] - sums[ord[b]]) <= 1e-10 * std::max(1.0, fabs(sums[ord[b]])))
-        ++b;
+      while (b + 1 < cut && tied(ord[b], ord[b + 1])) ++b;
       if (b > a)
         std::sort(ord.begin() + a, ord.begin() + b + 1, [&](int64_t x, int64_t y) {
           return sets[x].hi != sets[y].hi ? sets[x].hi < sets[y].hi : sets[x].lo < sets[y].lo;

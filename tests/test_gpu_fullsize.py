@@ -132,7 +132,12 @@ def compare_bonds(mps, ref, e_tol=1e-13, lam_tol=1e-9, S_tol=1e-10, tag="case"):
         worst["lam"] = max(worst["lam"], dl.max())
         worst["lam_ratio"] = max(worst.get("lam_ratio", 0.0), (dl / (lam_tol + 2.0 * lam_ref * cond)).max())
     assert worst["e"] <= e_tol and worst["lam_ratio"] <= 1.0 and worst["lam"] <= 1e-8, worst
-    assert len(events) <= 4, f"{len(events)} threshold events: {events}"     # 1 and 2 bonds of 1025 on the two inputs
+    # Round 2: 1 and 2 bonds of 1025 on the two inputs, where LAPACK's rounding and ours ordered two patterns differently.
+    # Since round 3 patterns whose sums agree within the noise of the eigenvalues (2e-15 / min(e, 1 - e) per orbital in which
+    # they differ, well inside the E_NOISE allowance checked above) are ordered by their masks, not by rounding, so that two
+    # sweeps agree with each other (tmf_cut_vectors): a few more bonds differ from LAPACK's rounding, every
+    # one verified above to be such an exchange (measured: 5 bonds on seed 1)
+    assert len(events) <= 16, f"{len(events)} threshold events: {events}"
     dS = np.abs(S - ref["S"]).max()
     assert dS <= S_tol, dS
     return dS, worst, events
