@@ -376,6 +376,10 @@ typedef struct {
   int32_t n, c, lda, ldq, ldr, flags;
 } tmf_slab_desc;             /* 48 bytes */
 int tmf_house_slab_batched(int dtype, const tmf_slab_desc* d_desc, int nprob, int max_n, int max_c, void* stream);
+/* The same, with every column of a block in registers when all blocks of the launch are real and at most 256 x 128
+ * (else the panel kernel): which kernel runs then depends on the launch, so not for callers that need a slab's result to be
+ * independent of its batch (the sharded sweep).  Used by the canonicalisation sweeps of gutzwiller.py:266 / :471. */
+int tmf_house_qr_regs_batched(int dtype, const tmf_slab_desc* d_desc, int nprob, int max_n, int max_c, void* stream);
 /* diagnostics (TMF_SLAB_STAMPS=1): cycles per phase of one wavefront [0..7], workgroups, rows [8, 9]; clears */
 int tmf_house_slab_stamps(uint64_t* out16);
 

@@ -668,11 +668,14 @@ __device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det
         acc[1] += t - tq, tq = t;
         for (int k = 0; k < 8; ++k) hist[k] += __popcll(__ballot(live && (k < 7 ? dd == k : dd >= 7)));
       }
-      const bool slow = live && dd > 4;
+      // (order 5 by the same closed form as the classed pair phase of the 32-bit kernel: the two kernels must do the same
+      // arithmetic pair by pair - which of them runs depends on the widest sector of the LAUNCH, and a rank's shard has to
+      // reproduce the unsharded conversion bit for bit, tests/soak/soak_shards.py seed 60313)
+      const bool slow = live && dd > (FAST ? 4 : 5);   // (the 32-bit kernel comes here only for sectors of more than 2048 ket sets, which the drivers give to the 64-bit kernel: keeping the order-5 form out of it keeps its registers at three wavefronts per SIMD)
       if (live && !slow) {
-        int iv[4], jv[4];
+        int iv[5], jv[5];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 5; ++t) {
           iv[t] = 0, jv[t] = 0;
           if (t < dd) {
             iv[t] = mk<M>::ffs(Rm) - 1;
@@ -718,6 +721,38 @@ __device__ __attribute__((always_inline)) inline void ppt_det_body(const tmf_det
           det = sc<T>::fmac(det, p12, sc<T>::fms(sc<T>::mul(c0, e3), e0, c3));
           det = sc<T>::fms(det, p13, sc<T>::fms(sc<T>::mul(c0, e2), e0, c2));
           det = sc<T>::fmac(det, p23, sc<T>::fms(sc<T>::mul(c0, e1), e0, c1));
+        } else if (!FAST && dd == 5) {      // expansion along the first column, five minors of order 4 (as in the classed phase)
+          auto det4g = [&](const int* ir, const int* jc) -> T {
+            T p01, p02, p03, p12, p13, p23;
+            {
+              const T a0 = Gm[ir[0] + jc[0]], a1 = Gm[ir[1] + jc[0]], a2 = Gm[ir[2] + jc[0]], a3 = Gm[ir[3] + jc[0]];
+              const T b0_ = Gm[ir[0] + jc[1]], b1 = Gm[ir[1] + jc[1]], b2 = Gm[ir[2] + jc[1]], b3 = Gm[ir[3] + jc[1]];
+              p01 = sc<T>::fms(sc<T>::mul(a0, b1), b0_, a1);
+              p02 = sc<T>::fms(sc<T>::mul(a0, b2), b0_, a2);
+              p03 = sc<T>::fms(sc<T>::mul(a0, b3), b0_, a3);
+              p12 = sc<T>::fms(sc<T>::mul(a1, b2), b1, a2);
+              p13 = sc<T>::fms(sc<T>::mul(a1, b3), b1, a3);
+              p23 = sc<T>::fms(sc<T>::mul(a2, b3), b2, a3);
+            }
+            const T c0 = Gm[ir[0] + jc[2]], c1 = Gm[ir[1] + jc[2]], c2 = Gm[ir[2] + jc[2]], c3 = Gm[ir[3] + jc[2]];
+            const T e0 = Gm[ir[0] + jc[3]], e1 = Gm[ir[1] + jc[3]], e2 = Gm[ir[2] + jc[3]], e3 = Gm[ir[3] + jc[3]];
+            T d4 = sc<T>::mul(p01, sc<T>::fms(sc<T>::mul(c2, e3), e2, c3));
+            d4 = sc<T>::fms(d4, p02, sc<T>::fms(sc<T>::mul(c1, e3), e1, c3));
+            d4 = sc<T>::fmac(d4, p03, sc<T>::fms(sc<T>::mul(c1, e2), e1, c2));
+            d4 = sc<T>::fmac(d4, p12, sc<T>::fms(sc<T>::mul(c0, e3), e0, c3));
+            d4 = sc<T>::fms(d4, p13, sc<T>::fms(sc<T>::mul(c0, e2), e0, c2));
+            d4 = sc<T>::fmac(d4, p23, sc<T>::fms(sc<T>::mul(c0, e1), e0, c1));
+            return d4;
+          };
+          det = sc<T>::zero();
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            int ir[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ir[t] = iv[t + (t >= i)];
+            const T mi = sc<T>::mul(Gm[iv[i] + jv[0]], det4g(ir, jv + 1));      // (the same expression as in the classed phase)
+            det = (i & 1) ? sc<T>::sub(det, mi) : sc<T>::add(det, mi);
+          }
         }
         T v = sc<T>::mul(pref_fac, det);
         if (par & 1) v = sc<T>::neg(v);

@@ -457,7 +457,22 @@ extern "C" int tmf_house_slab_stamps(uint64_t* out16) {
   return TMF_OK;
 }
 
+static int house_slab_launch(int dtype, const tmf_slab_desc* d_desc, int nprob, int max_n, int max_c, void* stream, bool use_reg);
+
+// The panel kernel only: its arithmetic per slab does not depend on what else is in the launch (a rank's shard must
+// reproduce the unsharded conversion bit for bit; found by tests/soak/soak_shards.py seed 60313 when the
+// register form below was chosen by the launch's largest slab).
 extern "C" int tmf_house_slab_batched(int dtype, const tmf_slab_desc* d_desc, int nprob, int max_n, int max_c, void* stream) {
+  return house_slab_launch(dtype, d_desc, nprob, max_n, max_c, stream, false);
+}
+// The same factorisation with every column in registers when the LAUNCH allows it (real, <= 256 x 128), else the panel
+// kernel: for callers without that requirement (the canonicalisation sweeps of gutzwiller.py).  TMF_SLAB_REG=0: never.
+extern "C" int tmf_house_qr_regs_batched(int dtype, const tmf_slab_desc* d_desc, int nprob, int max_n, int max_c, void* stream) {
+  static const bool allow = !(getenv("TMF_SLAB_REG") && atoi(getenv("TMF_SLAB_REG")) == 0);
+  return house_slab_launch(dtype, d_desc, nprob, max_n, max_c, stream, allow);
+}
+
+static int house_slab_launch(int dtype, const tmf_slab_desc* d_desc, int nprob, int max_n, int max_c, void* stream, bool use_reg) {
   using namespace tmf;
   if (nprob <= 0) return TMF_OK;
   const size_t elem = (dtype == TMF_C128) ? 16 : 8;
@@ -481,7 +496,6 @@ extern "C" int tmf_house_slab_batched(int dtype, const tmf_slab_desc* d_desc, in
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   // blocks whose columns all fit the registers of one workgroup: no panels, one barrier per column (house_reg_kernel)
-  static const bool use_reg = !(getenv("TMF_SLAB_REG") && atoi(getenv("TMF_SLAB_REG")) == 0);
   if (use_reg) {
 #define TMF_REG_TRY(T, RM, CW, NW_)                                                                                         \
     if (max_n <= 64 * RM && max_c <= NW_ * CW) {                                                                              \

@@ -1645,9 +1645,15 @@ struct Sweep {
           TMF_TRY(new_event(&ev.e1));
           LATER_HIP(hipEventRecord(ev.e0, c.s_main));
         }
+        // mask width of the launch: 32 bits when every sector fits them AND no sector has more than 2048 ket sets (the
+        // 32-bit kernel would take those on its unclassed path, which sends order-5 pairs to the queue; the 64-bit kernel
+        // uses the closed form of the classed phase there: pair by pair the same arithmetic whichever kernel runs)
         i64 widest = 0;
         for (i64 j = 0; j < ns; ++j) widest = std::max(widest, std::max(sbv[j], skv[j]));
-        const int mbits = widest <= 32 ? 32 : 64;
+        for (size_t q = 0; q + 1 < c.sec_buf.size(); ++q)
+          if (c.sec_buf[q].c1 - c.sec_buf[q].c0 > 2048) widest = std::max<i64>(widest, 33);
+        static const int force_bits = getenv("TMF_PPT_MASK_BITS") ? atoi(getenv("TMF_PPT_MASK_BITS")) : 0;   // (A/B switch)
+        const int mbits = force_bits == 64 ? 64 : (widest <= 32 ? 32 : 64);
         LATER(tmf_det_ppt_batched_w(c.dtype, (const tmf_det_desc*)t_dd, (int)nt, lds_max, mbits, c.s_main));
         if (timing()) {
           LATER_HIP(hipEventRecord(ev.e1, c.s_main));

@@ -1436,6 +1436,8 @@ class Engine:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record(torch.cuda.current_stream(self.device))
                 widest = int(max(souts["sb"].max(initial=0), souts["sk"].max(initial=0)))    # as csrc/sweep.cpp: mask width of the launch
+                if int((sec_buf["c1"] - sec_buf["c0"]).max(initial=0)) > 2048:
+                    widest = max(widest, 33)
                 nat.check(self.lib.tmf_det_ppt_batched_w(self.dtype, t_dd.data_ptr(), nt, int(lds_max[0]), 32 if widest <= 32 else 64,
                                                          self.stream), "tmf_det_ppt_batched")
                 ev1.record(torch.cuda.current_stream(self.device))

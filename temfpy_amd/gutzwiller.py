@@ -828,8 +828,8 @@ class _Projector:
         def qr(i, st_):
             o, n = QR.spans[i]
             if use_slab:
-                nat.check(lib.tmf_house_slab_batched(self.dt, t_sl.data_ptr() + 48 * o, n, qr_max[i][0], qr_max[i][1], st_),
-                          "tmf_house_slab_batched")
+                nat.check(lib.tmf_house_qr_regs_batched(self.dt, t_sl.data_ptr() + 48 * o, n, qr_max[i][0], qr_max[i][1], st_),
+                          "tmf_house_qr_regs_batched")
                 return
             nat.check(lib.tmf_house_qr_batched(self.dt, tabs_d["qr"].data_ptr() + 40 * o, n, qr_max[i][0], qr_max[i][1],
                                                st_), "tmf_house_qr_batched")

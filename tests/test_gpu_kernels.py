@@ -1048,6 +1048,45 @@ def test_house_slab_qr(eng, cplx):
         np.testing.assert_allclose(Q @ (Q.conj().T @ A), A, rtol=0, atol=1e-13 * scale * n ** 0.5)   # span(Q) contains A
 
 
+@pytest.mark.parametrize("shape", [(220, 110), (256, 128), (100, 40), (128, 128), (250, 112), (64, 90), (7, 3), (130, 0)])
+def test_house_qr_with_all_columns_in_registers(eng, shape):
+    """tmf_house_qr_regs_batched (house_reg_kernel: every column of a real block of at most 256 x 128 in registers, the form
+    the Gutzwiller canonicalisation sweeps use): thin Q into the scratch, R, against the defining properties; mixed launches
+    (several blocks of different sizes, one of them rank deficient, one R-only)."""
+    setup(eng, False)
+    nat, lib = eng.nat, eng.lib
+    rng = np.random.default_rng(shape[0] * 131 + shape[1])
+    n, c = shape
+    mats = [rnd(rng, (n, c), False), rnd(rng, (max(n // 2, 1), max(c // 2, 1)), False)]
+    if c >= 8:
+        mats.append(rnd(rng, (n, 5), False) @ rnd(rng, (5, c), False))        # rank 5
+    dA, dQ, dR, d = [], [], [], np.zeros(len(mats), nat.slab_desc)
+    for i, A in enumerate(mats):
+        m_, c_ = A.shape
+        dA.append(torch.from_numpy(np.ascontiguousarray(A.T).reshape(-1).copy()).to("cuda:0"))
+        dQ.append(torch.zeros(m_ * c_ + 2, dtype=torch.float64, device="cuda:0"))
+        dR.append(torch.zeros(c_ * c_ + 2, dtype=torch.float64, device="cuda:0"))
+        d[i] = (dA[i].data_ptr(), dQ[i].data_ptr(), dR[i].data_ptr(), m_, c_, m_, m_, c_, 4 if i == 1 else 2)    # block 1: R only
+    dd = torch.from_numpy(d.view(np.uint8).copy()).to("cuda:0")
+    nat.check(lib.tmf_house_qr_regs_batched(nat.TMF_F64, dd.data_ptr(), len(mats), max(a.shape[0] for a in mats),
+                                            max(a.shape[1] for a in mats), eng.stream), "tmf_house_qr_regs_batched")
+    torch.cuda.synchronize()
+    for i, A in enumerate(mats):
+        m_, c_ = A.shape
+        if c_ == 0:
+            continue
+        R = dR[i].cpu().numpy()[: c_ * c_].reshape(c_, c_).T
+        scale = max(np.abs(A).max(), 1e-300)
+        assert np.isfinite(R).all() and np.allclose(np.tril(R, -1), 0)
+        np.testing.assert_allclose(R.T @ R, A.T @ A, rtol=0, atol=1e-13 * scale ** 2 * max(m_, c_))
+        if i == 1:
+            continue
+        Q = dQ[i].cpu().numpy()[: m_ * c_].reshape(c_, m_).T
+        K = min(m_, c_)
+        np.testing.assert_allclose(Q[:, :K].T @ Q[:, :K], np.eye(K), rtol=0, atol=1e-13)
+        np.testing.assert_allclose(Q[:, :K] @ R[:K], A, rtol=0, atol=1e-13 * scale * max(m_, c_))
+
+
 def test_export_words_verdict_and_conditional_launches(eng):
     """Plumbing of the block-local elimination: tmf_export_words (device -> page-locked host memory by a kernel),
     tmf_diag_inverse_verdict (statistics -> device flag + summary in host memory) and tmf_launch_condition (GEMM / gather /
@@ -1177,7 +1216,7 @@ def test_jacobi_every_small_size(eng, cplx, left_only):
             np.testing.assert_allclose(np.linalg.norm(X @ O, axis=0), s, rtol=1e-11, atol=1e-14)
 
 
-@pytest.mark.parametrize("kernel", ["tmf_house_qr_batched", "tmf_house_slab_batched"])
+@pytest.mark.parametrize("kernel", ["tmf_house_qr_batched", "tmf_house_slab_batched", "tmf_house_qr_regs_batched"])
 def test_householder_far_past_the_rank(eng, kernel):
     """Householder QR of exactly rank-deficient blocks with many more steps than rank (Gutzwiller-projected tensors: zero rows,
     rank 4 of 16 x 19): past the rank every step works on the rounding noise of the previous one, whose squared length
@@ -1209,7 +1248,7 @@ def test_householder_far_past_the_rank(eng, kernel):
             d = np.zeros(1, eng.nat.slab_desc)
             d[0] = (dA.data_ptr(), dQ.data_ptr(), dR.data_ptr(), m, n, m, m, n, 0)
             dd = torch.from_numpy(d.view(np.uint8).copy()).to("cuda:0")
-            eng.nat.check(lib.tmf_house_slab_batched(dt, dd.data_ptr(), 1, m, n, st), kernel)
+            eng.nat.check(getattr(lib, kernel)(dt, dd.data_ptr(), 1, m, n, st), kernel)
         torch.cuda.synchronize()
         R = dR.cpu().numpy().reshape(n, n).T
         Q = dA.cpu().numpy().reshape(n, m).T

@@ -8,6 +8,7 @@ for non-degenerate spectra; for exactly degenerate spectra the order inside a de
 multiplet depends on rounding noise (also in the reference), so they are compared as sets
 and through gauge-invariant quantities."""
 import os
+import warnings
 
 import numpy as np
 import pytest
@@ -211,6 +212,38 @@ def test_site_sharding_reproduces_unsharded_result_bitwise():
             for b in range(lo, hi + 1):
                 assert np.array_equal(part.bonds[b].lam, full.bonds[b].lam)
                 assert np.array_equal(part.bonds[b].masks, full.bonds[b].masks)
+
+
+def test_site_sharding_bitwise_when_shards_take_other_kernel_variants():
+    """tests/soak/soak_shards.py seed 60313 (round 3): a real spinful chain of 122 sites, chi_max 300, cut into the ranges
+    (0, 1), (1, 7), (7, 122).  The short ranges next to the chain's end have only small charge sectors, so their launches
+    choose the 32-bit-mask determinant kernel (and, until this was separated, the register form of the slab QR) where the
+    unsharded conversion uses the 64-bit one: the variants must do the same arithmetic pair by pair - they differed by 1 ulp in
+    pairs of order 5 (closed form in one kernel, queued elimination in the other)."""
+    from temfpy_amd import slater
+    from temfpy_amd.engine import Engine
+    from temfpy_amd.schmidt_utils import to_stopping_condition
+
+    rng = np.random.default_rng(60313)
+    L = int(rng.integers(4, 65)); rng_h = float(rng.choice([0.7, 1.5, 3.0, 6.0])); cplx = bool(rng.integers(0, 2))
+    x, y = np.meshgrid(np.arange(L), np.arange(L), indexing="ij")
+    M = rng.normal(size=(2, L, L)) * np.exp(-abs(x - y) / rng_h)
+    H = M[0] + (1j * M[1] if cplx else 0)
+    H = H + H.conj().T
+    assert (L, cplx) == (61, False)
+    C, _ = slater.correlation_matrix(H)
+    C = slater.spinful_correlation_matrix(C, True)
+    Lf, oc = len(C), 61
+    tr = to_stopping_condition({"chi_max": 300})
+    eng = Engine("cuda:0")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        full = eng.run(C, tr, oc, Lf)
+        for (lo, hi) in [(0, 1), (1, 7), (7, 40)]:
+            part = eng.run(C, tr, oc, Lf, site_range=(lo, hi))
+            for i in range(lo, hi):
+                for bp, bf in zip(part.sites[i].blocks, full.sites[i].blocks):
+                    assert bp[:5] == bf[:5] and np.array_equal(bp[5], bf[5]), (lo, hi, i, bp[:5])
 
 
 def test_site_sharding_bitwise_on_the_wide_range_finder():
