@@ -1112,7 +1112,7 @@ struct Sweep {
         for (i64 j = 0; j < c.k[i]; ++j) {
           // (a group = eigenvalues C does not tell apart: rounding noise, or 1e-9 of their distance from 0 / 1)
           const double w = j > 0 ? std::min(std::min(e[(size_t)j], 1.0 - e[(size_t)j]), std::min(e[(size_t)j - 1], 1.0 - e[(size_t)j - 1])) : 0.0;
-          start[(size_t)j] = (j > 0 && !(fabs(e[(size_t)j] - e[(size_t)j - 1]) > 1e-14 + GAUGE_GROUP_TOL * w)) ? start[(size_t)j - 1] : (int32_t)j;
+          start[(size_t)j] = (j > 0 && !(fabs(e[(size_t)j] - e[(size_t)j - 1]) > 1e-13 + GAUGE_GROUP_TOL * w)) ? start[(size_t)j - 1] : (int32_t)j;
         }
         tmf_gauge_desc q{};
         TMF_TRY(up_vec(start, &q.start));

@@ -1226,7 +1226,7 @@ class Engine:
                 st_ = np.arange(len(e_), dtype=np.int32)
                 for j_ in range(1, len(e_)):
                     w_ = min(min(e_[j_], 1.0 - e_[j_]), min(e_[j_ - 1], 1.0 - e_[j_ - 1]))
-                    if not abs(e_[j_] - e_[j_ - 1]) > 1e-14 + 1e-9 * w_:
+                    if not abs(e_[j_] - e_[j_ - 1]) > 1e-13 + 1e-9 * w_:
                         st_[j_] = st_[j_ - 1]
                 starts.append(st_)
             t_st = self._up(np.concatenate(starts))
