@@ -396,7 +396,8 @@ def main():
         n_l = int(np.mean(gemm_n))
         g_ms, g_fl = float(np.mean(gemm_ms)), float(np.mean(gemm_fl))
         ach = g_fl / (g_ms * 1e-3) / 1e12
-        kk = [pmc_k.get("tmf::gemm_kernel<tmf::cd, %d, 64>" % o) for o in (0, 1)]
+        # (kernel names as rocprofv3 prints them: the 3M / 4M switch is a fourth template argument since round 3)
+        kk = [pmc_k.get("tmf::gemm_kernel<tmf::cd, %d, 64, false>" % o) or pmc_k.get("tmf::gemm_kernel<tmf::cd, %d, 64>" % o) for o in (0, 1)]
         traffic = None
         if all(kk):
             traffic = round(sum(k_["hbm_bytes_per_launch"] * k_["launches"] for k_ in kk) / sum(k_["launches"] for k_ in kk))
