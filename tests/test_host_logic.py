@@ -396,3 +396,83 @@ def test_infinite_cell_adapter_labels():
     cell.form = ["B", None]
     with pytest.raises(ValueError, match="right-canonical"):
         _fermions_from_imps(cell)
+
+
+def test_site_prepare_without_physical_leg_matches_oracle():
+    """tmf_site_prepare with mode bit 1 (two bases of the SAME orbitals, slater.py:1023-1024: the gauge overlaps of
+    ``C_to_iMPS``, slater.py:1538): bra rows are the bra Schmidt vectors themselves (no doubling, no re-sorting), the always /
+    sometimes split, signs, Schur complement and index lists against the oracle's ``site_tensor(short, long, "left")``."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_imps import ssh
+
+    L, cell, cut, chi = 20, 2, 10, 24
+    Cs, _ = orc.correlation_matrix(ssh(L))
+    Cl, _ = orc.correlation_matrix(ssh(L + cell))
+    tr = orc.as_trunc({"chi_max": chi})
+    bra, ket = orc.cut_vectors(Cs, cut, tr, "LR"), orc.cut_vectors(Cl, cut, tr, "LR")
+    for mode, side in ((0, "L"),):
+        s = orc.site_tensor(bra, ket, "left")
+        Vb, nfb = _device_layout(bra, side)
+        Vk, nfk = _device_layout(ket, side)
+        qb = bra.n_filled("L") + bra.sets.sum(axis=1)
+        qk = ket.n_filled("L") + ket.sets.sum(axis=1)
+        r = nat.site_prepare(mode | 2, bra.k, nfb, _masks(bra), qb, ket.k, nfk, _masks(ket), qk)
+        chi_b = len(bra.lam)
+        np.testing.assert_array_equal(r["bra_p"][:chi_b], 0)
+        np.testing.assert_array_equal(r["bra_alpha"][:chi_b], np.arange(chi_b))
+        assert (r["sb"], r["sk"]) == s.M.shape
+        assert not np.any(r["row_sel"] < 0)                      # no physical orbital anywhere
+        Ofull = Vb.conj().T @ Vk
+        W = np.zeros((r["mb"], r["mk"]), complex)
+        for a, (rs, sg) in enumerate(zip(r["row_sel"], r["row_sign"])):
+            W[a] = sg * Ofull[rs, r["col_sel"]] * r["col_sign"]
+        k = r["k"]
+        det, M = (np.linalg.det(W[:k, :k]), W[k:, k:] - W[k:, :k] @ np.linalg.inv(W[:k, :k]) @ W[:k, k:]) if k else (1.0, W)
+        np.testing.assert_allclose(det, s.det_always, rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(M, s.M, rtol=0, atol=1e-10)
+        assert sorted(int(x) for x in r["sectors"]["q"]) == sorted(s.blocks)
+        for sec in r["sectors"]:
+            r0, r1, c0, c1, blk = s.blocks[int(sec["q"])]
+            assert (sec["r0"], sec["r1"], sec["c0"], sec["c1"]) == (r0, r1, c0, c1)
+
+
+def test_patterns_of_equal_weight_come_in_one_order_whatever_the_rounding():
+    """tmf_cut_vectors orders occupation patterns whose subset sums agree within the noise of the eigenvalues by their masks
+    (DESIGN 10.5): a particle-hole symmetric spectrum (e_i, 1 - e_i: partner patterns of equal weight) perturbed by 1e-15 in
+    ten different ways gives ten times the same list of patterns, also where a weak orbital (e = 1e-10: a_i uncertain by
+    1e-5) makes partner weights differ by parts per million; TMF_TIE_ORDER is read once per process, so the heap order is not
+    compared here."""
+    rng = np.random.default_rng(12)
+    half = np.array([0.31, 0.07, 2e-4, 1e-10])
+    e0 = np.sort(np.concatenate((half, 1.0 - half)))[::-1]
+    ref = None
+    for trial in range(10):
+        e = e0 + rng.uniform(-1, 1, e0.size) * 1e-15 * (trial > 0)
+        e = np.clip(e, 1e-300, 1.0 - 1e-17)
+        sets, lam, q, _ = nat.cut_vectors(e, 0, 60, 1e-6, 1e-12)
+        if ref is None:
+            ref = (sets.copy(), q.copy())
+            assert len(sets) > 20
+        else:
+            np.testing.assert_array_equal(q, ref[1])
+            np.testing.assert_array_equal(sets, ref[0])
+    # inside a charge sector the weights are still descending up to that noise
+    for c in np.unique(ref[1]):
+        w = lam[ref[1] == c]
+        assert np.all(np.diff(w) <= 1e-4 * w[:-1])
+
+
+def test_group_order_of_the_centre_cut():
+    """engine._group_order (= Sweep::group_order): inside runs of eigenvalues closer than the tolerance the columns go by
+    descending e (1 - e) (the order of the reference's group SVD, utils.py:66-94); exact multiplets and separated eigenvalues
+    stay."""
+    from temfpy_amd.engine import _group_order
+
+    e = np.array([1 - 1e-9, 1 - 3e-8, 1 - 4e-7, 0.9, 0.5, 0.2, 3e-7, 1e-8])
+    assert _group_order(e, 1e-12) is None
+    p = _group_order(e, 1e-6)
+    np.testing.assert_array_equal(p, [2, 1, 0, 3, 4, 5, 6, 7])        # the three next to 1 reversed, the two next to 0 already in order
+    assert _group_order(np.array([0.7, 0.7, 0.3, 0.3]), 1e-12) is None  # exact pairs keep their places
+    p = _group_order(np.array([0.6, 0.55, 0.52]), 0.1)
+    np.testing.assert_array_equal(p, [2, 1, 0])
