@@ -207,6 +207,13 @@ def load():
         _set_host_argtypes(lib)
         _LIB = lib
         return lib
+    # PyTorch ships its own HIP runtime.  Whichever of the two copies is loaded first serves the process; loaded second,
+    # /opt/rocm's reported "no ROCm-capable device" to this library (build() followed by smoke() in ONE process).  Every
+    # other entry path imports torch first - do the same here.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(_PATH):
         raise NativeError(
             f"{_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
