@@ -186,20 +186,21 @@ def _fermions_from_slater(mps):
     f.charges = [np.asarray(b.q_left, np.int64) for b in mps.bonds]
     f.lam_c = np.asarray(mps.bonds[mps.ortho_center].lam)
     recs, arrs = [], []
+    f.tabs = [_sector_table(q) for q in f.charges]        # (reused by _Projector.plan: 2 x L calls of numpy.unique less)
     for i, s in enumerate(mps.sites):
         left = s.mode == "left"
         bra_q = f.charges[i] if left else f.charges[i + 1]
-        bra_tab = _sector_table(bra_q)
+        bra_tab = f.tabs[i] if left else f.tabs[i + 1]
         for q, r0, r1, c0, c1, arr in s.blocks:
             c = c1 - c0
             pr = np.asarray(s.bra_p[r0:r1])
             al = np.asarray(s.bra_alpha[r0:r1])
-            for p in (0, 1):
-                idx = np.nonzero(pr == p)[0]
-                if idx.size == 0:
+            # rows of one sector: the p = 0 run, then the p = 1 run (stable sort of the merged leg by particle number)
+            k0 = int(np.count_nonzero(pr == 0))
+            assert not pr[:k0].any() and pr[k0:].all(), "rows of one physical state are contiguous inside a sector"
+            for p, ra, rb in ((0, 0, k0), (1, k0, len(pr))):
+                if rb == ra:
                     continue
-                ra, rb = int(idx[0]), int(idx[-1]) + 1
-                assert rb - ra == idx.size, "rows of one physical state are contiguous inside a sector"
                 qb = int(bra_q[al[ra]])
                 st, nb = bra_tab[qb]
                 assert al[ra] == st and rb - ra == nb, "a block spans whole charge sectors"
@@ -473,7 +474,7 @@ class _Projector:
     def plan(self):
         f = self.f
         Ls = f.L // 2
-        tabs = [_sector_table(q) for q in f.charges]
+        tabs = getattr(f, "tabs", None) or [_sector_table(q) for q in f.charges]
         blk = {}
         for k, r in enumerate(f.blocks):
             key = (int(r["site"]), int(r["p"]), int(r["cl"]))
