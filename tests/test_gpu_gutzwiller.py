@@ -265,6 +265,25 @@ def test_config5_full_size_properties():
     assert abs(S[255] - S[255 - 2]) < 0.5 and 0.5 < S[255] < 2.0          # log-law plateau of the projected chain
 
 
+def test_adapter_from_flat_tables_equals_the_per_site_adapter():
+    """gutzwiller._fermions_from_shard (all block records of a conversion at once from its flat tables) against the loop over
+    the per-site objects: the same records, offsets into the same page-locked buffer and charges."""
+    from temfpy_amd import gutzwiller, slater
+
+    for spinful, L in (("PH", 24), ("simple", 10), (None, 20)):
+        C, _ = slater.correlation_matrix(uniform_chain(L))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mps = slater.C_to_MPS(C, {"chi_max": 64}, spinful=spinful, as_tenpy=False, ortho_center=None if spinful else 7)
+        a, b = gutzwiller._fermions_from_shard(mps), gutzwiller._fermions_from_sites(mps)
+        assert a is not None and len(a.blocks) == len(b.blocks) > 0
+        key = lambda r: tuple(int(x) for x in r)      # noqa: E731
+        assert sorted(map(key, a.blocks)) == sorted(map(key, b.blocks))
+        assert [key(r) for r in a.blocks] == [key(r) for r in b.blocks]      # and in the same order
+        assert all(np.array_equal(x, y) for x, y in zip(a.charges, b.charges))
+        assert a.flat is b.flat and a.dtype == b.dtype and np.array_equal(a.lam_c, b.lam_c)
+
+
 def test_chi512_sample_against_oracle():
     """Config-5 bond dimension (chi_max = 512, 140-state charge sectors, the slab QR + preconditioned Jacobi
     path at full block size) on a 64-spin chain against the charge-block oracle: Schmidt values 1e-12 (default method:
