@@ -435,6 +435,16 @@ typedef struct {
 } tmf_colnorm_desc;          /* 40 bytes */
 int tmf_normalise_columns_batched(int dtype, const tmf_colnorm_desc* d_desc, int nprob, void* stream);
 
+/* Rescaling inside a chain of dependent factorisations (the QR sweeps of gutzwiller.py:266 / :471 through TeNPy's
+ * canonical_form_finite, which renormalises every step): all `nblk` blocks are multiplied by the SAME power of two 2^-e,
+ * e = exponent of their largest entry, so that the products of a long chain neither underflow nor overflow; e is added to
+ * the running sum *d_acc, whose new value is also written to *d_out (one slot per step).  Exact: powers of two. */
+typedef struct {
+  uint64_t A;
+  int32_t rows, cols, ld, pad;
+} tmf_rescale_desc;                /* 24 bytes */
+int tmf_rescale_pow2_batched(int dtype, const tmf_rescale_desc* d_desc, int nblk, int64_t* d_acc, int64_t* d_out, void* stream);
+
 /* Canonical gauge of the entangled orbitals of a cut side.  The reference takes whatever phases (and, inside an exactly
  * degenerate group, whatever basis) LAPACK's eigh returns, slater.py:347; its own example (src/examples/iMPS.py:27-38)
  * relies on two calls with the same matrix giving the same vectors.  Here the Ritz vectors of two sweeps differ by such a

@@ -48,6 +48,7 @@ det_desc = np.dtype([("S", "<u8"), ("scale", "<u8"), ("bra_idx", "<u8"), ("ket_i
 gather_desc = np.dtype([("src", "<u8"), ("dst", "<u8"), ("row_sel", "<u8"), ("col_sel", "<u8"),
                         ("row_sign", "<u8"), ("col_sign", "<u8"), ("phys", "<u8"), ("rows", "<i4"),
                         ("cols", "<i4"), ("lds_", "<i4"), ("ldd", "<i4"), ("ldp", "<i4"), ("pad", "<i4")])
+rescale_desc = np.dtype([("A", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("ld", "<i4"), ("pad", "<i4")])
 gauge_desc = np.dtype([("V", "<u8"), ("start", "<u8"), ("n", "<i4"), ("k", "<i4"), ("ld", "<i4"), ("from_top", "<i4")])
 colnorm_desc = np.dtype([("src", "<u8"), ("dst", "<u8"), ("n", "<i4"), ("c", "<i4"), ("lds_", "<i4"),
                          ("ldd", "<i4"), ("reverse", "<i4"), ("flip_odd", "<i4")])
@@ -91,7 +92,7 @@ SYMBOLS = [
     "tmf_jacobi_block_batched", "tmf_nested_products_batched", "tmf_recon_error_batched", "tmf_lu_schur_batched",
     "tmf_det_gather_batched", "tmf_det_reduced_batched", "tmf_det_ppt_batched", "tmf_det_ppt_batched_w", "tmf_det_ppt_stamps", "tmf_block_orth_batched", "tmf_house_slab_stamps", "tmf_pfaffian_sweep", "tmf_pf_result_dims", "tmf_pf_result_bond", "tmf_pf_result_site",
     "tmf_pf_result_block", "tmf_pf_result_checks", "tmf_pf_result_flat", "tmf_pf_result_download", "tmf_pf_result_free", "tmf_onishi_norms", "tmf_host_parallel_for", "tmf_gemm_set_4m", "tmf_block_orth_stamps", "tmf_transpose", "tmf_fill_normal",
-    "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_canonical_gauge_batched", "tmf_column_norms_batched", "tmf_cut_vectors",
+    "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_canonical_gauge_batched", "tmf_rescale_pow2_batched", "tmf_column_norms_batched", "tmf_cut_vectors",
     "tmf_site_prepare", "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_det_tiles_build", "tmf_pf_gather_batched",
     "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched", "tmf_copy_blocks_batched", "tmf_house_qr_batched", "tmf_jacobi_compact_batched", "tmf_house_slab_batched", "tmf_house_qr_regs_batched",
     "tmf_host_register", "tmf_host_unregister", "tmf_memcpy_async", "tmf_lu_block_batched", "tmf_lu_trsm_batched", "tmf_diag_inverse_batched", "tmf_diag_inverse_verdict", "tmf_launch_condition", "tmf_export_words",
@@ -255,6 +256,7 @@ def load():
     lib.tmf_gather_signed_batched.argtypes = [i32, vp, i32, vp]
     lib.tmf_normalise_columns_batched.argtypes = [i32, vp, i32, vp]
     lib.tmf_canonical_gauge_batched.argtypes = [i32, vp, i32, i32, i32, vp]
+    lib.tmf_rescale_pow2_batched.argtypes = [i32, vp, i32, vp, vp, vp]
     lib.tmf_column_norms_batched.argtypes = [i32, vp, i32, vp]
     _set_host_argtypes(lib)
     lib.tmf_lu_block_batched.argtypes = [i32, vp, i32, i32, i32, i32, vp]

@@ -237,6 +237,66 @@ extern "C" int tmf_gather_signed_batched(int dtype, const tmf_gather_desc* d_des
   return check_hip(hipGetLastError(), "tmf_gather_signed_batched");
 }
 
+// ---- common power-of-two rescaling of the blocks of one step (tmf_rescale_desc) --------------
+template <typename T>
+__global__ __launch_bounds__(1024) void rescale_pow2_kernel(const tmf_rescale_desc* __restrict__ desc, int nblk,
+                                                            long long* __restrict__ acc, long long* __restrict__ out) {
+  __shared__ double s_max[16];
+  __shared__ int s_e;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double m = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    const tmf_rescale_desc d = desc[b];
+    const T* __restrict__ A = reinterpret_cast<const T*>(d.A);
+    const int total = d.rows * d.cols;
+    for (int e = tid; e < total; e += 1024) {
+      const T v = A[(size_t)(e % d.rows) + (size_t)(e / d.rows) * d.ld];
+      m = fmax(m, fmax(fabs(sc<T>::real(v)), fabs(sc<T>::imag(v))));
+    }
+  }
+  m = wave_max64(m);
+  if (lane == 0) s_max[wave] = m;
+  __syncthreads();
+  if (tid == 0) {
+    double mm = 0.0;
+    for (int w = 0; w < 16; ++w) mm = fmax(mm, s_max[w]);
+    int e = 0;
+    if (mm > 0.0 && mm < 1.7e308) e = ilogb(mm);
+    s_e = e;
+    const long long a = *acc + e;
+    *acc = a;
+    if (out) *out = a;
+  }
+  __syncthreads();
+  const int e = s_e;
+  if (e == 0) return;
+  const double f = ldexp(1.0, -e);
+  for (int b = 0; b < nblk; ++b) {
+    const tmf_rescale_desc d = desc[b];
+    T* __restrict__ A = reinterpret_cast<T*>(d.A);
+    const int total = d.rows * d.cols;
+    for (int x = tid; x < total; x += 1024) {
+      const size_t o = (size_t)(x % d.rows) + (size_t)(x / d.rows) * d.ld;
+      A[o] = sc<T>::scale(A[o], f);
+    }
+  }
+}
+
+extern "C" int tmf_rescale_pow2_batched(int dtype, const tmf_rescale_desc* d_desc, int nblk, int64_t* d_acc, int64_t* d_out,
+                                        void* stream) {
+  if (nblk <= 0) return TMF_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == TMF_C128)
+    hipLaunchKernelGGL(rescale_pow2_kernel<cd>, dim3(1), dim3(1024), 0, s, d_desc, nblk, (long long*)d_acc, (long long*)d_out);
+  else if (dtype == TMF_F64)
+    hipLaunchKernelGGL(rescale_pow2_kernel<double>, dim3(1), dim3(1024), 0, s, d_desc, nblk, (long long*)d_acc, (long long*)d_out);
+  else {
+    set_error("tmf_rescale_pow2_batched: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+  return check_hip(hipGetLastError(), "tmf_rescale_pow2_batched");
+}
+
 // ---- canonical gauge of the entangled orbitals (tmf_gauge_desc) --------------------------
 namespace {
 constexpr int GAUGE_DMAX = 8;

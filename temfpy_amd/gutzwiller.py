@@ -750,7 +750,7 @@ class _Projector:
                                                     stream=stream, keep=keep_alive, Tping=Tping, Tpong=Tpong))
             self.timings["fixed points"] = time.perf_counter() - t1
             self.timings["cell applications"] = self.cell_applications
-        G, CP, QR = _Launches(nat.gemm_desc), _Launches(nat.copy_desc), _Launches(nat.qr_desc)
+        G, CP, QR, RS = _Launches(nat.gemm_desc), _Launches(nat.copy_desc), _Launches(nat.qr_desc), _Launches(nat.rescale_desc)
         steps1, steps2 = [], []
         # rightward sweep: V_j = R_j T_j (left-merged), QR in place, R -> bond j+1
         for j in range(Ls):
@@ -761,10 +761,12 @@ class _Projector:
                 n, npr = self.sect[j][c], self.sect[j + 1][cp_]
                 g.append((P(Rb[j][c]), P(Toff[(j, sg, c)]), P(voff + rows[(sg, c)]), n, npr, n, n, n, m))
             qd = np.zeros(len(Vinfo[j]), nat.qr_desc)
+            rs = np.zeros(len(Vinfo[j]), nat.rescale_desc)
             for i, (cp_, (voff, m, rows)) in enumerate(Vinfo[j].items()):
                 npr = self.sect[j + 1][cp_]
                 qd[i] = (P(voff), P(Rb[j + 1][cp_]), m, npr, m, npr, 0, 0)
-            steps1.append((G.add(_gemm_recs(g)), QR.add(qd)))
+                rs[i] = (P(Rb[j + 1][cp_]), npr, npr, npr, 0)
+            steps1.append((G.add(_gemm_recs(g)), QR.add(qd), RS.add(rs)))
         sv_ptr, cnt_ptr = d_sv.data_ptr(), d_cnt.data_ptr()
         jd, tail = np.zeros(n_sec_tot, nat.jacobi_desc), None
         for j in range(Ls + 1):
@@ -814,16 +816,19 @@ class _Projector:
                     cols = Winfo[j][c][2]
                     g.append((P(Toff[(j, sg, c)]), P(Lb[j + 1][cp_]), P(Wo + wl[c] + n * cols[(sg, cp_)]), n, npr, npr, n, npr, n))
                 qd = np.zeros(len(Winfo[j]), nat.qr_desc)
+                rs = np.zeros(len(Winfo[j]), nat.rescale_desc)
                 for i, (c, v) in enumerate(Winfo[j].items()):
                     n, w = self.sect[j][c], v[1]
                     cpy.append((P(Wo + wl[c]), P(Yq[j][c]), n, w, n, w, 3 if self.cplx else 1, 0))
                     qd[i] = (P(Yq[j][c]), P(Lb[j][c]), w, n, w, n, 1, 0)
-                steps2.append((G.add(_gemm_recs(g)), CP.add(np.array(cpy, nat.copy_desc)), QR.add(qd)))
+                    rs[i] = (P(Lb[j][c]), n, n, n, 0)
+                steps2.append((G.add(_gemm_recs(g)), CP.add(np.array(cpy, nat.copy_desc)), QR.add(qd), RS.add(rs)))
             # batched tail: C = R L / norm, SVD of every bond and sector at once, B^H = blockdiag(Vz_{j+1})^H (Q~ Vz_j)
-            gc, g1, g2 = [], [], []
+            gc, g1, g2, gc_bond = [], [], [], []
             for j in range(Ls + 1):
                 for c, n in self.sect[j].items():
                     gc.append((P(Rb[j][c]), P(Lb[j][c]), P(Cb[j][c]), n, n, n, n, n, n))
+                    gc_bond.append(j)
             for j in range(Ls):
                 for c, v in Winfo[j].items():
                     n, w = self.sect[j][c], v[1]
@@ -849,7 +854,7 @@ class _Projector:
             tile_n.append(tn)
             to += len(tl)
         tiles = np.concatenate(tiles) if tiles else np.zeros((0, 4), np.int32)
-        tabs_h = {"g": gt, "t": tiles, "cp": CP.table(), "qr": QR.table(), "jc": jd}
+        tabs_h = {"g": gt, "t": tiles, "cp": CP.table(), "qr": QR.table(), "jc": jd, "rs": RS.table()}
         tabs_d = {k: torch.from_numpy(v.view(np.uint8).reshape(-1).copy() if v.size else np.zeros(16, np.uint8)).to(self.device)
                   for k, v in tabs_h.items()}
         keep_alive.append(tabs_d)
@@ -901,18 +906,41 @@ class _Projector:
             nat.check(lib.tmf_house_qr_batched(self.dt, tabs_d["qr"].data_ptr() + 40 * o, n, qr_max[i][0], qr_max[i][1],
                                                st_), "tmf_house_qr_batched")
 
+        # Power-of-two rescaling of the triangular factors after every step (TeNPy's canonical_form_finite renormalises every
+        # step): the norm of the projected state falls by a constant factor per site and would leave the range of a double
+        # after ~1300 spins.  exps[0 / 1]: running exponents of the two sweeps; exps[2 + j] / exps[2 + Ls + 1 + j]: their values
+        # when R_j / L_j were written.  (Infinite cells are short: not rescaled.)
+        d_exp = torch.zeros(2 + 2 * (Ls + 1), dtype=torch.int64, device=self.device)
+        keep_alive.append(d_exp)
+        rescaling = self.shift is None and os.environ.get("TMF_GW_RESCALE", "1") != "0"
+
+        def rescale(i, st_, sweep, bond):
+            if not rescaling:
+                return
+            o, n = RS.spans[i]
+            slot = 2 + sweep * (Ls + 1) + bond
+            nat.check(lib.tmf_rescale_pow2_batched(self.dt, tabs_d["rs"].data_ptr() + 24 * o, n, d_exp.data_ptr() + 8 * sweep,
+                                                   d_exp.data_ptr() + 8 * slot, st_), "tmf_rescale_pow2_batched")
+
         cur = torch.cuda.current_stream(self.device)
         s1 = cur.cuda_stream
         t2 = time.perf_counter()
         if self.method == "sequential":
             # ================= rightward QR sweep, then one SVD per site on the way back =================
-            for ga, qa in steps1:
+            for jstep, (ga, qa, ra_) in enumerate(steps1):
                 gemm(ga, s1)
                 qr(qa, s1)
+                rescale(ra_, s1, 0, jstep + 1)
             end = next(iter(self.sect[Ls]))
             norm = abs(complex(d_ar[Rb[Ls][end]].item()))                         # (host sync: end of sweep 1)
+            if rescaling:                                    # R_Ls = (stored mantissa) 2^e
+                e_tot = int(d_exp[0].item())
+                self.log2_norm = float(np.log2(norm) + e_tot) if norm > 0 else -np.inf
+                norm_mant, norm = norm, float(np.ldexp(norm, e_tot))       # (0.0 beyond the range of a double: see log2_norm)
+            else:
+                norm_mant = norm
             self.timings["sweep1"] = time.perf_counter() - t2
-            if not norm > 0.0 or not np.isfinite(norm):
+            if not norm_mant > 0.0 or not np.isfinite(norm_mant):
                 raise ValueError("the Gutzwiller projection annihilates the state")
             t3 = time.perf_counter()
             # (the last tensor was normalised by its own QR: X of the right end stays 1)
@@ -942,15 +970,26 @@ class _Projector:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(cur)
             s2 = side.cuda_stream
-            for (ga, qa), (gb_, cb_, qb) in zip(steps1, steps2):     # interleaved issue: both queues stay fed
+            for jstep, ((ga, qa, ra_), (gb_, cb_, qb, rb_)) in enumerate(zip(steps1, steps2)):     # interleaved issue: both queues stay fed
                 gemm(ga, s1)
                 qr(qa, s1)
+                rescale(ra_, s1, 0, jstep + 1)               # R_{j+1}
                 gemm(gb_, s2)
                 copy(cb_, s2)
                 qr(qb, s2)
+                rescale(rb_, s2, 1, Ls - 1 - jstep)          # L_j, j = Ls - 1 - jstep
             cur.wait_stream(side)
+            bond_exp = None
             if cell is None:
                 norm = abs(complex(d_ar[Lb[0][next(iter(self.sect[0]))]].item()))   # (host sync: both sweeps done)
+                if rescaling:
+                    h_exp = d_exp.cpu().numpy()
+                    e_tot = int(h_exp[1])                    # L_0 = (stored mantissa) 2^e_tot
+                    eR = np.concatenate(([0], h_exp[2 + 1: 2 + Ls + 1]))                       # bond 0: R = 1, never scaled
+                    eL = np.concatenate((h_exp[2 + (Ls + 1): 2 + (Ls + 1) + Ls], [0]))        # bond Ls: L = 1
+                    bond_exp = (eR + eL - e_tot).astype(np.int64)          # C_j = R_j' L_j' 2^bond_exp[j] / mantissa
+                    self.log2_norm = float(np.log2(norm) + e_tot) if norm > 0 else -np.inf
+                    norm_mant, norm = norm, float(np.ldexp(norm, e_tot))   # (0.0 beyond the range of a double: see log2_norm)
             else:
                 norm = float(np.sqrt(cell["eta"]))      # norm of the projected state per unit cell
             self.timings["sweeps"] = time.perf_counter() - t2
@@ -962,11 +1001,18 @@ class _Projector:
                                     for c, n in self.sect[j].items()},
                               "L": {(j, c): h_all[Lb[j][c]: Lb[j][c] + n * n].reshape(n, n).T.copy() for j in range(Ls + 1)
                                     for c, n in self.sect[j].items()}, "sect": [dict(s_) for s_ in self.sect]}
-            if not norm > 0.0 or not np.isfinite(norm):
+            if bond_exp is None:
+                norm_mant = norm
+            if not norm_mant > 0.0 or not np.isfinite(norm_mant):
                 raise ValueError("the Gutzwiller projection annihilates the state")
             # ================= every bond at once =================
             t3 = time.perf_counter()
-            gemm(tail[0], s1, alpha=1.0 / norm)
+            if bond_exp is None or not bond_exp.any():
+                gemm(tail[0], s1, alpha=1.0 / norm_mant)
+            else:      # bonds whose two factors were scaled by a different total than the norm: one launch per power of two
+                ks = bond_exp[np.asarray(gc_bond)]
+                for kv in np.unique(ks):
+                    self._gemm_now([gc[i] for i in np.nonzero(ks == kv)[0]], 0, s1, keep_alive, alpha=float(np.ldexp(1.0 / norm_mant, int(kv))))
             qr(tail[3], s1)
             d_sw = torch.zeros(n_sec_tot, dtype=torch.int32, device=self.device)
             nat.check(lib.tmf_jacobi_compact_batched(self.dt, tabs_d["jc"].data_ptr(), n_sec_tot, int(jd["p"].max()),
@@ -1492,6 +1538,7 @@ def abrikosov(mps, *, inplace: bool = False, return_canonical: bool = True, cuto
             res.form = [None] * res.L
     else:
         res = SpinMPSData(blocks, lam, ch, None, norm, ucw, canonical=return_canonical, timings=pr.timings)
+        res.log2_norm = getattr(pr, "log2_norm", None)      # log2 of the norm: finite where `norm` has left the range of a double
     return _finish(mps, inplace, res)
 
 
@@ -1542,6 +1589,7 @@ def abrikosov_ph(mps, *, inplace: bool = False, return_canonical: bool = True, c
             res.form = [None] * res.L
     else:
         res = SpinMPSData(blocks, lam, ch, spin, norm, ucw, canonical=return_canonical, timings=pr.timings)
+        res.log2_norm = getattr(pr, "log2_norm", None)      # log2 of the norm: finite where `norm` has left the range of a double
     return _finish(mps, inplace, res)
 
 

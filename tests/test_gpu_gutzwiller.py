@@ -4,6 +4,7 @@ against the oracle (oracle/gutzwiller_oracle.py, itself pinned by brute force in
 Tolerances (fp64): Schmidt values 1e-10 abs (per bond, sorted), entropies 1e-10, norm of the projected state
 1e-10 rel, state overlap 1 - |<oracle|hip>| <= 1e-10, right-canonical isometry 1e-10, kept bond dimensions
 equal wherever no Schmidt value lies within a factor 10 of the cutoff."""
+import os
 import warnings
 
 import numpy as np
@@ -263,6 +264,65 @@ def test_config5_full_size_properties():
         assert np.abs(a[:n] - r[:n]).max() < 1e-11 and abs(len(a) - len(r)) <= (a < 1e-11).sum() + (r < 1e-11).sum()
     S = seq.entanglement_entropy()
     assert abs(S[255] - S[255 - 2]) < 0.5 and 0.5 < S[255] < 2.0          # log-law plateau of the projected chain
+
+
+def test_rescaling_inside_the_sweeps_leaves_the_result_alone_and_lifts_the_underflow():
+    """The triangular factors of the two QR sweeps are rescaled by a common power of two after every step
+    (tmf_rescale_pow2_batched; TeNPy's canonical_form_finite renormalises every step): powers of two are exact, so the
+    result of a short chain is THE SAME with and without (Schmidt values, tensors up to rounding of the different scale of
+    intermediate products: 1e-13), and a chain whose projected norm leaves the range of a double (0.6 per spin: 2 200 spins)
+    is projected like any other - `norm` then underflows and `log2_norm` carries it."""
+    from temfpy_amd import gutzwiller, slater
+
+    # (a) same result as without rescaling (the switch is read per call)
+    C, _ = slater.correlation_matrix(uniform_chain(24))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mps = slater.C_to_MPS(C, {"chi_max": 64}, spinful="PH", as_tenpy=False)
+        on = gutzwiller.abrikosov_ph(mps)
+        os.environ["TMF_GW_RESCALE"] = "0"
+        try:
+            off = gutzwiller.abrikosov_ph(mps)
+        finally:
+            del os.environ["TMF_GW_RESCALE"]
+    assert abs(on.norm / off.norm - 1) < 1e-13 and abs(on.log2_norm - np.log2(off.norm)) < 1e-10
+    for a, b in zip(on.lam, off.lam):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-13)
+    assert abs(spin_overlap(on.dense_tensors(), off.dense_tensors()) - 1) < 1e-12
+    # (b) long chains against the oracle run with a renormalisation per step of its first sweep.  (Without the rescaling
+    # the SQUARES of the triangular factors leave the range at ~1000 spins and the result is silently wrong.)
+    def stable(M):
+        M = [np.array(m, complex) for m in M]
+        lg = 0.0
+        for j in range(len(M) - 1):
+            d, cl, cr = M[j].shape
+            Q, R = np.linalg.qr(M[j].reshape(d * cl, cr))
+            sc = np.abs(R).max()
+            lg += np.log2(sc)
+            M[j] = Q.reshape(d, cl, -1)
+            M[j + 1] = np.einsum("ab,pbc->pac", R / sc, M[j + 1])
+        _, S, nrm = gw.canonical_form_finite(M, 1e-12)
+        return S, lg + np.log2(nrm)
+
+    for Ls in (1200, 2200):
+        C, _ = slater.correlation_matrix(uniform_chain(Ls))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mps = slater.C_to_MPS(C, {"chi_max": 16}, spinful="PH", as_tenpy=False)
+            results = [gutzwiller.abrikosov_ph(mps), gutzwiller.abrikosov_ph(mps, method="sequential")]
+        T, q, lam, oc = oracle_inputs(mps)
+        M, _ = gw.group_and_project(T, q, lam, oc, "ph")
+        S, lg = stable(M)
+        for res in results:
+            assert res.L == Ls and abs(res.log2_norm - lg) < 1e-9 and lg < -500.0
+            assert abs(res.norm / 2.0 ** lg - 1) < 1e-9 if Ls == 1200 else res.norm < 1e-300
+            for x, r in zip(res.lam, S):
+                x, r = np.sort(x)[::-1], np.sort(r)[::-1]
+                n = min(len(x), len(r))
+                assert np.abs(x[:n] - r[:n]).max() < 1e-12
+            for t in res.dense_tensors()[Ls // 2 - 2: Ls // 2 + 2]:
+                X = np.einsum("pab,pcb->ac", t, t.conj()) - np.eye(t.shape[1])
+                assert np.abs(X).max() < 1e-9
 
 
 def test_adapter_from_flat_tables_equals_the_per_site_adapter():
