@@ -368,7 +368,8 @@ int tmf_house_qr_batched(int dtype, const tmf_qr_desc* d_desc, int nprob, int ma
 /* Householder QR of tall slabs with the working panel in LDS (n x c, c <= 64, n <= 4096): A is replaced by the
  * thin orthonormal factor Q (flags & 2: Q stays in the scratch, A is left holding the reflectors; flags & 4: no Q at
  * all, only R), R or R^H (flags & 1) goes to `R` (may be 0); `Q` is a caller-provided scratch of n x c elements
- * (leading dimension ldq; unused with flags & 4).  One workgroup per
+ * (leading dimension ldq; unused with flags & 4).  flags & 8: Q later - A is left holding the reflectors and `Q` points to
+ * a buffer of c elements that receives their scalars; tmf_house_form_q_batched then turns A into Q.  One workgroup per
  * slab.  The two range-finder QRs of every cut (orthonormal bases inside the replacement of
  * numpy.linalg.eigh, slater.py:347): orthogonal for any numerical rank, one launch instead of ~60. */
 typedef struct {
@@ -376,6 +377,10 @@ typedef struct {
   int32_t n, c, lda, ldq, ldr, flags;
 } tmf_slab_desc;             /* 48 bytes */
 int tmf_house_slab_batched(int dtype, const tmf_slab_desc* d_desc, int nprob, int max_n, int max_c, void* stream);
+/* Thin Q, in place, of slabs factored with flags & 8 (same descriptors: A = the reflectors, Q = their scalars; R, ldq, ldr
+ * and flags are not read).  For chains of dependent factorisations in which only R feeds the next link (the canonicalisation
+ * sweeps, gutzwiller.py:266 / :471): every Q of the chain in one launch afterwards. */
+int tmf_house_form_q_batched(int dtype, const tmf_slab_desc* d_desc, int nprob, int max_n, int max_c, void* stream);
 /* The same, with every column of a block in registers when all blocks of the launch are real and at most 256 x 128
  * (else the panel kernel): which kernel runs then depends on the launch, so not for callers that need a slab's result to be
  * independent of its batch (the sharded sweep).  Used by the canonicalisation sweeps of gutzwiller.py:266 / :471. */

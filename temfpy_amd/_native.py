@@ -94,7 +94,7 @@ SYMBOLS = [
     "tmf_pf_result_block", "tmf_pf_result_checks", "tmf_pf_result_flat", "tmf_pf_result_download", "tmf_pf_result_free", "tmf_onishi_norms", "tmf_host_parallel_for", "tmf_gemm_set_4m", "tmf_block_orth_stamps", "tmf_transpose", "tmf_fill_normal",
     "tmf_gather_signed_batched", "tmf_normalise_columns_batched", "tmf_canonical_gauge_batched", "tmf_rescale_pow2_batched", "tmf_column_norms_batched", "tmf_cut_vectors",
     "tmf_site_prepare", "tmf_cut_vectors_batch", "tmf_site_prepare_batch", "tmf_det_tiles_build", "tmf_pf_gather_batched",
-    "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched", "tmf_copy_blocks_batched", "tmf_house_qr_batched", "tmf_jacobi_compact_batched", "tmf_house_slab_batched", "tmf_house_qr_regs_batched",
+    "tmf_nambu_assemble_batched", "tmf_nambu_w_batched", "tmf_pf_matrix_batched", "tmf_copy_blocks_batched", "tmf_house_qr_batched", "tmf_jacobi_compact_batched", "tmf_house_slab_batched", "tmf_house_qr_regs_batched", "tmf_house_form_q_batched",
     "tmf_host_register", "tmf_host_unregister", "tmf_memcpy_async", "tmf_lu_block_batched", "tmf_lu_trsm_batched", "tmf_diag_inverse_batched", "tmf_diag_inverse_verdict", "tmf_launch_condition", "tmf_export_words",
     "tmf_ctx_create", "tmf_ctx_destroy", "tmf_sweep_begin", "tmf_sweep_entangled", "tmf_sweep_sites", "tmf_sweep_download",
     "tmf_sweep_query", "tmf_sweep_wait", "tmf_sweep_info_get", "tmf_sweep_stage_name", "tmf_sweep_device_out",
@@ -251,6 +251,7 @@ def load():
     lib.tmf_house_qr_batched.argtypes = [i32, vp, i32, i32, i32, vp]
     lib.tmf_house_slab_batched.argtypes = [i32, vp, i32, i32, i32, vp]
     lib.tmf_house_qr_regs_batched.argtypes = [i32, vp, i32, i32, i32, vp]
+    lib.tmf_house_form_q_batched.argtypes = [i32, vp, i32, i32, i32, vp]
     lib.tmf_transpose.argtypes = [i32, vp, vp, i32, vp]
     lib.tmf_fill_normal.argtypes = [i32, vp, i64, u64, vp]
     lib.tmf_gather_signed_batched.argtypes = [i32, vp, i32, vp]

@@ -174,7 +174,9 @@ void house_slab_kernel(const tmf_slab_desc* __restrict__ desc, int w, unsigned l
       if (d.flags & 1) R[cc + (size_t)r * d.ldr] = sc<T>::conj(v);
       else R[r + (size_t)cc * d.ldr] = v;
     }
-  if (d.flags & 4) {            // only R wanted: no Q at all (A is left holding the reflectors)
+  if (d.flags & 12) {           // 4: only R wanted, no Q at all; 8: Q later (tmf_house_form_q_batched): A is left holding
+    if (d.flags & 8)            // the reflectors, their scalars go to the caller's buffer
+      for (int e = tid; e < c; e += NT) Q[e] = e < K ? taus[e] : sc<T>::zero();
     if (dbg && tid == 64) {
       for (int i = 0; i < 8; ++i) atomicAdd(&dbg[i], tacc[i]);
       atomicAdd(&dbg[8], 1ull), atomicAdd(&dbg[9], (unsigned long long)n);
@@ -222,6 +224,80 @@ void house_slab_kernel(const tmf_slab_desc* __restrict__ desc, int w, unsigned l
       const int r = e % n, j = e / n;
       A[r + (size_t)j * lda] = Q[r + (size_t)j * ldq];
     }
+}
+
+// Thin Q of slabs factored with flags & 8, in place: A holds the reflectors below the diagonal, `Q` their K scalars.  The
+// arithmetic per column is that of phase 2 above; the panels are taken from the LAST to the first, since the columns of panel
+// p only need the reflectors of the panels <= p (H_k e_j = e_j for k > j) and may then overwrite their own.
+// For callers whose factorisations form a dependent chain (the canonicalisation sweeps of gutzwiller.py: 2 x 512 of them with
+// <= 5 workgroups each) while nothing in the chain needs Q: one launch over all slabs of the chain afterwards fills the device.
+template <typename T, int RMAX>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, (RMAX * sizeof(T) <= 128) ? 8 : 4)))
+void house_formq_kernel(const tmf_slab_desc* __restrict__ desc, int w) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const tmf_slab_desc d = desc[blockIdx.x];
+  const int n = d.n, c = d.c;
+  if (n <= 0 || c <= 0) return;
+  const int NT = blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = n < c ? n : c;
+  T* VBLK = reinterpret_cast<T*>(smem);
+  T* taus = VBLK + (size_t)VB * n;
+  T* __restrict__ A = reinterpret_cast<T*>(d.A);
+  const T* __restrict__ tau_g = reinterpret_cast<const T*>(d.Q);
+  const size_t lda = d.lda;
+  for (int e = tid; e < K; e += NT) taus[e] = tau_g[e];
+  T col[RMAX];
+  auto apply = [&](int k, T f, const T* __restrict__ v) {
+    T dot = sc<T>::zero();
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+      const int r = lane + 64 * i;
+      if (r >= k && r < n) dot = sc<T>::fmacc(dot, v[r], col[i]);
+    }
+    dot = sc<T>::mul(f, wsum<T>(dot));
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+      const int r = lane + 64 * i;
+      if (r >= k && r < n) col[i] = sc<T>::fms(col[i], dot, v[r]);
+    }
+  };
+  const int npan = (c + w - 1) / w;
+  for (int pi = npan - 1; pi >= 0; --pi) {
+    const int p0 = pi * w;
+    const int wp = (c - p0 < w) ? c - p0 : w;
+    const bool mine = wave < wp;
+    const int jc = p0 + wave;
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+      const int r = lane + 64 * i;
+      col[i] = (mine && r == jc && r < K) ? sc<T>::one() : sc<T>::zero();
+    }
+    int ktop = p0 + wp;
+    if (ktop > K) ktop = K;
+    for (int kb_end = ktop; kb_end > 0; kb_end -= VB) {
+      const int kb = (kb_end - VB > 0) ? kb_end - VB : 0;
+      const int nb = kb_end - kb;
+      __syncthreads();
+      for (int e = tid; e < n * nb; e += NT) {
+        const int r = e % n, j = e / n, k = kb + j;
+        VBLK[e] = (r == k) ? sc<T>::one() : (r > k ? A[r + (size_t)k * lda] : sc<T>::zero());
+      }
+      __syncthreads();
+      if (mine)
+        for (int j = nb - 1; j >= 0; --j)
+          if (kb + j <= jc) apply(kb + j, taus[kb + j], VBLK + (size_t)j * n);
+    }
+    __syncthreads();            // the reflectors held by this panel's columns have been read by everybody
+    if (mine) {
+      T* __restrict__ q = A + (size_t)jc * lda;
+#pragma unroll
+      for (int i = 0; i < RMAX; ++i) {
+        const int r = lane + 64 * i;
+        if (r < n) q[r] = col[i];
+      }
+    }
+  }
 }
 
 
@@ -408,6 +484,10 @@ __global__ __launch_bounds__(64 * NW) void house_reg_kernel(const tmf_slab_desc*
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  if (d.flags & 8) {            // Q later (tmf_house_form_q_batched): the scalars of the reflectors to the caller's buffer
+    for (int e = tid; e < c; e += 64 * NW) Q[e] = e < K ? taus[e] : sc<T>::zero();
+    return;
+  }
   __syncthreads();
   // ---------------- phase 2: thin Q = H_0 ... H_{K-1} [1; 0], reflectors applied from the last to the first ----------------
 #pragma unroll
@@ -470,6 +550,48 @@ extern "C" int tmf_house_slab_batched(int dtype, const tmf_slab_desc* d_desc, in
 extern "C" int tmf_house_qr_regs_batched(int dtype, const tmf_slab_desc* d_desc, int nprob, int max_n, int max_c, void* stream) {
   static const bool allow = !(getenv("TMF_SLAB_REG") && atoi(getenv("TMF_SLAB_REG")) == 0);
   return house_slab_launch(dtype, d_desc, nprob, max_n, max_c, stream, allow);
+}
+
+extern "C" int tmf_house_form_q_batched(int dtype, const tmf_slab_desc* d_desc, int nprob, int max_n, int max_c, void* stream) {
+  using namespace tmf;
+  if (nprob <= 0) return TMF_OK;
+  const size_t elem = (dtype == TMF_C128) ? 16 : 8;
+  const int w = 16;
+  if (max_n <= 0 || max_c <= 0 || max_n > ((dtype == TMF_C128) ? 1024 : 2048)) {
+    set_error("tmf_house_form_q_batched: %d rows not in 1..%d", max_n, (dtype == TMF_C128) ? 1024 : 2048);
+    return TMF_E_LIMIT;
+  }
+  const size_t lds = ((size_t)max_n * VB + (size_t)max_c + 4) * elem + 64;
+  if (lds > 150 * 1024) {
+    set_error("tmf_house_form_q_batched: %d rows need %zu B of LDS", max_n, lds);
+    return TMF_E_LIMIT;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+#define TMF_FQ_ATTR(T, RM) (void)hipFuncSetAttribute((const void*)house_formq_kernel<T, RM>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)
+    TMF_FQ_ATTR(cd, 4); TMF_FQ_ATTR(cd, 8); TMF_FQ_ATTR(cd, 16); TMF_FQ_ATTR(double, 4); TMF_FQ_ATTR(double, 8);
+    TMF_FQ_ATTR(double, 16); TMF_FQ_ATTR(double, 32);
+#undef TMF_FQ_ATTR
+    attr_done = true;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 g(nprob), b(64 * w);
+#define TMF_FQ_LAUNCH(T, RM) hipLaunchKernelGGL((house_formq_kernel<T, RM>), g, b, lds, s, d_desc, w)
+  if (dtype == TMF_C128) {
+    if (max_n <= 256) TMF_FQ_LAUNCH(cd, 4);
+    else if (max_n <= 512) TMF_FQ_LAUNCH(cd, 8);
+    else TMF_FQ_LAUNCH(cd, 16);
+  } else if (dtype == TMF_F64) {
+    if (max_n <= 256) TMF_FQ_LAUNCH(double, 4);
+    else if (max_n <= 512) TMF_FQ_LAUNCH(double, 8);
+    else if (max_n <= 1024) TMF_FQ_LAUNCH(double, 16);
+    else TMF_FQ_LAUNCH(double, 32);
+  } else {
+    set_error("tmf_house_form_q_batched: bad dtype %d", dtype);
+    return TMF_E_ARG;
+  }
+#undef TMF_FQ_LAUNCH
+  return check_hip(hipGetLastError(), "tmf_house_form_q_batched");
 }
 
 static int house_slab_launch(int dtype, const tmf_slab_desc* d_desc, int nprob, int max_n, int max_c, void* stream, bool use_reg) {

@@ -764,7 +764,7 @@ class _Projector:
             rs = np.zeros(len(Vinfo[j]), nat.rescale_desc)
             for i, (cp_, (voff, m, rows)) in enumerate(Vinfo[j].items()):
                 npr = self.sect[j + 1][cp_]
-                qd[i] = (P(voff), P(Rb[j + 1][cp_]), m, npr, m, npr, 0, 0)
+                qd[i] = (P(voff), P(Rb[j + 1][cp_]), m, npr, m, npr, 2 if self.method == "parallel" else 4, 0)   # parallel: nothing reads Q; else: every Q after the sweep
                 rs[i] = (P(Rb[j + 1][cp_]), npr, npr, npr, 0)
             steps1.append((G.add(_gemm_recs(g)), QR.add(qd), RS.add(rs)))
         sv_ptr, cnt_ptr = d_sv.data_ptr(), d_cnt.data_ptr()
@@ -820,7 +820,7 @@ class _Projector:
                 for i, (c, v) in enumerate(Winfo[j].items()):
                     n, w = self.sect[j][c], v[1]
                     cpy.append((P(Wo + wl[c]), P(Yq[j][c]), n, w, n, w, 3 if self.cplx else 1, 0))
-                    qd[i] = (P(Yq[j][c]), P(Lb[j][c]), w, n, w, n, 1, 0)
+                    qd[i] = (P(Yq[j][c]), P(Lb[j][c]), w, n, w, n, 1 | 4, 0)      # 4: Q~ of every site in one launch after the sweep
                     rs[i] = (P(Lb[j][c]), n, n, n, 0)
                 steps2.append((G.add(_gemm_recs(g)), CP.add(np.array(cpy, nat.copy_desc)), QR.add(qd), RS.add(rs)))
             # batched tail: C = R L / norm, SVD of every bond and sector at once, B^H = blockdiag(Vz_{j+1})^H (Q~ Vz_j)
@@ -855,20 +855,25 @@ class _Projector:
             to += len(tl)
         tiles = np.concatenate(tiles) if tiles else np.zeros((0, 4), np.int32)
         tabs_h = {"g": gt, "t": tiles, "cp": CP.table(), "qr": QR.table(), "jc": jd, "rs": RS.table()}
-        tabs_d = {k: torch.from_numpy(v.view(np.uint8).reshape(-1).copy() if v.size else np.zeros(16, np.uint8)).to(self.device)
-                  for k, v in tabs_h.items()}
-        keep_alive.append(tabs_d)
         qr_max = [(int(tabs_h["qr"][o: o + n]["m"].max()), int(tabs_h["qr"][o: o + n]["n"].max())) for o, n in QR.spans]
         # The same factorisations through the on-chip slab kernel (panel columns in registers, reflector blocks in
         # LDS: 2x faster than the L2-resident kernel at 280 x 140) whenever the rows fit its registers; Q is built
         # in a scratch (one per sweep direction) and copied over the block.
         slab_rows = 1024 if self.cplx else 2048
         use_slab = os.environ.get("TMF_GW_QR", "slab") == "slab" and max(q[0] for q in qr_max) <= slab_rows
+        later = (tabs_h["qr"]["flags"] & 4) != 0            # factorisations whose Q is formed after the sweep
+        if not use_slab or os.environ.get("TMF_GW_Q_LATER", "1") == "0":
+            tabs_h["qr"]["flags"] &= ~np.int32(4)
+            later[:] = False
+        tabs_d = {k: torch.from_numpy(v.view(np.uint8).reshape(-1).copy() if v.size else np.zeros(16, np.uint8)).to(self.device)
+                  for k, v in tabs_h.items()}
+        keep_alive.append(tabs_d)
+        formq = None
         if use_slab:
             qt = tabs_h["qr"]
             sl = np.zeros(len(qt), nat.slab_desc)
             sl["A"], sl["R"], sl["n"], sl["c"], sl["lda"], sl["ldr"] = qt["A"], qt["R"], qt["m"], qt["n"], qt["lda"], qt["ldr"]
-            sl["flags"] = (qt["flags"] & 1) | np.where(qt["flags"] & 2, 4, 0)
+            sl["flags"] = (qt["flags"] & 1) | np.where(qt["flags"] & 2, 4, 0) | np.where(later, 8, 0)
             sl["ldq"] = qt["m"]
             sizes = (qt["m"].astype(np.int64) * qt["n"] + 1) & ~1
             need, rel = 0, np.zeros(len(qt), np.int64)
@@ -881,6 +886,16 @@ class _Projector:
             first2 = min([x[2] for x in steps2] + ([tail[3]] if tail is not None else []), default=len(QR.spans))
             for i, (o, n) in enumerate(QR.spans):      # launches of the rightward sweep come first in the table
                 sl["Q"][o: o + n] = scratch[0 if i < first2 else 1].data_ptr() + el * rel[o: o + n]
+            if later.any():      # their reflector scalars: one buffer for all; the launch that forms every Q, large slabs first
+                ix = np.nonzero(later)[0]
+                toff = np.concatenate(([0], np.cumsum((sl["c"][ix].astype(np.int64) + 1) & ~1)))
+                d_tau = torch.zeros(int(toff[-1]) + 2, dtype=d_ar.dtype, device=self.device)
+                keep_alive.append(d_tau)
+                sl["Q"][ix] = d_tau.data_ptr() + el * toff[:-1]
+                fq = sl[ix][np.argsort(-(sl["n"][ix].astype(np.int64) * sl["c"][ix]), kind="stable")]
+                formq = (torch.from_numpy(fq.view(np.uint8).reshape(-1).copy()).to(self.device), len(fq), int(fq["n"].max()),
+                         int(fq["c"].max()))
+                keep_alive.append(formq)
             t_sl = torch.from_numpy(sl.view(np.uint8).reshape(-1).copy()).to(self.device)
             keep_alive.append(t_sl)
         cp_max = [int((_cdiv(tabs_h["cp"][o: o + n]["rows"].astype(np.int64), 32)
@@ -931,6 +946,9 @@ class _Projector:
                 gemm(ga, s1)
                 qr(qa, s1)
                 rescale(ra_, s1, 0, jstep + 1)
+            if formq is not None:      # the isometries of the whole sweep in one launch
+                nat.check(lib.tmf_house_form_q_batched(self.dt, formq[0].data_ptr(), formq[1], formq[2], formq[3], s1),
+                          "tmf_house_form_q_batched")
             end = next(iter(self.sect[Ls]))
             norm = abs(complex(d_ar[Rb[Ls][end]].item()))                         # (host sync: end of sweep 1)
             if rescaling:                                    # R_Ls = (stored mantissa) 2^e
@@ -1014,6 +1032,9 @@ class _Projector:
                 for kv in np.unique(ks):
                     self._gemm_now([gc[i] for i in np.nonzero(ks == kv)[0]], 0, s1, keep_alive, alpha=float(np.ldexp(1.0 / norm_mant, int(kv))))
             qr(tail[3], s1)
+            if formq is not None:
+                nat.check(lib.tmf_house_form_q_batched(self.dt, formq[0].data_ptr(), formq[1], formq[2], formq[3], s1),
+                          "tmf_house_form_q_batched")
             d_sw = torch.zeros(n_sec_tot, dtype=torch.int32, device=self.device)
             nat.check(lib.tmf_jacobi_compact_batched(self.dt, tabs_d["jc"].data_ptr(), n_sec_tot, int(jd["p"].max()),
                                                      d_sw.data_ptr(), s1), "tmf_jacobi_compact_batched")

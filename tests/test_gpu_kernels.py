@@ -1087,6 +1087,58 @@ def test_house_qr_with_all_columns_in_registers(eng, shape):
         np.testing.assert_allclose(Q[:, :K] @ R[:K], A, rtol=0, atol=1e-13 * scale * max(m_, c_))
 
 
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("shape", [(320, 160), (220, 110), (100, 130), (64, 64), (9, 4)])
+def test_house_qr_with_q_formed_later(eng, shape, cplx):
+    """flags & 8 of both slab entry points + tmf_house_form_q_batched: the factorisation leaves the reflectors in A and their
+    scalars in the caller's buffer, Q is formed in place by a later launch (the Gutzwiller sweeps form every Q of a sweep in
+    one launch after the chain of factorisations).  Against the one-launch form of the panel kernel: R and Q bit for bit
+    (same arithmetic per column); from the register kernel: the defining properties."""
+    setup(eng, cplx)
+    nat, lib = eng.nat, eng.lib
+    dt, tdt = (nat.TMF_C128, torch.complex128) if cplx else (nat.TMF_F64, torch.float64)
+    rng = np.random.default_rng(shape[0] * 7 + shape[1] + cplx)
+    n, c = shape
+    mats = [rnd(rng, (n, c), cplx), rnd(rng, (max(n // 3, 1), max(c // 2, 1)), cplx)]
+    if c >= 8:
+        mats.append(rnd(rng, (n, 5), cplx) @ rnd(rng, (5, c), cplx))
+    mx_n, mx_c = max(a.shape[0] for a in mats), max(a.shape[1] for a in mats)
+
+    def run(entry, deferred):
+        dA, dQ, dR, d = [], [], [], np.zeros(len(mats), nat.slab_desc)
+        for i, A in enumerate(mats):
+            m_, c_ = A.shape
+            dA.append(torch.from_numpy(np.ascontiguousarray(A.T).reshape(-1).copy()).to("cuda:0"))
+            dQ.append(torch.zeros(m_ * c_ + 2, dtype=tdt, device="cuda:0"))
+            dR.append(torch.zeros(c_ * c_ + 2, dtype=tdt, device="cuda:0"))
+            d[i] = (dA[i].data_ptr(), dQ[i].data_ptr(), dR[i].data_ptr(), m_, c_, m_, m_, c_, 8 if deferred else 0)
+        dd = torch.from_numpy(d.view(np.uint8).copy()).to("cuda:0")
+        nat.check(getattr(lib, entry)(dt, dd.data_ptr(), len(mats), mx_n, mx_c, eng.stream), entry)
+        if deferred:
+            torch.cuda.synchronize()
+            for i, A in enumerate(mats):      # the scalars: c entries, zero past min(n, c); nothing written behind them
+                t = dQ[i].cpu().numpy()
+                K = min(A.shape)
+                assert np.all(t[K:] == 0)
+            nat.check(lib.tmf_house_form_q_batched(dt, dd.data_ptr(), len(mats), mx_n, mx_c, eng.stream), "tmf_house_form_q_batched")
+        torch.cuda.synchronize()
+        Qs = [dA[i].cpu().numpy()[: A.shape[0] * A.shape[1]].reshape(A.shape[1], A.shape[0]).T for i, A in enumerate(mats)]
+        Rs = [dR[i].cpu().numpy()[: A.shape[1] ** 2].reshape(A.shape[1], A.shape[1]).T for i, A in enumerate(mats)]
+        return Qs, Rs
+
+    Q0, R0 = run("tmf_house_slab_batched", False)
+    Q1, R1 = run("tmf_house_slab_batched", True)
+    for a, b in zip(Q0 + R0, Q1 + R1):
+        assert np.array_equal(a, b)
+    Q2, R2 = run("tmf_house_qr_regs_batched", True)
+    for A, Q, R in zip(mats, Q2, R2):
+        m_, c_ = A.shape
+        K = min(m_, c_)
+        scale = np.abs(A).max()
+        np.testing.assert_allclose(Q[:, :K].conj().T @ Q[:, :K], np.eye(K), rtol=0, atol=1e-13)
+        np.testing.assert_allclose(Q[:, :K] @ R[:K], A, rtol=0, atol=1e-13 * scale * max(m_, c_))
+
+
 def test_export_words_verdict_and_conditional_launches(eng):
     """Plumbing of the block-local elimination: tmf_export_words (device -> page-locked host memory by a kernel),
     tmf_diag_inverse_verdict (statistics -> device flag + summary in host memory) and tmf_launch_condition (GEMM / gather /
