@@ -521,6 +521,250 @@ __global__ __launch_bounds__(64 * NW) void house_reg_kernel(const tmf_slab_desc*
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The register form for blocks with more columns than one workgroup holds: panels of NW CPW columns, each factored as above;
+// the reflectors of the earlier panels are read back from A one per step (their entry for step k + 2 is on its way from
+// memory while reflector k is applied) and applied to the CPW columns of a wavefront together.  320 x 160 blocks of the
+// Gutzwiller sweeps (two panels of 80 columns): against the panel kernel above (16 columns per panel, one per wavefront,
+// 90 reflector blocks loaded behind two barriers each).  Phase 2 takes the panels from the last to the first, in place.
+// (Kept apart from the one-panel kernel: with the panel loop around it that one needs 27 more registers and spills.)
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int RMAX, int CPW, int NW>
+__global__ __launch_bounds__(64 * NW) void house_regp_kernel(const tmf_slab_desc* __restrict__ desc) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const tmf_slab_desc d = desc[blockIdx.x];
+  const int n = d.n, c = d.c;
+  if (n <= 0 || c <= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = n < c ? n : c;
+  constexpr int NS = 64 * RMAX;
+  constexpr int PW = NW * CPW;                 // columns per panel; blocks of up to PW columns have one panel
+  static_assert(NS <= 64 * NW, "one thread per reflector entry");
+  T* slots = reinterpret_cast<T*>(smem);       // two reflectors of 64 RMAX entries (zeros above the diagonal, 1 on it)
+  T* taus = slots + 2 * NS;                    // K scalars
+  T* __restrict__ A = reinterpret_cast<T*>(d.A);
+  T* __restrict__ Q = reinterpret_cast<T*>(d.Q);
+  T* __restrict__ R = reinterpret_cast<T*>(d.R);
+  const size_t lda = d.lda, ldq = d.ldq;
+  const int npan = (c + PW - 1) / PW;
+  int p0 = 0;                                  // first column of the panel in the registers
+
+  // col[q][i]: row lane + 64 i of column p0 + wave + NW q; rows >= n and columns >= c hold zeros throughout
+  T col[CPW][RMAX];
+  // Reflector k from register column QQ of this wavefront (the column's entries above row k are final R entries):
+  // v into `slot` (all 64 RMAX entries), tau into LDS.  One wave reduction (the squared length below the diagonal); the
+  // diagonal entry comes by v_readlane, 1 / b and 1 / (alpha - beta) by v_rcp_f64 + Newton steps.
+  auto build = [&](const int k, auto qq_tag, T* __restrict__ slot) {
+    constexpr int QQ = decltype(qq_tag)::value;
+    double s_ = 0.0;
+    T al = sc<T>::zero();
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+      const int r = lane + 64 * i;
+      if (r > k) s_ += sc<T>::abs2(col[QQ][i]);
+      if ((k >> 6) == i) al = sc<T>::from2(readlane_d(sc<T>::real(col[QQ][i]), k & 63), sc<T>::cplx ? readlane_d(sc<T>::imag(col[QQ][i]), k & 63) : 0.0);
+    }
+    s_ = wave_sum64(s_);
+    const T alpha = al;
+    T tau = sc<T>::zero(), scal = sc<T>::zero(), beta = alpha;
+    if ((s_ > 0.0 || sc<T>::imag(alpha) != 0.0) && sc<T>::abs2(alpha) + s_ > 1e-290) {    // (see the panel kernel)
+      const double nn = sc<T>::abs2(alpha) + s_;
+      double rs = __builtin_amdgcn_rsq(nn);                 // 1 / sqrt(nn), two Newton steps
+      rs = rs * fma(-0.5 * nn * rs, rs, 1.5);
+      rs = rs * fma(-0.5 * nn * rs, rs, 1.5);
+      double b_ = nn * rs, binv = rs;
+      if (sc<T>::real(alpha) > 0.0) b_ = -b_, binv = -binv;
+      beta = sc<T>::from_real(b_);
+      tau = sc<T>::scale(sc<T>::sub(beta, alpha), binv);
+      scal = sc<T>::inv_fast(sc<T>::sub(alpha, beta));
+    }
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+      const int r = lane + 64 * i;
+      T v = sc<T>::zero();
+      if (r == k) v = sc<T>::one();
+      else if (r > k) v = sc<T>::mul(col[QQ][i], scal);
+      slot[r] = v;
+      if (r == k) col[QQ][i] = beta;
+      else if (r > k) col[QQ][i] = v;
+    }
+    if (lane == 0) taus[k] = tau;
+  };
+  // (I - f v v^H) on register column QQ
+  auto apply_one = [&](const T f, const T* __restrict__ v, auto qq_tag) {
+    constexpr int QQ = decltype(qq_tag)::value;
+    T dot = sc<T>::zero();
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) dot = sc<T>::fmacc(dot, v[lane + 64 * i], col[QQ][i]);
+    dot = sc<T>::mul(f, wave_sum64(dot));
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) col[QQ][i] = sc<T>::fms(col[QQ][i], dot, v[lane + 64 * i]);
+  };
+  // ... on every register column of this wavefront whose index lies in [lo, c), except column `skip`; four columns at a
+  // time: their dot products are formed together and the wave reductions interleaved (the DPP latencies overlap)
+  auto apply_range = [&](const T f, const T* __restrict__ v, const int lo, const int skip) {
+    T vr[RMAX];
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) vr[i] = v[lane + 64 * i];
+#pragma unroll
+    for (int q0 = 0; q0 < CPW; q0 += 4) {
+      if (p0 + wave + NW * (q0 + 3 < CPW ? q0 + 3 : CPW - 1) < lo) continue;      // (uniform: nothing of this group is left)
+      T dot[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        dot[u] = sc<T>::zero();
+        if (q0 + u < CPW) {
+#pragma unroll
+          for (int i = 0; i < RMAX; ++i) dot[u] = sc<T>::fmacc(dot[u], vr[i], col[q0 + u][i]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (q0 + u < CPW) {
+          const int j = p0 + wave + NW * (q0 + u);
+          dot[u] = (j >= lo && j != skip) ? sc<T>::mul(f, wave_sum64(dot[u])) : sc<T>::zero();     // (condition uniform in the wavefront)
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (q0 + u < CPW) {
+#pragma unroll
+          for (int i = 0; i < RMAX; ++i) col[q0 + u][i] = sc<T>::fms(col[q0 + u][i], dot[u], vr[i]);
+        }
+    }
+  };
+  // compile-time dispatch on the register column
+  auto with_q = [&](const int q, auto&& fn) {
+#pragma unroll
+    for (int qq = 0; qq < CPW; ++qq)
+      if (qq == q) {
+        switch (qq) {   // (integral_constant per case keeps the register index static)
+#define TMF_Q(N_) case N_: if constexpr (N_ < CPW) fn(std::integral_constant<int, N_>{}); break;
+          TMF_Q(0) TMF_Q(1) TMF_Q(2) TMF_Q(3) TMF_Q(4) TMF_Q(5) TMF_Q(6) TMF_Q(7) TMF_Q(8) TMF_Q(9) TMF_Q(10) TMF_Q(11)
+          TMF_Q(12) TMF_Q(13) TMF_Q(14) TMF_Q(15) TMF_Q(16) TMF_Q(17) TMF_Q(18) TMF_Q(19)
+#undef TMF_Q
+        }
+      }
+  };
+  // this thread's entry of reflector k as A holds it (the vector has 64 RMAX entries, one per thread of the first wavefronts)
+  auto fetch = [&](const int k) -> T {
+    const int r = tid;
+    if (r >= NS) return sc<T>::zero();
+    return (r == k) ? sc<T>::one() : ((r > k && r < n) ? A[r + (size_t)k * lda] : sc<T>::zero());
+  };
+  auto store_cols = [&](T* __restrict__ dst, const size_t ldd) {
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) {
+      const int j = p0 + wave + NW * q;
+      if (j >= c) continue;
+#pragma unroll
+      for (int i = 0; i < RMAX; ++i) {
+        const int r = lane + 64 * i;
+        if (r < n) dst[r + (size_t)j * ldd] = col[q][i];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---------------- phase 1, panel by panel (one panel when c <= PW) ----------------
+  for (int pi = 0; pi < npan; ++pi) {
+    p0 = pi * PW;
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) {
+      const int j = p0 + wave + NW * q;
+#pragma unroll
+      for (int i = 0; i < RMAX; ++i) {
+        const int r = lane + 64 * i;
+        col[q][i] = (j < c && r < n) ? A[r + (size_t)j * lda] : sc<T>::zero();
+      }
+      __builtin_amdgcn_sched_barrier(0);      // (one column's addresses at a time: hoisted together they spill the columns)
+    }
+    // the reflectors of the earlier panels, read back from A one per step; the entry of reflector k + 2 is on its way from
+    // memory while reflector k is applied
+    const int kprev = p0 < K ? p0 : K;
+    if (kprev > 0) {
+      __syncthreads();                         // (everybody is done with the slots; the earlier panels are in memory)
+      if (tid < NS) slots[tid] = fetch(0);
+      T pre = kprev > 1 ? fetch(1) : sc<T>::zero();
+      __syncthreads();
+      for (int k = 0; k < kprev; ++k) {
+        apply_range(sc<T>::conj(taus[k]), slots + (size_t)(k & 1) * NS, p0, -1);
+        if (k + 1 < kprev && tid < NS) slots[(size_t)((k + 1) & 1) * NS + tid] = pre;
+        if (k + 2 < kprev) pre = fetch(k + 2);
+        __syncthreads();
+      }
+    }
+    const int kend = (p0 + PW < K) ? p0 + PW : K;
+    if (wave == 0 && p0 < K) build(p0, std::integral_constant<int, 0>{}, slots + (size_t)(p0 & 1) * NS);
+    __syncthreads();
+    for (int k = p0; k < kend; ++k) {
+      const T* cur = slots + (size_t)(k & 1) * NS;
+      const T f = sc<T>::conj(taus[k]);
+      const int k1 = k + 1, kk1 = k1 - p0, q1 = kk1 / NW;
+      const bool next_owner = (kk1 % NW) == wave && kk1 < PW && k1 < c;
+      if (next_owner) {      // column k + 1 first, then its reflector into the other slot while the others still apply this one
+        with_q(q1, [&](auto tag) {
+          apply_one(f, cur, tag);
+          if (k1 < K) build(k1, tag, slots + (size_t)(k1 & 1) * NS);
+        });
+      }
+      apply_range(f, cur, k1, next_owner ? k1 : -1);
+      __syncthreads();
+    }
+    // R (c x c, zero rows beyond K), optionally as R^H: straight from the registers
+    if (R) {
+#pragma unroll
+      for (int q = 0; q < CPW; ++q) {
+        const int j = p0 + wave + NW * q;
+        if (j >= c) continue;
+#pragma unroll
+        for (int i = 0; i < RMAX; ++i) {
+          const int r = lane + 64 * i;
+          if (r >= c) continue;
+          const T v = (r <= j && r < K) ? col[q][i] : sc<T>::zero();
+          if (d.flags & 1) R[j + (size_t)r * d.ldr] = sc<T>::conj(v);
+          else R[r + (size_t)j * d.ldr] = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // the reflectors go to A (below the diagonal): the later panels and phase 2 read them there
+    if (!(d.flags & 4) || npan > 1) store_cols(A, lda);
+  }
+  if (d.flags & 4) return;      // only R wanted
+  if (d.flags & 8) {            // Q later (tmf_house_form_q_batched): the scalars of the reflectors to the caller's buffer
+    __syncthreads();
+    for (int e = tid; e < c; e += 64 * NW) Q[e] = e < K ? taus[e] : sc<T>::zero();
+    return;
+  }
+  // ---------------- phase 2: thin Q = H_0 ... H_{K-1} [1; 0], reflectors applied from the last to the first; the panels
+  // from the last to the first as well: panel p needs the reflectors of the panels <= p only and may then overwrite its own
+  for (int pi = npan - 1; pi >= 0; --pi) {
+    p0 = pi * PW;
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) {
+      const int j = p0 + wave + NW * q;
+#pragma unroll
+      for (int i = 0; i < RMAX; ++i) col[q][i] = (j < c && j < K && lane + 64 * i == j) ? sc<T>::one() : sc<T>::zero();
+    }
+    const int ktop = (p0 + PW < K) ? p0 + PW : K;
+    __syncthreads();            // (the stores of phase 1 / of the previous panel are done, the slots are free)
+    if (ktop > 0) {
+      if (tid < NS) slots[(size_t)((ktop - 1) & 1) * NS + tid] = fetch(ktop - 1);
+      T pre = ktop > 1 ? fetch(ktop - 2) : sc<T>::zero();
+      __syncthreads();
+      for (int k = ktop - 1; k >= 0; --k) {
+        apply_range(taus[k], slots + (size_t)(k & 1) * NS, k, -1);          // H_k e_j = e_j for j < k
+        if (k > 0 && tid < NS) slots[(size_t)((k - 1) & 1) * NS + tid] = pre;
+        if (k > 1) pre = fetch(k - 2);
+        __syncthreads();
+      }
+    }
+    if (d.flags & 2) store_cols(Q, ldq);
+    else store_cols(A, lda);
+  }
+}
+
 }  // namespace tmf
 
 static unsigned long long* slab_stamps() {
@@ -630,6 +874,18 @@ static int house_slab_launch(int dtype, const tmf_slab_desc* d_desc, int nprob, 
     // memory by the compiler: larger and complex blocks stay on the panel kernel)
     if (dtype == TMF_F64) {
       TMF_REG_TRY(double, 2, 8, 16) TMF_REG_TRY(double, 4, 7, 16) TMF_REG_TRY(double, 4, 8, 16)
+      // larger blocks: panels of 80 / 64 columns in registers, the reflectors of the earlier panels read back one per step
+      static const bool panels = !(getenv("TMF_SLAB_REG_PANELS") && atoi(getenv("TMF_SLAB_REG_PANELS")) == 0);
+      if (panels && max_n <= 320) {
+        const size_t lds_r = ((size_t)2 * 320 + (size_t)max_c + 4) * elem + 64;
+        hipLaunchKernelGGL((house_regp_kernel<double, 5, 5, 16>), dim3(nprob), dim3(1024), lds_r, s, d_desc);
+        return check_hip(hipGetLastError(), "tmf_house_slab_batched (register form, panels)");
+      }
+      if (panels && max_n <= 512) {
+        const size_t lds_r = ((size_t)2 * 512 + (size_t)max_c + 4) * elem + 64;
+        hipLaunchKernelGGL((house_regp_kernel<double, 8, 2, 16>), dim3(nprob), dim3(1024), lds_r, s, d_desc);
+        return check_hip(hipGetLastError(), "tmf_house_slab_batched (register form, panels)");
+      }
     }
 #undef TMF_REG_TRY
   }

@@ -1048,10 +1048,12 @@ def test_house_slab_qr(eng, cplx):
         np.testing.assert_allclose(Q @ (Q.conj().T @ A), A, rtol=0, atol=1e-13 * scale * n ** 0.5)   # span(Q) contains A
 
 
-@pytest.mark.parametrize("shape", [(220, 110), (256, 128), (100, 40), (128, 128), (250, 112), (64, 90), (7, 3), (130, 0)])
+@pytest.mark.parametrize("shape", [(220, 110), (256, 128), (100, 40), (128, 128), (250, 112), (64, 90), (7, 3), (130, 0),
+                                   (320, 160), (300, 200), (320, 81), (257, 80), (500, 150), (512, 33), (90, 300)])
 def test_house_qr_with_all_columns_in_registers(eng, shape):
     """tmf_house_qr_regs_batched (house_reg_kernel: every column of a real block of at most 256 x 128 in registers, the form
-    the Gutzwiller canonicalisation sweeps use): thin Q into the scratch, R, against the defining properties; mixed launches
+    the Gutzwiller canonicalisation sweeps use; house_regp_kernel: panels of 80 / 32 columns in registers for blocks of up to
+    320 / 512 rows and any number of columns): thin Q into the scratch, R, against the defining properties; mixed launches
     (several blocks of different sizes, one of them rank deficient, one R-only)."""
     setup(eng, False)
     nat, lib = eng.nat, eng.lib
@@ -1131,7 +1133,8 @@ def test_house_qr_with_q_formed_later(eng, shape, cplx):
     for a, b in zip(Q0 + R0, Q1 + R1):
         assert np.array_equal(a, b)
     Q2, R2 = run("tmf_house_qr_regs_batched", True)
-    for A, Q, R in zip(mats, Q2, R2):
+    Q3, R3 = run("tmf_house_qr_regs_batched", False)           # Q over A in the same launch
+    for A, Q, R in list(zip(mats, Q2, R2)) + list(zip(mats, Q3, R3)):
         m_, c_ = A.shape
         K = min(m_, c_)
         scale = np.abs(A).max()
