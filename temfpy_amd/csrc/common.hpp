@@ -149,6 +149,27 @@ __device__ inline double wave_sum64(double v) {
   return readlane_d(v, 63);
 }
 __device__ inline cd wave_sum64(cd v) { return make_cd(wave_sum64(v.x), wave_sum64(v.y)); }
+// Four sums over the 64 lanes for the price of one and a half: v_permlane32_swap / v_permlane16_swap (gfx950) fold the
+// four values into one register whose rows of 16 lanes hold the partial sums of a, c, b, d; one row scan serves all four.
+// 29 instructions against 80 for four wave_sum64 (the reductions are what the register QR kernels issue most).
+__device__ inline double swap_sum32(double a, double b) {      // lanes 0-31: a(l) + a(l + 32), lanes 32-63: b(l - 32) + b(l)
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ inline double swap_sum16(double a, double b) {      // rows 0, 2: a(row) + a(row + 1); rows 1, 3: b(row - 1) + b(row)
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ inline void wave_sum64x4(double& a, double& b, double& c, double& d) {
+  double z = swap_sum16(swap_sum32(a, b), swap_sum32(c, d));      // rows: a, c, b, d
+  z += dpp_mov_zero<0x111>(z);
+  z += dpp_mov_zero<0x112>(z);
+  z += dpp_mov_zero<0x114>(z);
+  z += dpp_mov_zero<0x118>(z);
+  a = readlane_d(z, 15), c = readlane_d(z, 31), b = readlane_d(z, 47), d = readlane_d(z, 63);
+}
 // maximum over the 64 lanes (non-NaN input), the same value in every lane
 __device__ inline double wave_max64(double v) {
   v = fmax(v, dpp_mov_keep<0x111>(v));

@@ -409,12 +409,31 @@ __global__ __launch_bounds__(64 * NW) void house_reg_kernel(const tmf_slab_desc*
           for (int i = 0; i < RMAX; ++i) dot[u] = sc<T>::fmacc(dot[u], vr[i], col[q0 + u][i]);
         }
       }
+      if constexpr (!sc<T>::cplx && CPW >= 3) {      // all four sums by one folded reduction
+        if (q0 + 2 < CPW) {
+          wave_sum64x4(dot[0], dot[1], dot[2], dot[3]);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (q0 + u < CPW) {
-          const int j = wave + NW * (q0 + u);
-          dot[u] = (j >= lo && j != skip) ? sc<T>::mul(f, wave_sum64(dot[u])) : sc<T>::zero();     // (condition uniform in the wavefront)
+          for (int u = 0; u < 4; ++u)
+            if (q0 + u < CPW) {
+              const int j = wave + NW * (q0 + u);
+              dot[u] = (j >= lo && j != skip) ? f * dot[u] : 0.0;
+            }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (q0 + u < CPW) {
+              const int j = wave + NW * (q0 + u);
+              dot[u] = (j >= lo && j != skip) ? sc<T>::mul(f, wave_sum64(dot[u])) : sc<T>::zero();
+            }
         }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (q0 + u < CPW) {
+            const int j = wave + NW * (q0 + u);
+            dot[u] = (j >= lo && j != skip) ? sc<T>::mul(f, wave_sum64(dot[u])) : sc<T>::zero();     // (condition uniform in the wavefront)
+          }
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (q0 + u < CPW) {
@@ -529,10 +548,19 @@ __global__ __launch_bounds__(64 * NW) void house_reg_kernel(const tmf_slab_desc*
 // 90 reflector blocks loaded behind two barriers each).  Phase 2 takes the panels from the last to the first, in place.
 // (Kept apart from the one-panel kernel: with the panel loop around it that one needs 27 more registers and spills.)
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int RMAX, int CPW, int NW>
-__global__ __launch_bounds__(64 * NW) void house_regp_kernel(const tmf_slab_desc* __restrict__ desc) {
+template <typename T, int RMAX, int CPW, int NW, bool STAMPS>
+__global__ __launch_bounds__(64 * NW) void house_regp_kernel(const tmf_slab_desc* __restrict__ desc, unsigned long long* __restrict__ dbg) {
   extern __shared__ __align__(16) unsigned char smem[];
   const tmf_slab_desc d = desc[blockIdx.x];
+  // diagnostics (TMF_SLAB_STAMPS=1): clock of wavefront 1 per part, summed over the launch's blocks of more than 256 rows
+  if (!STAMPS || d.n <= 256) dbg = nullptr;
+  unsigned long long tq = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull, tacc[STAMPS ? 8 : 1] = {0};
+  auto lap = [&](int i) {
+    if constexpr (STAMPS) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tacc[i] += now - tq, tq = now;
+    }
+  };
   const int n = d.n, c = d.c;
   if (n <= 0 || c <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -619,12 +647,31 @@ __global__ __launch_bounds__(64 * NW) void house_regp_kernel(const tmf_slab_desc
           for (int i = 0; i < RMAX; ++i) dot[u] = sc<T>::fmacc(dot[u], vr[i], col[q0 + u][i]);
         }
       }
+      if constexpr (!sc<T>::cplx && CPW >= 3) {      // all four sums by one folded reduction
+        if (q0 + 2 < CPW) {
+          wave_sum64x4(dot[0], dot[1], dot[2], dot[3]);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (q0 + u < CPW) {
-          const int j = p0 + wave + NW * (q0 + u);
-          dot[u] = (j >= lo && j != skip) ? sc<T>::mul(f, wave_sum64(dot[u])) : sc<T>::zero();     // (condition uniform in the wavefront)
+          for (int u = 0; u < 4; ++u)
+            if (q0 + u < CPW) {
+              const int j = p0 + wave + NW * (q0 + u);
+              dot[u] = (j >= lo && j != skip) ? f * dot[u] : 0.0;
+            }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (q0 + u < CPW) {
+              const int j = p0 + wave + NW * (q0 + u);
+              dot[u] = (j >= lo && j != skip) ? sc<T>::mul(f, wave_sum64(dot[u])) : sc<T>::zero();
+            }
         }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (q0 + u < CPW) {
+            const int j = p0 + wave + NW * (q0 + u);
+            dot[u] = (j >= lo && j != skip) ? sc<T>::mul(f, wave_sum64(dot[u])) : sc<T>::zero();     // (condition uniform in the wavefront)
+          }
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (q0 + u < CPW) {
@@ -679,6 +726,7 @@ __global__ __launch_bounds__(64 * NW) void house_regp_kernel(const tmf_slab_desc
       }
       __builtin_amdgcn_sched_barrier(0);      // (one column's addresses at a time: hoisted together they spill the columns)
     }
+    lap(0);
     // the reflectors of the earlier panels, read back from A one per step; the entry of reflector k + 2 is on its way from
     // memory while reflector k is applied
     const int kprev = p0 < K ? p0 : K;
@@ -694,22 +742,31 @@ __global__ __launch_bounds__(64 * NW) void house_regp_kernel(const tmf_slab_desc
         __syncthreads();
       }
     }
+    lap(1);
     const int kend = (p0 + PW < K) ? p0 + PW : K;
     if (wave == 0 && p0 < K) build(p0, std::integral_constant<int, 0>{}, slots + (size_t)(p0 & 1) * NS);
     __syncthreads();
+    // One barrier per column; everybody waits for the chain of the wavefront that owns column k + 1 (reflector k on it, then
+    // reflector k + 1 from it: two dependent wave reductions, 1 900 of the 3 700 ticks of a step; its other columns 800).
+    // Tried without gain: those other columns one step later (three slots; the compiler then spills 44 B per lane), a higher
+    // issue priority for the chain (s_setprio).
     for (int k = p0; k < kend; ++k) {
       const T* cur = slots + (size_t)(k & 1) * NS;
       const T f = sc<T>::conj(taus[k]);
       const int k1 = k + 1, kk1 = k1 - p0, q1 = kk1 / NW;
       const bool next_owner = (kk1 % NW) == wave && kk1 < PW && k1 < c;
+      lap(2);
       if (next_owner) {      // column k + 1 first, then its reflector into the other slot while the others still apply this one
         with_q(q1, [&](auto tag) {
           apply_one(f, cur, tag);
           if (k1 < K) build(k1, tag, slots + (size_t)(k1 & 1) * NS);
         });
+        lap(3);
       }
       apply_range(f, cur, k1, next_owner ? k1 : -1);
+      lap(next_owner ? 4 : 5);
       __syncthreads();
+      lap(6);
     }
     // R (c x c, zero rows beyond K), optionally as R^H: straight from the registers
     if (R) {
@@ -730,7 +787,13 @@ __global__ __launch_bounds__(64 * NW) void house_regp_kernel(const tmf_slab_desc
     }
     // the reflectors go to A (below the diagonal): the later panels and phase 2 read them there
     if (!(d.flags & 4) || npan > 1) store_cols(A, lda);
+    lap(7);
   }
+  if constexpr (STAMPS)
+    if (dbg && tid == 64) {
+      for (int i = 0; i < 8; ++i) atomicAdd(&dbg[i], tacc[i]);
+      atomicAdd(&dbg[8], 1ull), atomicAdd(&dbg[9], (unsigned long long)n);
+    }
   if (d.flags & 4) return;      // only R wanted
   if (d.flags & 8) {            // Q later (tmf_house_form_q_batched): the scalars of the reflectors to the caller's buffer
     __syncthreads();
@@ -878,12 +941,13 @@ static int house_slab_launch(int dtype, const tmf_slab_desc* d_desc, int nprob, 
       static const bool panels = !(getenv("TMF_SLAB_REG_PANELS") && atoi(getenv("TMF_SLAB_REG_PANELS")) == 0);
       if (panels && max_n <= 320) {
         const size_t lds_r = ((size_t)2 * 320 + (size_t)max_c + 4) * elem + 64;
-        hipLaunchKernelGGL((house_regp_kernel<double, 5, 5, 16>), dim3(nprob), dim3(1024), lds_r, s, d_desc);
+        if (slab_stamps()) hipLaunchKernelGGL((house_regp_kernel<double, 5, 5, 16, true>), dim3(nprob), dim3(1024), lds_r, s, d_desc, slab_stamps());
+        else hipLaunchKernelGGL((house_regp_kernel<double, 5, 5, 16, false>), dim3(nprob), dim3(1024), lds_r, s, d_desc, nullptr);
         return check_hip(hipGetLastError(), "tmf_house_slab_batched (register form, panels)");
       }
       if (panels && max_n <= 512) {
         const size_t lds_r = ((size_t)2 * 512 + (size_t)max_c + 4) * elem + 64;
-        hipLaunchKernelGGL((house_regp_kernel<double, 8, 2, 16>), dim3(nprob), dim3(1024), lds_r, s, d_desc);
+        hipLaunchKernelGGL((house_regp_kernel<double, 8, 2, 16, false>), dim3(nprob), dim3(1024), lds_r, s, d_desc, nullptr);
         return check_hip(hipGetLastError(), "tmf_house_slab_batched (register form, panels)");
       }
     }
