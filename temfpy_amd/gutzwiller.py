@@ -424,7 +424,12 @@ class _Launches:
         return len(self.spans) - 1
 
     def table(self):
-        return np.concatenate(self.descs) if self.descs else np.zeros(0, self.dtype)
+        if not self.descs:
+            return np.zeros(0, self.dtype)
+        # (as bytes: np.concatenate of structured arrays promotes the field list once per array, 20 ms for a thousand launches)
+        sz = self.dtype.itemsize
+        raw = np.concatenate([np.ascontiguousarray(d_).view(np.uint8).reshape(len(d_), sz) for d_ in self.descs])
+        return raw.reshape(-1).view(self.dtype)
 
 
 class _Arena:
@@ -459,6 +464,34 @@ def _gemm_tiles(d):
     tiles = np.zeros((total, 4), np.int32)
     tiles[:, 0], tiles[:, 1], tiles[:, 2] = prob, local % tm[prob], local // tm[prob]
     return tiles, tn
+
+
+def _gemm_tiles_spans(d, spans):
+    """The tile tables of every launch of a GEMM descriptor table at once: (tiles, [(first tile, count)], [tile_n])."""
+    if not spans:
+        return np.zeros((0, 4), np.int32), [], []
+    starts = np.array([o for o, _ in spans], np.int64)
+    lens = np.array([n for _, n in spans], np.int64)
+    N, M = d["N"].astype(np.int64), d["M"].astype(np.int64)
+    tn_span = np.full(len(spans), 64, np.int64)
+    nz = lens > 0
+    if nz.any():
+        mx = np.maximum.reduceat(N, starts[nz]) if len(N) else np.zeros(0, np.int64)
+        # (reduceat runs to the next start: spans are contiguous and in order, empty ones skipped)
+        tn_span[nz] = np.where(mx <= 16, 16, 64)
+    span_of = np.repeat(np.arange(len(spans)), lens)
+    tn = tn_span[span_of]
+    tm = _cdiv(M, 64)
+    cnt = tm * _cdiv(N, tn)
+    total = int(cnt.sum())
+    prob_g = np.repeat(np.arange(len(d)), cnt)                    # index into the whole table
+    local = np.arange(total) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    tiles = np.zeros((total, 4), np.int32)
+    tiles[:, 0] = prob_g - starts[span_of][prob_g]                 # problem index inside its launch
+    tiles[:, 1], tiles[:, 2] = local % tm[prob_g], local // tm[prob_g]
+    per_span = np.bincount(span_of, weights=cnt, minlength=len(spans)).astype(np.int64)
+    first = np.cumsum(per_span) - per_span
+    return tiles, [(int(a), int(b)) for a, b in zip(first, per_span)], [int(x) for x in tn_span]
 
 
 def _dominant_eigenpair(apply, v0, tol=2e-15, krylov=24, restarts=400, stagnation=1e-11):
@@ -600,9 +633,23 @@ class _Projector:
 
     # ---- run ------------------------------------------------------------------------------------
     def run(self, canonical=True):
+        """(The collector is paused for the call: the tables are tens of thousands of small Python objects, and a collection
+        of the oldest generation in the middle of building them cost 40 - 50 ms in one call out of three.)"""
+        import gc
+
+        was = gc.isenabled()
+        gc.disable()
+        try:
+            return self._run(canonical)
+        finally:
+            if was:
+                gc.enable()
+
+    def _run(self, canonical=True):
         torch, lib, f = self.torch, self.lib, self.f
         t0 = time.perf_counter()
         self.plan()
+        self.timings["setup: plan"] = time.perf_counter() - t0
         Ls, el = self.Ls, self.elem
         stream = torch.cuda.current_stream(self.device).cuda_stream
         ar = _Arena(el)
@@ -670,6 +717,8 @@ class _Projector:
             Tpong = {k: ar.take(self.sect[k[0]][k[2]] * self.sect[k[0] + 1][x3]) for k, x3 in
                      (((x[0], x[1], x[2]), x[3]) for x in self.sb[0])}
 
+        self.timings["setup: layout"] = time.perf_counter() - t0 - self.timings["setup: plan"]
+        t_al = time.perf_counter()
         d_ar = torch.zeros(ar.n, dtype=torch.complex128 if self.cplx else torch.float64, device=self.device)
         base = d_ar.data_ptr()
         P = lambda off: base + el * off                      # noqa: E731
@@ -688,6 +737,7 @@ class _Projector:
             cp[i] = (fbase + el * int(r["off"]), P(Foff[k][0]), int(r["rows"]), int(r["cols"]), int(r["ld"]),
                      Foff[k][1], 1 if r["trans"] else 0, 0)
         keep_alive = [d_flat]
+        self.timings["setup: arena + upload"] = time.perf_counter() - t_al
         self._copy(cp, stream, keep_alive)
         Fptr = {k: P(v[0]) for k, v in Foff.items()}
         if scale_blocks:      # Lambda on the left index of the centre tensor: F' = diag(lam) F by the GEMM kernel
@@ -845,15 +895,7 @@ class _Projector:
             jd = jd[np.argsort(-jd["p"], kind="stable")]          # one launch over all bonds: large problems first
         # upload all tables
         gt = G.table()
-        tiles, tile_span, tile_n = [], [], []
-        to = 0
-        for (o, n) in G.spans:
-            tl, tn = _gemm_tiles(gt[o: o + n])
-            tiles.append(tl)
-            tile_span.append((to, len(tl)))
-            tile_n.append(tn)
-            to += len(tl)
-        tiles = np.concatenate(tiles) if tiles else np.zeros((0, 4), np.int32)
+        tiles, tile_span, tile_n = _gemm_tiles_spans(gt, G.spans)
         tabs_h = {"g": gt, "t": tiles, "cp": CP.table(), "qr": QR.table(), "jc": jd, "rs": RS.table()}
         qr_max = [(int(tabs_h["qr"][o: o + n]["m"].max()), int(tabs_h["qr"][o: o + n]["n"].max())) for o, n in QR.spans]
         # The same factorisations through the on-chip slab kernel (panel columns in registers, reflector blocks in
@@ -985,17 +1027,22 @@ class _Projector:
                       f"mean {h[big].mean():.1f} hist {np.bincount(h[big]).tolist()}", flush=True)
         else:
             # ================= two QR-only sweeps, independent of each other, on two HIP streams =================
-            side = torch.cuda.Stream(device=self.device)
+            # (Two streams taken from the pool one after the other: streams share the device's few hardware queues round robin,
+            # and a side stream next to the CURRENT stream landed on the current stream's queue in one call out of four or
+            # five - the sweeps then ran one after the other, 220 instead of 114 ms at config 5.)
+            first, side = torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)
+            first.wait_stream(cur)
             side.wait_stream(cur)
-            s2 = side.cuda_stream
+            sa, s2 = first.cuda_stream, side.cuda_stream
             for jstep, ((ga, qa, ra_), (gb_, cb_, qb, rb_)) in enumerate(zip(steps1, steps2)):     # interleaved issue: both queues stay fed
-                gemm(ga, s1)
-                qr(qa, s1)
-                rescale(ra_, s1, 0, jstep + 1)               # R_{j+1}
+                gemm(ga, sa)
+                qr(qa, sa)
+                rescale(ra_, sa, 0, jstep + 1)               # R_{j+1}
                 gemm(gb_, s2)
                 copy(cb_, s2)
                 qr(qb, s2)
                 rescale(rb_, s2, 1, Ls - 1 - jstep)          # L_j, j = Ls - 1 - jstep
+            cur.wait_stream(first)
             cur.wait_stream(side)
             bond_exp = None
             if cell is None:
