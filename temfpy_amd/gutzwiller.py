@@ -175,6 +175,26 @@ def _sector_table(q):
     return {int(v): (int(a), int(b - a)) for v, a, b in zip(vals, start, stop)}
 
 
+def _sector_tables(charges):
+    """_sector_table of every bond from one pass over the concatenated charges."""
+    nb = len(charges)
+    sizes = np.array([len(q) for q in charges], np.int64)
+    if nb == 0 or sizes.sum() == 0:
+        return [{} for _ in range(nb)]
+    q = np.concatenate([np.asarray(x, np.int64) for x in charges])
+    bond = np.repeat(np.arange(nb), sizes)
+    off = np.concatenate(([0], np.cumsum(sizes)))
+    same_bond = bond[1:] == bond[:-1]
+    assert np.all(q[1:][same_bond] >= q[:-1][same_bond]), "bond charges must be sorted"
+    new = np.concatenate(([True], ~same_bond | (q[1:] != q[:-1])))
+    st = np.nonzero(new)[0]                                   # first index of every (bond, charge) run
+    ln = np.diff(np.concatenate((st, [q.size])))
+    rb = bond[st]
+    first_run = np.searchsorted(rb, np.arange(nb + 1))
+    v_l, s_l, n_l = q[st].tolist(), (st - off[rb]).tolist(), ln.tolist()
+    return [dict(zip(v_l[a:b], zip(s_l[a:b], n_l[a:b]))) for a, b in zip(first_run[:-1].tolist(), first_run[1:].tolist())]
+
+
 def _fermions_from_shard(mps):
     """The same adapter from the flat tables of a conversion that one rank did in full (the usual case): every record of
     every site at once, no per-site objects (87 -> ~10 ms of host time at 1024 sites).  None if the MPS is not of that kind."""
@@ -195,7 +215,7 @@ def _fermions_from_shard(mps):
     cpos = sh.cpos
     chi = A["c_chi"][cpos[np.arange(L + 1)]].astype(np.int64)
     f.charges = [np.asarray(A["c_q"][cpos[b], : chi[b]], np.int64) for b in range(L + 1)]
-    f.tabs = [_sector_table(q) for q in f.charges]
+    f.tabs = _sector_tables(f.charges)
     f.lam_c = np.asarray(mps.bonds[mps.ortho_center].lam)
     nsec = A["nsec"].astype(np.int64)
     site = np.repeat(np.arange(L), nsec)
@@ -484,11 +504,10 @@ def _gemm_tiles_spans(d, spans):
     tm = _cdiv(M, 64)
     cnt = tm * _cdiv(N, tn)
     total = int(cnt.sum())
-    prob_g = np.repeat(np.arange(len(d)), cnt)                    # index into the whole table
-    local = np.arange(total) - np.repeat(np.cumsum(cnt) - cnt, cnt)
     tiles = np.zeros((total, 4), np.int32)
-    tiles[:, 0] = prob_g - starts[span_of][prob_g]                 # problem index inside its launch
-    tiles[:, 1], tiles[:, 2] = local % tm[prob_g], local // tm[prob_g]
+    tiles[:, 0] = np.repeat((np.arange(len(d)) - starts[span_of]).astype(np.int32), cnt)      # problem index inside its launch
+    local = np.arange(total, dtype=np.int32) - np.repeat((np.cumsum(cnt) - cnt).astype(np.int32), cnt)
+    tiles[:, 2], tiles[:, 1] = np.divmod(local, np.repeat(tm.astype(np.int32), cnt))
     per_span = np.bincount(span_of, weights=cnt, minlength=len(spans)).astype(np.int64)
     first = np.cumsum(per_span) - per_span
     return tiles, [(int(a), int(b)) for a, b in zip(first, per_span)], [int(x) for x in tn_span]
@@ -574,11 +593,10 @@ class _Projector:
         f = self.f
         Ls = f.L // 2
         tabs = getattr(f, "tabs", None) or [_sector_table(q) for q in f.charges]
-        blk = {}
-        for k, r in enumerate(f.blocks):
-            key = (int(r["site"]), int(r["p"]), int(r["cl"]))
-            assert key not in blk, "a physical state maps a left charge sector to one right sector"
-            blk[key] = (int(r["cr"]), k)
+        fb = f.blocks                 # (column lists: iterating the records of a structured array costs 1 us per field)
+        keys = list(zip(fb["site"].tolist(), fb["p"].tolist(), fb["cl"].tolist()))
+        blk = dict(zip(keys, zip(fb["cr"].tolist(), range(len(fb)))))
+        assert len(blk) == len(keys), "a physical state maps a left charge sector to one right sector"
         kept = []
         for j in range(Ls + 1):
             kept.append({c: n for c, (st, n) in tabs[2 * j].items() if self.keep_fn(j, c)})
@@ -656,11 +674,11 @@ class _Projector:
         # -- fermion blocks F (regrouped, column-major) and centre scaling matrices
         need = sorted({x[4] for row in self.sb for x in row} | {x[5] for row in self.sb for x in row})
         Foff = {}
+        b_rows, b_cols, b_trans, b_site = (f.blocks[x].tolist() for x in ("rows", "cols", "trans", "site"))
         for k in need:
-            r = f.blocks[k]
-            n_l, n_r = (int(r["cols"]), int(r["rows"])) if r["trans"] else (int(r["rows"]), int(r["cols"]))
+            n_l, n_r = (b_cols[k], b_rows[k]) if b_trans[k] else (b_rows[k], b_cols[k])
             Foff[k] = (ar.take(n_l * n_r), n_l, n_r)
-        scale_blocks = [k for k in need if int(f.blocks[k]["site"]) == f.oc and f.oc < f.L]
+        scale_blocks = [k for k in need if b_site[k] == f.oc and f.oc < f.L]
         Goff = {k: ar.take(Foff[k][1] * Foff[k][2]) for k in scale_blocks}
         # -- spin blocks T, V (left-merged), V2, W (right-merged), Y, Z, Vz, Bh, X, R
         Toff = {}
@@ -732,10 +750,11 @@ class _Projector:
             d_flat = f.flat.to(self.device, non_blocking=True)
         fbase = d_flat.data_ptr()
         cp = np.zeros(len(need), nat.copy_desc)
-        for i, k in enumerate(need):
-            r = f.blocks[k]
-            cp[i] = (fbase + el * int(r["off"]), P(Foff[k][0]), int(r["rows"]), int(r["cols"]), int(r["ld"]),
-                     Foff[k][1], 1 if r["trans"] else 0, 0)
+        if need:
+            sel = f.blocks[np.asarray(need, np.int64)]
+            cp["src"], cp["dst"] = fbase + el * sel["off"].astype(np.int64), base + el * np.array([Foff[k][0] for k in need], np.int64)
+            cp["rows"], cp["cols"], cp["lds_"] = sel["rows"], sel["cols"], sel["ld"]
+            cp["ldd"], cp["flags"] = np.array([Foff[k][1] for k in need], np.int64), np.where(sel["trans"] != 0, 1, 0)
         keep_alive = [d_flat]
         self.timings["setup: arena + upload"] = time.perf_counter() - t_al
         self._copy(cp, stream, keep_alive)

@@ -476,3 +476,34 @@ def test_group_order_of_the_centre_cut():
     assert _group_order(np.array([0.7, 0.7, 0.3, 0.3]), 1e-12) is None  # exact pairs keep their places
     p = _group_order(np.array([0.6, 0.55, 0.52]), 0.1)
     np.testing.assert_array_equal(p, [2, 1, 0])
+
+
+def test_gutzwiller_table_helpers_vectorised_forms():
+    """_gemm_tiles_spans / _sector_tables (all launches / bonds at once) against the per-launch / per-bond forms."""
+    from temfpy_amd import gutzwiller as g, _native as nat
+
+    rng = np.random.default_rng(0)
+    spans, ds, o = [], [], 0
+    for _ in range(300):
+        n = int(rng.integers(0, 6))
+        d = np.zeros(n, nat.gemm_desc)
+        d["M"] = rng.integers(0, 300, n)
+        d["N"] = rng.integers(0, 17 if rng.random() < 0.3 else 300, n)
+        ds.append(d)
+        spans.append((o, n))
+        o += n
+    t = np.concatenate(ds)
+    tiles, ts, tn = g._gemm_tiles_spans(t, spans)
+    for (o, n), (a, b), x in zip(spans, ts, tn):
+        tl, tnn = g._gemm_tiles(t[o: o + n])
+        assert (tnn == x or n == 0) and b == len(tl) and np.array_equal(tiles[a: a + b], tl)
+    assert g._gemm_tiles_spans(t[:0], []) [1:] == ([], [])
+    ch = [np.sort(rng.integers(-3, 4, int(rng.integers(0, 40)))) for _ in range(200)]
+    assert g._sector_tables(ch) == [g._sector_table(q) for q in ch]
+    assert g._sector_tables([]) == [] and g._sector_tables([np.zeros(0, int)]) == [{}]
+    L = g._Launches(nat.qr_desc)
+    a, b = np.zeros(2, nat.qr_desc), np.zeros(3, nat.qr_desc)
+    a["m"], b["n"] = [1, 2], [3, 4, 5]
+    L.add(a), L.add(b)
+    tab = L.table()
+    assert tab.dtype == nat.qr_desc and tab["m"].tolist() == [1, 2, 0, 0, 0] and tab["n"].tolist() == [0, 0, 3, 4, 5]
