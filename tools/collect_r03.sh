@@ -6,9 +6,6 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03
 mkdir -p $O
 cd $R
-python bench.py > $O/bench_r03.json 2> $O/bench_r03.err || exit 1
-echo bench done
-TMF_BENCH_SAME_DEVICE=1 python bench.py --gpus 2 --steps 5 --warmup 2 --cpu-sample 0 > $O/bench_r03_2ranks_one_gpu.json 2> $O/bench_2.err || exit 1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/prof -o sweep -- python3 $R/tools/profile_sweep.py 1024 512 10 > $O/prof.log 2>&1 || exit 1
 echo stats done
@@ -21,6 +18,10 @@ cd $R
 python tools/rocpd_stats.py $O/prof/sweep_results.db $O/bench_kernel_stats.csv > $O/kernel_stats.txt
 python tools/rocpd_stats.py $O/prof_shard/shard_results.db $O/shard_8way_rank3_kernel_stats.csv > /dev/null
 python tools/pmc_traffic.py $O/pmc_w/w_counter_collection.csv $O/pmc_f/f_counter_collection.csv $O/pmc_traffic.json > /dev/null
+cp $O/pmc_traffic.json $R/profiles/r03/pmc_traffic.json      # bench.py reads it there (and refuses a file of other sources)
+python bench.py > $O/bench_r03.json 2> $O/bench_r03.err || exit 1
+TMF_BENCH_SAME_DEVICE=1 python bench.py --gpus 2 --steps 5 --warmup 2 --cpu-sample 0 > $O/bench_r03_2ranks_one_gpu.json 2> $O/bench_2.err || exit 1
+echo bench done
 python tools/pmc_sq.py $O/pmc_sq/sq_counter_collection.csv $O/pmc_mfma_lds.json > /dev/null 2>&1
 python tools/run_cfg4.py --reps 3 > $O/cfg4_kitaev_L512_chi256.log 2>&1
 python tools/run_cfg4.py --random --reps 3 > $O/cfg4_random_bdg_L512_chi256.log 2>&1
