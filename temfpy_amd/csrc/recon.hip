@@ -6,7 +6,7 @@
 //   mode 1:  dev = max_{r,c} | T[r,c] - sum_i conj(X[i,r]) Y[i,c] |,  T = identity when its address is 0
 //            ("vL is not unitary", evaluated as V^H V on the kept columns)
 //
-// Nothing is materialised: a 64 x 64 tile per workgroup, 4 x 4 outputs per thread, operands staged
+// Nothing is materialised: a 64 x 64 tile per workgroup, 4 x 4 outputs per thread (rows ty + 16 a, columns tx + 16 b), operands staged
 // through LDS in slices of 8, the tile maximum folded into the problem's result with an atomic max
 // on the (non-negative) bit pattern.
 #include "common.hpp"
@@ -64,9 +64,9 @@ __global__ __launch_bounds__(256) void recon_error_kernel(const tmf_recon_desc* 
     for (int kk = 0; kk < RK; ++kk) {
       T xa[4], yb[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) xa[a] = Xs[kk][ty * 4 + a];
+      for (int a = 0; a < 4; ++a) xa[a] = Xs[kk][ty + 16 * a];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) yb[b] = Ys[kk][tx * 4 + b];
+      for (int b = 0; b < 4; ++b) yb[b] = Ys[kk][tx + 16 * b];      // (lanes on consecutive elements: tx * 4 + b cost 4.6 bank conflicts per LDS cycle)
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void recon_error_kernel(const tmf_recon_desc* 
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int r = r0 + ty * 4 + a, c = c0 + tx * 4 + b;
+      const int r = r0 + ty + 16 * a, c = c0 + tx + 16 * b;
       if (r < d.rows && c < d.cols) {
         T t = Tg ? Tg[(size_t)r + (size_t)c * d.ldt] : ((r == c) ? sc<T>::one() : sc<T>::zero());
         const double v = sqrt(sc<T>::abs2(sc<T>::sub(t, acc[a][b])));
