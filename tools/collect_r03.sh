@@ -26,4 +26,9 @@ python tools/pmc_sq.py $O/pmc_sq/sq_counter_collection.csv $O/pmc_mfma_lds.json 
 python tools/run_cfg4.py --reps 3 > $O/cfg4_kitaev_L512_chi256.log 2>&1
 python tools/run_cfg4.py --random --reps 3 > $O/cfg4_random_bdg_L512_chi256.log 2>&1
 python tools/run_cfg5.py --reps 3 --json $O/cfg5_gutzwiller_parallel.json > $O/cfg5_gutzwiller_parallel.log 2>&1
+python tools/run_cfg5.py --reps 3 --method sequential > $O/cfg5_gutzwiller_sequential.log 2>&1
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $O/prof_c5 -o c5 -- python3 $R/tools/run_cfg5.py --reps 3 > $O/prof_c5.log 2>&1 || exit 1
+cd $R
+python tools/rocpd_stats.py $O/prof_c5/c5_results.db $O/cfg5_gutzwiller_kernel_stats.csv > /dev/null
 echo collected
