@@ -819,169 +819,6 @@ class _Projector:
                                                     stream=stream, keep=keep_alive, Tping=Tping, Tpong=Tpong))
             self.timings["fixed points"] = time.perf_counter() - t1
             self.timings["cell applications"] = self.cell_applications
-        G, CP, QR, RS = _Launches(nat.gemm_desc), _Launches(nat.copy_desc), _Launches(nat.qr_desc), _Launches(nat.rescale_desc)
-        steps1, steps2 = [], []
-        # rightward sweep: V_j = R_j T_j (left-merged), QR in place, R -> bond j+1
-        for j in range(Ls):
-            g = []
-            for x in self.sb[j]:
-                _, sg, c, cp_, *_ = x
-                voff, m, rows = Vinfo[j][cp_]
-                n, npr = self.sect[j][c], self.sect[j + 1][cp_]
-                g.append((P(Rb[j][c]), P(Toff[(j, sg, c)]), P(voff + rows[(sg, c)]), n, npr, n, n, n, m))
-            qd = np.zeros(len(Vinfo[j]), nat.qr_desc)
-            rs = np.zeros(len(Vinfo[j]), nat.rescale_desc)
-            for i, (cp_, (voff, m, rows)) in enumerate(Vinfo[j].items()):
-                npr = self.sect[j + 1][cp_]
-                qd[i] = (P(voff), P(Rb[j + 1][cp_]), m, npr, m, npr, 2 if self.method == "parallel" else 4, 0)   # parallel: nothing reads Q; else: every Q after the sweep
-                rs[i] = (P(Rb[j + 1][cp_]), npr, npr, npr, 0)
-            steps1.append((G.add(_gemm_recs(g)), QR.add(qd), RS.add(rs)))
-        sv_ptr, cnt_ptr = d_sv.data_ptr(), d_cnt.data_ptr()
-        jd, tail = np.zeros(n_sec_tot, nat.jacobi_desc), None
-        for j in range(Ls + 1):
-            for c, n in self.sect[j].items():
-                i = cnt_index[(j, c)]
-                # Jacobi without accumulator on the conjugate transpose of the QR-preconditioned factor (graded
-                # columns): its sorted, normalised left singular vectors are the wanted right ones
-                jd[i] = (P(Jwb[j][c]), 0, P(Vzb[j][c]), sv_ptr + 8 * So[j][c], cnt_ptr + 4 * i, self.cutoff ** 2, n, n, n, n)
-        if self.method == "sequential":
-            # leftward sweep, one SVD per site as TeNPy does it (X = U S of bond j+1 lives in the L buffers):
-            # N = A_j X_{j+1}, Y = N^H = Q R, second QR R^H = Q3 R3 (preconditioner: R3 is nearly diagonal), Jacobi on
-            # R3^H gives the right singular vectors V3 of R3, so N = (Q3 U3) S (Q V3)^H: B^H = Q V3, X_j = N B^H
-            for j in range(Ls - 1, -1, -1):
-                g, cpy, gb, gx, wl, o = [], [], [], [], {}, 0
-                for c, v in Winfo[j].items():
-                    wl[c] = o
-                    o += (self.sect[j][c] * v[1] + 1) & ~1
-                for x in self.sb[j]:
-                    _, sg, c, cp_, *_ = x
-                    voff, m, rows = Vinfo[j][cp_]
-                    n, npr = self.sect[j][c], self.sect[j + 1][cp_]
-                    cols = Winfo[j][c][2]
-                    g.append((P(voff + rows[(sg, c)]), P(Lb[j + 1][cp_]), P(Wo + wl[c] + n * cols[(sg, cp_)]),
-                              n, npr, npr, m, npr, n))
-                qd, qd2 = np.zeros(len(Winfo[j]), nat.qr_desc), np.zeros(len(Winfo[j]), nat.qr_desc)
-                for i, (c, v) in enumerate(Winfo[j].items()):
-                    n, w = self.sect[j][c], v[1]
-                    cpy.append((P(Wo + wl[c]), P(Yq[j][c]), n, w, n, w, 3 if self.cplx else 1, 0))
-                    qd[i] = (P(Yq[j][c]), P(Cb[j][c]), w, n, w, n, 1, 0)
-                    qd2[i] = (P(Cb[j][c]), P(Jwb[j][c]), n, n, n, n, 3, 0)       # R3^H only, Q3 is not needed
-                    gb.append((P(Yq[j][c]), P(Vzb[j][c]), P(Bho[j][c]), w, n, n, w, n, w))
-                    gx.append((P(Wo + wl[c]), P(Bho[j][c]), P(Lb[j][c]), n, n, w, n, w, n))
-                i0 = cnt_index[(j, next(iter(self.sect[j])))]
-                steps2.append((G.add(_gemm_recs(g)), CP.add(np.array(cpy, nat.copy_desc)), QR.add(qd), QR.add(qd2),
-                               (i0, len(self.sect[j]), max(self.sect[j].values())), G.add(_gemm_recs(gb)),
-                               G.add(_gemm_recs(gx))))
-        else:
-            # leftward sweep: W_j = T_j L_{j+1} (right-merged), Y = W^H = Q~ R, L_j = R^H
-            for j in range(Ls - 1, -1, -1):
-                g, cpy, wl, o = [], [], {}, 0
-                for c, v in Winfo[j].items():
-                    wl[c] = o
-                    o += (self.sect[j][c] * v[1] + 1) & ~1
-                for x in self.sb[j]:
-                    _, sg, c, cp_, *_ = x
-                    n, npr = self.sect[j][c], self.sect[j + 1][cp_]
-                    cols = Winfo[j][c][2]
-                    g.append((P(Toff[(j, sg, c)]), P(Lb[j + 1][cp_]), P(Wo + wl[c] + n * cols[(sg, cp_)]), n, npr, npr, n, npr, n))
-                qd = np.zeros(len(Winfo[j]), nat.qr_desc)
-                rs = np.zeros(len(Winfo[j]), nat.rescale_desc)
-                for i, (c, v) in enumerate(Winfo[j].items()):
-                    n, w = self.sect[j][c], v[1]
-                    cpy.append((P(Wo + wl[c]), P(Yq[j][c]), n, w, n, w, 3 if self.cplx else 1, 0))
-                    qd[i] = (P(Yq[j][c]), P(Lb[j][c]), w, n, w, n, 1 | 4, 0)      # 4: Q~ of every site in one launch after the sweep
-                    rs[i] = (P(Lb[j][c]), n, n, n, 0)
-                steps2.append((G.add(_gemm_recs(g)), CP.add(np.array(cpy, nat.copy_desc)), QR.add(qd), RS.add(rs)))
-            # batched tail: C = R L / norm, SVD of every bond and sector at once, B^H = blockdiag(Vz_{j+1})^H (Q~ Vz_j)
-            gc, g1, g2, gc_bond = [], [], [], []
-            for j in range(Ls + 1):
-                for c, n in self.sect[j].items():
-                    gc.append((P(Rb[j][c]), P(Lb[j][c]), P(Cb[j][c]), n, n, n, n, n, n))
-                    gc_bond.append(j)
-            for j in range(Ls):
-                for c, v in Winfo[j].items():
-                    n, w = self.sect[j][c], v[1]
-                    g1.append((P(Yq[j][c]), P(Vzb[j][c]), P(G1o[j][c]), w, n, n, w, n, w))
-                    for (sg, cp_), c0 in v[2].items():
-                        npr = self.sect[j + 1][cp_]
-                        g2.append((P(Vzb[j + 1][cp_]), P(G1o[j][c] + c0), P(Bho[j][c] + c0), npr, n, npr, npr, w, w))
-            qc = np.zeros(n_sec_tot, nat.qr_desc)
-            for j in range(Ls + 1):
-                for c, n in self.sect[j].items():
-                    qc[cnt_index[(j, c)]] = (P(Cb[j][c]), P(Jwb[j][c]), n, n, n, n, 3, 0)      # C = Q R, R^H -> Jacobi
-            qc = qc[np.argsort(-qc["n"], kind="stable")]
-            tail = (G.add(_gemm_recs(gc)), G.add(_gemm_recs(g1)), G.add(_gemm_recs(g2)), QR.add(qc))
-            jd = jd[np.argsort(-jd["p"], kind="stable")]          # one launch over all bonds: large problems first
-        # upload all tables
-        gt = G.table()
-        tiles, tile_span, tile_n = _gemm_tiles_spans(gt, G.spans)
-        tabs_h = {"g": gt, "t": tiles, "cp": CP.table(), "qr": QR.table(), "jc": jd, "rs": RS.table()}
-        qr_max = [(int(tabs_h["qr"][o: o + n]["m"].max()), int(tabs_h["qr"][o: o + n]["n"].max())) for o, n in QR.spans]
-        # The same factorisations through the on-chip slab kernel (panel columns in registers, reflector blocks in
-        # LDS: 2x faster than the L2-resident kernel at 280 x 140) whenever the rows fit its registers; Q is built
-        # in a scratch (one per sweep direction) and copied over the block.
-        slab_rows = 1024 if self.cplx else 2048
-        use_slab = os.environ.get("TMF_GW_QR", "slab") == "slab" and max(q[0] for q in qr_max) <= slab_rows
-        later = (tabs_h["qr"]["flags"] & 4) != 0            # factorisations whose Q is formed after the sweep
-        if not use_slab or os.environ.get("TMF_GW_Q_LATER", "1") == "0":
-            tabs_h["qr"]["flags"] &= ~np.int32(4)
-            later[:] = False
-        tabs_d = {k: torch.from_numpy(v.view(np.uint8).reshape(-1).copy() if v.size else np.zeros(16, np.uint8)).to(self.device)
-                  for k, v in tabs_h.items()}
-        keep_alive.append(tabs_d)
-        formq = None
-        if use_slab:
-            qt = tabs_h["qr"]
-            sl = np.zeros(len(qt), nat.slab_desc)
-            sl["A"], sl["R"], sl["n"], sl["c"], sl["lda"], sl["ldr"] = qt["A"], qt["R"], qt["m"], qt["n"], qt["lda"], qt["ldr"]
-            sl["flags"] = (qt["flags"] & 1) | np.where(qt["flags"] & 2, 4, 0) | np.where(later, 8, 0)
-            sl["ldq"] = qt["m"]
-            sizes = (qt["m"].astype(np.int64) * qt["n"] + 1) & ~1
-            need, rel = 0, np.zeros(len(qt), np.int64)
-            for o, n in QR.spans:
-                c_ = np.concatenate(([0], np.cumsum(sizes[o: o + n])))
-                rel[o: o + n] = c_[:-1]
-                need = max(need, int(c_[-1]))
-            scratch = [torch.empty(need + 2, dtype=d_ar.dtype, device=self.device) for _ in range(2)]
-            keep_alive.append(scratch)
-            first2 = min([x[2] for x in steps2] + ([tail[3]] if tail is not None else []), default=len(QR.spans))
-            for i, (o, n) in enumerate(QR.spans):      # launches of the rightward sweep come first in the table
-                sl["Q"][o: o + n] = scratch[0 if i < first2 else 1].data_ptr() + el * rel[o: o + n]
-            if later.any():      # their reflector scalars: one buffer for all; the launch that forms every Q, large slabs first
-                ix = np.nonzero(later)[0]
-                toff = np.concatenate(([0], np.cumsum((sl["c"][ix].astype(np.int64) + 1) & ~1)))
-                d_tau = torch.zeros(int(toff[-1]) + 2, dtype=d_ar.dtype, device=self.device)
-                keep_alive.append(d_tau)
-                sl["Q"][ix] = d_tau.data_ptr() + el * toff[:-1]
-                fq = sl[ix][np.argsort(-(sl["n"][ix].astype(np.int64) * sl["c"][ix]), kind="stable")]
-                formq = (torch.from_numpy(fq.view(np.uint8).reshape(-1).copy()).to(self.device), len(fq), int(fq["n"].max()),
-                         int(fq["c"].max()))
-                keep_alive.append(formq)
-            t_sl = torch.from_numpy(sl.view(np.uint8).reshape(-1).copy()).to(self.device)
-            keep_alive.append(t_sl)
-        cp_max = [int((_cdiv(tabs_h["cp"][o: o + n]["rows"].astype(np.int64), 32)
-                       * _cdiv(tabs_h["cp"][o: o + n]["cols"].astype(np.int64), 32)).max()) for o, n in CP.spans]
-        self.timings["descriptors"] = time.perf_counter() - t1
-
-        def gemm(i, st_, opA=0, alpha=1.0):
-            (o, n), (t_o, t_n) = G.spans[i], tile_span[i]
-            nat.check(lib.tmf_gemm_batched(self.dt, opA, alpha, 0.0, tabs_d["g"].data_ptr() + 48 * o,
-                                           tabs_d["t"].data_ptr() + 16 * t_o, t_n, tile_n[i], st_), "tmf_gemm_batched")
-
-        def copy(i, st_):
-            o, n = CP.spans[i]
-            nat.check(lib.tmf_copy_blocks_batched(self.dt, tabs_d["cp"].data_ptr() + 40 * o, n, cp_max[i], st_),
-                      "tmf_copy_blocks_batched")
-
-        def qr(i, st_):
-            o, n = QR.spans[i]
-            if use_slab:
-                nat.check(lib.tmf_house_qr_regs_batched(self.dt, t_sl.data_ptr() + 48 * o, n, qr_max[i][0], qr_max[i][1], st_),
-                          "tmf_house_qr_regs_batched")
-                return
-            nat.check(lib.tmf_house_qr_batched(self.dt, tabs_d["qr"].data_ptr() + 40 * o, n, qr_max[i][0], qr_max[i][1],
-                                               st_), "tmf_house_qr_batched")
-
         # Power-of-two rescaling of the triangular factors after every step (TeNPy's canonical_form_finite renormalises every
         # step): the norm of the projected state falls by a constant factor per site and would leave the range of a double
         # after ~1300 spins.  exps[0 / 1]: running exponents of the two sweeps; exps[2 + j] / exps[2 + Ls + 1 + j]: their values
@@ -990,14 +827,200 @@ class _Projector:
         keep_alive.append(d_exp)
         rescaling = self.shift is None and os.environ.get("TMF_GW_RESCALE", "1") != "0"
 
-        def rescale(i, st_, sweep, bond):
-            if not rescaling:
-                return
-            o, n = RS.spans[i]
-            slot = 2 + sweep * (Ls + 1) + bond
-            nat.check(lib.tmf_rescale_pow2_batched(self.dt, tabs_d["rs"].data_ptr() + 24 * o, n, d_exp.data_ptr() + 8 * sweep,
-                                                   d_exp.data_ptr() + 8 * slot, st_), "tmf_rescale_pow2_batched")
+        def make(sites1, sites2, with_tail):
+            """Descriptor tables of the sweep steps of the given sites (and of the all-bond tail), uploaded; the launch closures."""
+            from types import SimpleNamespace as _NS
 
+            t_mk = time.perf_counter()
+            G, CP, QR, RS = _Launches(nat.gemm_desc), _Launches(nat.copy_desc), _Launches(nat.qr_desc), _Launches(nat.rescale_desc)
+            steps1, steps2 = [], []
+            gc = gc_bond = None
+            # rightward sweep: V_j = R_j T_j (left-merged), QR in place, R -> bond j+1
+            for j in sites1:
+                g = []
+                for x in self.sb[j]:
+                    _, sg, c, cp_, *_ = x
+                    voff, m, rows = Vinfo[j][cp_]
+                    n, npr = self.sect[j][c], self.sect[j + 1][cp_]
+                    g.append((P(Rb[j][c]), P(Toff[(j, sg, c)]), P(voff + rows[(sg, c)]), n, npr, n, n, n, m))
+                qd = np.zeros(len(Vinfo[j]), nat.qr_desc)
+                rs = np.zeros(len(Vinfo[j]), nat.rescale_desc)
+                for i, (cp_, (voff, m, rows)) in enumerate(Vinfo[j].items()):
+                    npr = self.sect[j + 1][cp_]
+                    qd[i] = (P(voff), P(Rb[j + 1][cp_]), m, npr, m, npr, 2 if self.method == "parallel" else 4, 0)   # parallel: nothing reads Q; else: every Q after the sweep
+                    rs[i] = (P(Rb[j + 1][cp_]), npr, npr, npr, 0)
+                steps1.append((G.add(_gemm_recs(g)), QR.add(qd), RS.add(rs)))
+            sv_ptr, cnt_ptr = d_sv.data_ptr(), d_cnt.data_ptr()
+            jd, tail = np.zeros(n_sec_tot if with_tail else 0, nat.jacobi_desc), None
+            for j in range(Ls + 1 if with_tail else 0):
+                for c, n in self.sect[j].items():
+                    i = cnt_index[(j, c)]
+                    # Jacobi without accumulator on the conjugate transpose of the QR-preconditioned factor (graded
+                    # columns): its sorted, normalised left singular vectors are the wanted right ones
+                    jd[i] = (P(Jwb[j][c]), 0, P(Vzb[j][c]), sv_ptr + 8 * So[j][c], cnt_ptr + 4 * i, self.cutoff ** 2, n, n, n, n)
+            if self.method == "sequential":
+                # leftward sweep, one SVD per site as TeNPy does it (X = U S of bond j+1 lives in the L buffers):
+                # N = A_j X_{j+1}, Y = N^H = Q R, second QR R^H = Q3 R3 (preconditioner: R3 is nearly diagonal), Jacobi on
+                # R3^H gives the right singular vectors V3 of R3, so N = (Q3 U3) S (Q V3)^H: B^H = Q V3, X_j = N B^H
+                for j in range(Ls - 1, -1, -1):
+                    g, cpy, gb, gx, wl, o = [], [], [], [], {}, 0
+                    for c, v in Winfo[j].items():
+                        wl[c] = o
+                        o += (self.sect[j][c] * v[1] + 1) & ~1
+                    for x in self.sb[j]:
+                        _, sg, c, cp_, *_ = x
+                        voff, m, rows = Vinfo[j][cp_]
+                        n, npr = self.sect[j][c], self.sect[j + 1][cp_]
+                        cols = Winfo[j][c][2]
+                        g.append((P(voff + rows[(sg, c)]), P(Lb[j + 1][cp_]), P(Wo + wl[c] + n * cols[(sg, cp_)]),
+                                  n, npr, npr, m, npr, n))
+                    qd, qd2 = np.zeros(len(Winfo[j]), nat.qr_desc), np.zeros(len(Winfo[j]), nat.qr_desc)
+                    for i, (c, v) in enumerate(Winfo[j].items()):
+                        n, w = self.sect[j][c], v[1]
+                        cpy.append((P(Wo + wl[c]), P(Yq[j][c]), n, w, n, w, 3 if self.cplx else 1, 0))
+                        qd[i] = (P(Yq[j][c]), P(Cb[j][c]), w, n, w, n, 1, 0)
+                        qd2[i] = (P(Cb[j][c]), P(Jwb[j][c]), n, n, n, n, 3, 0)       # R3^H only, Q3 is not needed
+                        gb.append((P(Yq[j][c]), P(Vzb[j][c]), P(Bho[j][c]), w, n, n, w, n, w))
+                        gx.append((P(Wo + wl[c]), P(Bho[j][c]), P(Lb[j][c]), n, n, w, n, w, n))
+                    i0 = cnt_index[(j, next(iter(self.sect[j])))]
+                    steps2.append((G.add(_gemm_recs(g)), CP.add(np.array(cpy, nat.copy_desc)), QR.add(qd), QR.add(qd2),
+                                   (i0, len(self.sect[j]), max(self.sect[j].values())), G.add(_gemm_recs(gb)),
+                                   G.add(_gemm_recs(gx))))
+            else:
+                # leftward sweep: W_j = T_j L_{j+1} (right-merged), Y = W^H = Q~ R, L_j = R^H
+                for j in sites2:
+                    g, cpy, wl, o = [], [], {}, 0
+                    for c, v in Winfo[j].items():
+                        wl[c] = o
+                        o += (self.sect[j][c] * v[1] + 1) & ~1
+                    for x in self.sb[j]:
+                        _, sg, c, cp_, *_ = x
+                        n, npr = self.sect[j][c], self.sect[j + 1][cp_]
+                        cols = Winfo[j][c][2]
+                        g.append((P(Toff[(j, sg, c)]), P(Lb[j + 1][cp_]), P(Wo + wl[c] + n * cols[(sg, cp_)]), n, npr, npr, n, npr, n))
+                    qd = np.zeros(len(Winfo[j]), nat.qr_desc)
+                    rs = np.zeros(len(Winfo[j]), nat.rescale_desc)
+                    for i, (c, v) in enumerate(Winfo[j].items()):
+                        n, w = self.sect[j][c], v[1]
+                        cpy.append((P(Wo + wl[c]), P(Yq[j][c]), n, w, n, w, 3 if self.cplx else 1, 0))
+                        qd[i] = (P(Yq[j][c]), P(Lb[j][c]), w, n, w, n, 1 | 4, 0)      # 4: Q~ of every site in one launch after the sweep
+                        rs[i] = (P(Lb[j][c]), n, n, n, 0)
+                    steps2.append((G.add(_gemm_recs(g)), CP.add(np.array(cpy, nat.copy_desc)), QR.add(qd), RS.add(rs)))
+                gc = gc_bond = None
+                if with_tail:
+                    # batched tail: C = R L / norm, SVD of every bond and sector at once, B^H = blockdiag(Vz_{j+1})^H (Q~ Vz_j)
+                    gc, g1, g2, gc_bond = [], [], [], []
+                    for j in range(Ls + 1):
+                        for c, n in self.sect[j].items():
+                            gc.append((P(Rb[j][c]), P(Lb[j][c]), P(Cb[j][c]), n, n, n, n, n, n))
+                            gc_bond.append(j)
+                    for j in range(Ls):
+                        for c, v in Winfo[j].items():
+                            n, w = self.sect[j][c], v[1]
+                            g1.append((P(Yq[j][c]), P(Vzb[j][c]), P(G1o[j][c]), w, n, n, w, n, w))
+                            for (sg, cp_), c0 in v[2].items():
+                                npr = self.sect[j + 1][cp_]
+                                g2.append((P(Vzb[j + 1][cp_]), P(G1o[j][c] + c0), P(Bho[j][c] + c0), npr, n, npr, npr, w, w))
+                    qc = np.zeros(n_sec_tot, nat.qr_desc)
+                    for j in range(Ls + 1):
+                        for c, n in self.sect[j].items():
+                            qc[cnt_index[(j, c)]] = (P(Cb[j][c]), P(Jwb[j][c]), n, n, n, n, 3, 0)      # C = Q R, R^H -> Jacobi
+                    qc = qc[np.argsort(-qc["n"], kind="stable")]
+                    tail = (G.add(_gemm_recs(gc)), G.add(_gemm_recs(g1)), G.add(_gemm_recs(g2)), QR.add(qc))
+                    jd = jd[np.argsort(-jd["p"], kind="stable")]          # one launch over all bonds: large problems first
+            # upload all tables
+            gt = G.table()
+            tiles, tile_span, tile_n = _gemm_tiles_spans(gt, G.spans)
+            tabs_h = {"g": gt, "t": tiles, "cp": CP.table(), "qr": QR.table(), "jc": jd, "rs": RS.table()}
+            qr_max = [(int(tabs_h["qr"][o: o + n]["m"].max()), int(tabs_h["qr"][o: o + n]["n"].max())) for o, n in QR.spans]
+            # The same factorisations through the on-chip slab kernel (panel columns in registers, reflector blocks in
+            # LDS: 2x faster than the L2-resident kernel at 280 x 140) whenever the rows fit its registers; Q is built
+            # in a scratch (one per sweep direction) and copied over the block.
+            slab_rows = 1024 if self.cplx else 2048
+            use_slab = os.environ.get("TMF_GW_QR", "slab") == "slab" and max(q[0] for q in qr_max) <= slab_rows
+            later = (tabs_h["qr"]["flags"] & 4) != 0            # factorisations whose Q is formed after the sweep
+            if not use_slab or os.environ.get("TMF_GW_Q_LATER", "1") == "0":
+                tabs_h["qr"]["flags"] &= ~np.int32(4)
+                later[:] = False
+            tabs_d = {k: torch.from_numpy(v.view(np.uint8).reshape(-1).copy() if v.size else np.zeros(16, np.uint8)).to(self.device)
+                      for k, v in tabs_h.items()}
+            keep_alive.append(tabs_d)
+            formq = None
+            if use_slab:
+                qt = tabs_h["qr"]
+                sl = np.zeros(len(qt), nat.slab_desc)
+                sl["A"], sl["R"], sl["n"], sl["c"], sl["lda"], sl["ldr"] = qt["A"], qt["R"], qt["m"], qt["n"], qt["lda"], qt["ldr"]
+                sl["flags"] = (qt["flags"] & 1) | np.where(qt["flags"] & 2, 4, 0) | np.where(later, 8, 0)
+                sl["ldq"] = qt["m"]
+                sizes = (qt["m"].astype(np.int64) * qt["n"] + 1) & ~1
+                need, rel = 0, np.zeros(len(qt), np.int64)
+                for o, n in QR.spans:
+                    c_ = np.concatenate(([0], np.cumsum(sizes[o: o + n])))
+                    rel[o: o + n] = c_[:-1]
+                    need = max(need, int(c_[-1]))
+                scratch = [torch.empty(need + 2, dtype=d_ar.dtype, device=self.device) for _ in range(2)]
+                keep_alive.append(scratch)
+                first2 = min([x[2] for x in steps2] + ([tail[3]] if tail is not None else []), default=len(QR.spans))
+                for i, (o, n) in enumerate(QR.spans):      # launches of the rightward sweep come first in the table
+                    sl["Q"][o: o + n] = scratch[0 if i < first2 else 1].data_ptr() + el * rel[o: o + n]
+                if later.any():      # their reflector scalars: one buffer for all; the launch that forms every Q, large slabs first
+                    ix = np.nonzero(later)[0]
+                    toff = np.concatenate(([0], np.cumsum((sl["c"][ix].astype(np.int64) + 1) & ~1)))
+                    d_tau = torch.zeros(int(toff[-1]) + 2, dtype=d_ar.dtype, device=self.device)
+                    keep_alive.append(d_tau)
+                    sl["Q"][ix] = d_tau.data_ptr() + el * toff[:-1]
+                    fq = sl[ix][np.argsort(-(sl["n"][ix].astype(np.int64) * sl["c"][ix]), kind="stable")]
+                    formq = (torch.from_numpy(fq.view(np.uint8).reshape(-1).copy()).to(self.device), len(fq), int(fq["n"].max()),
+                             int(fq["c"].max()))
+                    keep_alive.append(formq)
+                t_sl = torch.from_numpy(sl.view(np.uint8).reshape(-1).copy()).to(self.device)
+                keep_alive.append(t_sl)
+            cp_max = [int((_cdiv(tabs_h["cp"][o: o + n]["rows"].astype(np.int64), 32)
+                           * _cdiv(tabs_h["cp"][o: o + n]["cols"].astype(np.int64), 32)).max()) for o, n in CP.spans]
+            self.timings["descriptors"] = self.timings.get("descriptors", 0.0) + time.perf_counter() - t_mk
+
+            def gemm(i, st_, opA=0, alpha=1.0):
+                (o, n), (t_o, t_n) = G.spans[i], tile_span[i]
+                nat.check(lib.tmf_gemm_batched(self.dt, opA, alpha, 0.0, tabs_d["g"].data_ptr() + 48 * o,
+                                               tabs_d["t"].data_ptr() + 16 * t_o, t_n, tile_n[i], st_), "tmf_gemm_batched")
+
+            def copy(i, st_):
+                o, n = CP.spans[i]
+                nat.check(lib.tmf_copy_blocks_batched(self.dt, tabs_d["cp"].data_ptr() + 40 * o, n, cp_max[i], st_),
+                          "tmf_copy_blocks_batched")
+
+            def qr(i, st_):
+                o, n = QR.spans[i]
+                if use_slab:
+                    nat.check(lib.tmf_house_qr_regs_batched(self.dt, t_sl.data_ptr() + 48 * o, n, qr_max[i][0], qr_max[i][1], st_),
+                              "tmf_house_qr_regs_batched")
+                    return
+                nat.check(lib.tmf_house_qr_batched(self.dt, tabs_d["qr"].data_ptr() + 40 * o, n, qr_max[i][0], qr_max[i][1],
+                                                   st_), "tmf_house_qr_batched")
+
+            def rescale(i, st_, sweep, bond):
+                if not rescaling:
+                    return
+                o, n = RS.spans[i]
+                slot = 2 + sweep * (Ls + 1) + bond
+                nat.check(lib.tmf_rescale_pow2_batched(self.dt, tabs_d["rs"].data_ptr() + 24 * o, n, d_exp.data_ptr() + 8 * sweep,
+                                                       d_exp.data_ptr() + 8 * slot, st_), "tmf_rescale_pow2_batched")
+            return _NS(steps1=steps1, steps2=steps2, tail=tail, jd=jd, gemm=gemm, copy=copy, qr=qr, rescale=rescale, formq=formq,
+                       tabs_d=tabs_d, gc=gc, gc_bond=gc_bond)
+
+        # The two sweeps of the parallel method start as soon as the tables of their first steps are up: the tables of the later
+        # steps (and of the all-bond tail) are built while the device works on the earlier ones (host: 50 us per step pair, device:
+        # 220 us).  TMF_GW_CHUNKS=0: everything first, as for the other paths.
+        chunked = (self.method == "parallel" and cell is None and Ls >= 96 and os.environ.get("TMF_GW_CHUNKS", "1") != "0")
+        formqs = []
+
+        def bind(T):
+            return (T.steps1, T.steps2, T.tail, T.jd, T.gemm, T.copy, T.qr, T.rescale, T.tabs_d, T.gc, T.gc_bond)
+
+        if not chunked:
+            T = make(range(Ls), range(Ls - 1, -1, -1), True)
+            steps1, steps2, tail, jd, gemm, copy, qr, rescale, tabs_d, gc, gc_bond = bind(T)
+            formqs.append(T.formq)
         cur = torch.cuda.current_stream(self.device)
         s1 = cur.cuda_stream
         t2 = time.perf_counter()
@@ -1007,9 +1030,9 @@ class _Projector:
                 gemm(ga, s1)
                 qr(qa, s1)
                 rescale(ra_, s1, 0, jstep + 1)
-            if formq is not None:      # the isometries of the whole sweep in one launch
-                nat.check(lib.tmf_house_form_q_batched(self.dt, formq[0].data_ptr(), formq[1], formq[2], formq[3], s1),
-                          "tmf_house_form_q_batched")
+            for fq in formqs:          # the isometries of the whole sweep in one launch
+                if fq is not None:
+                    nat.check(lib.tmf_house_form_q_batched(self.dt, fq[0].data_ptr(), fq[1], fq[2], fq[3], s1), "tmf_house_form_q_batched")
             end = next(iter(self.sect[Ls]))
             norm = abs(complex(d_ar[Rb[Ls][end]].item()))                         # (host sync: end of sweep 1)
             if rescaling:                                    # R_Ls = (stored mantissa) 2^e
@@ -1053,14 +1076,26 @@ class _Projector:
             first.wait_stream(cur)
             side.wait_stream(cur)
             sa, s2 = first.cuda_stream, side.cuda_stream
-            for jstep, ((ga, qa, ra_), (gb_, cb_, qb, rb_)) in enumerate(zip(steps1, steps2)):     # interleaved issue: both queues stay fed
-                gemm(ga, sa)
-                qr(qa, sa)
-                rescale(ra_, sa, 0, jstep + 1)               # R_{j+1}
-                gemm(gb_, s2)
-                copy(cb_, s2)
-                qr(qb, s2)
-                rescale(rb_, s2, 1, Ls - 1 - jstep)          # L_j, j = Ls - 1 - jstep
+            def issue(T_, first_step):
+                for jstep, ((ga, qa, ra_), (gb_, cb_, qb, rb_)) in enumerate(zip(T_.steps1, T_.steps2), first_step):     # interleaved issue: both queues stay fed
+                    T_.gemm(ga, sa)
+                    T_.qr(qa, sa)
+                    T_.rescale(ra_, sa, 0, jstep + 1)               # R_{j+1}
+                    T_.gemm(gb_, s2)
+                    T_.copy(cb_, s2)
+                    T_.qr(qb, s2)
+                    T_.rescale(rb_, s2, 1, Ls - 1 - jstep)          # L_j, j = Ls - 1 - jstep
+
+            if chunked:
+                bounds = [b_ for b_ in (0, 16, 64, 224) if b_ < Ls] + [Ls]
+                for a_, b_ in zip(bounds[:-1], bounds[1:]):
+                    Tc = make(range(a_, b_), range(Ls - 1 - a_, Ls - 1 - b_, -1), False)
+                    issue(Tc, a_)
+                    formqs.append(Tc.formq)
+                T = make((), (), True)
+                steps1, steps2, tail, jd, gemm, copy, qr, rescale, tabs_d, gc, gc_bond = bind(T)
+            else:
+                issue(T, 0)
             cur.wait_stream(first)
             cur.wait_stream(side)
             bond_exp = None
@@ -1098,9 +1133,9 @@ class _Projector:
                 for kv in np.unique(ks):
                     self._gemm_now([gc[i] for i in np.nonzero(ks == kv)[0]], 0, s1, keep_alive, alpha=float(np.ldexp(1.0 / norm_mant, int(kv))))
             qr(tail[3], s1)
-            if formq is not None:
-                nat.check(lib.tmf_house_form_q_batched(self.dt, formq[0].data_ptr(), formq[1], formq[2], formq[3], s1),
-                          "tmf_house_form_q_batched")
+            for fq in formqs:
+                if fq is not None:
+                    nat.check(lib.tmf_house_form_q_batched(self.dt, fq[0].data_ptr(), fq[1], fq[2], fq[3], s1), "tmf_house_form_q_batched")
             d_sw = torch.zeros(n_sec_tot, dtype=torch.int32, device=self.device)
             nat.check(lib.tmf_jacobi_compact_batched(self.dt, tabs_d["jc"].data_ptr(), n_sec_tot, int(jd["p"].max()),
                                                      d_sw.data_ptr(), s1), "tmf_jacobi_compact_batched")

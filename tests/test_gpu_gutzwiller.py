@@ -325,6 +325,31 @@ def test_rescaling_inside_the_sweeps_leaves_the_result_alone_and_lifts_the_under
                 assert np.abs(X).max() < 1e-9
 
 
+def test_tables_built_while_the_sweeps_run_give_the_same_result():
+    """From 96 spins on the parallel method starts its two sweeps when the tables of their first 16 steps are up and builds
+    the rest (and the all-bond tail) under them: same launches, same arithmetic - the result must equal the one-piece form
+    (TMF_GW_CHUNKS=0) bit for bit."""
+    from temfpy_amd import gutzwiller, slater
+
+    for Ls, real in ((130, True), (100, False)):
+        H = uniform_chain(Ls) if real else random_hopping(Ls, 5)
+        C, _ = slater.correlation_matrix(H, Ls // 2)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mps = slater.C_to_MPS(C, {"chi_max": 48}, spinful="PH", as_tenpy=False)
+            a = gutzwiller.abrikosov_ph(mps)
+            os.environ["TMF_GW_CHUNKS"] = "0"
+            try:
+                b = gutzwiller.abrikosov_ph(mps)
+            finally:
+                del os.environ["TMF_GW_CHUNKS"]
+        assert a.norm == b.norm and a.log2_norm == b.log2_norm
+        for x, y in zip(a.lam, b.lam):
+            assert np.array_equal(x, y)
+        for x, y in zip(a.dense_tensors(), b.dense_tensors()):
+            assert np.array_equal(x, y)
+
+
 def test_adapter_from_flat_tables_equals_the_per_site_adapter():
     """gutzwiller._fermions_from_shard (all block records of a conversion at once from its flat tables) against the loop over
     the per-site objects: the same records, offsets into the same page-locked buffer and charges."""
