@@ -74,46 +74,59 @@ def shard_sites(L, oc, world):
 def _shard_sites(L, oc, world):
     """Contiguous site ranges that minimise the time of the slowest rank under the cost model
 
-        t(lo, hi) = 3.26 + sum_{i in [lo, hi)} (0.0131 + 0.0109 x_i^3) * 1024 / L + 3.67 max_i x_i^2   [ms],   x_i = n_i / (L / 2),
+        t(lo, hi) = 1.81 + sum_{i in [lo, hi)} (0.0214 - 0.0201 x_i + 0.0202 x_i^3) * 1024 / L + 3.54 max_i x_i^2   [ms],   x_i = n_i / (L / 2),
 
-    n_i = size of the smaller block at site i.  Fitted (0.5 ms residual) to the device times of the 15 shards that world
-    sizes 1, 2, 4, 8 cut out of the benchmark chain (tools/shard_cost.py): a per-site part (determinant stage ~ constant
-    in the chi-saturated bulk, eigen / overlap stages ~ n^3) and a per-rank latency that grows with the largest block of
-    the range - the per-cut kernels of a shard with fewer than 256 cuts take as long as their slowest workgroup."""
+    n_i = size of the smaller block at site i.  Fitted (0.26 ms residual, round 3) to the HOST -> HOST time per conversion of 17
+    site ranges of the benchmark chain, conversions pipelined as bench.py does (tools/shard_host_cost.py): a per-site part (host
+    enumeration and site preparation, determinant stage ~ constant in the chi-saturated bulk, eigen / overlap stages ~ n^3)
+    and a per-rank latency that grows with the largest block of the range - the per-cut kernels of a shard with fewer than 256
+    cuts take as long as their slowest workgroup.  (The round-2 fit was to device times only and off by up to 2.2 ms: the end
+    ranks, with the most sites, were host bound.)"""
     if world > L:
         raise ValueError(f"{world} ranks for {L} sites: every rank needs at least one site")
     i = np.arange(L)
     n = np.where(i < oc, i + 1, L - i)
     x = n / max(L / 2, 1)
-    c1 = np.concatenate(([0.0], np.cumsum((0.01307 + 0.01089 * x ** 3) * (1024.0 / L))))
+    c1 = np.concatenate(([0.0], np.cumsum((0.02142 - 0.02009 * x + 0.02017 * x ** 3) * (1024.0 / L))))
     x2 = x ** 2
 
-    c1, x2 = c1.tolist(), x2.tolist()
+    def greedy(c1, x2):
+        c1, x2 = c1.tolist(), x2.tolist()
 
-    def cut(T):            # greedy: every range as long as the budget T allows
-        b = [0]
-        while b[-1] < L and len(b) <= world:
-            lo = b[-1]
-            hi, mx = lo + 1, x2[lo]
-            while hi < L and 3.26 + (c1[hi + 1] - c1[lo]) + 3.67 * max(mx, x2[hi]) <= T:
-                mx = max(mx, x2[hi])
-                hi += 1
-            b.append(hi)
+        def cut(T):            # every range as long as the budget T allows
+            b = [0]
+            while b[-1] < L and len(b) <= world:
+                lo = b[-1]
+                hi, mx = lo + 1, x2[lo]
+                while hi < L and 1.81 + (c1[hi + 1] - c1[lo]) + 3.54 * max(mx, x2[hi]) <= T:
+                    mx = max(mx, x2[hi])
+                    hi += 1
+                b.append(hi)
+            return b
+
+        lo_T, hi_T = 0.0, 1.81 + c1[L] + 3.54 * max(x2)
+        for _ in range(50):
+            mid = 0.5 * (lo_T + hi_T)
+            b = cut(mid)
+            if b[-1] >= L and len(b) - 1 <= world:
+                hi_T = mid
+            else:
+                lo_T = mid
+        b = cut(hi_T)
+        b[-1] = L
+        while len(b) - 1 < world:          # fewer ranges than ranks (tiny chains): split the longest
+            k = int(np.argmax(np.diff(b)))
+            b.insert(k + 1, (b[k] + b[k + 1]) // 2)
         return b
 
-    lo_T, hi_T = 0.0, 3.26 + c1[L] + 3.67 * max(x2)
-    for _ in range(50):
-        mid = 0.5 * (lo_T + hi_T)
-        b = cut(mid)
-        if b[-1] >= L and len(b) - 1 <= world:
-            hi_T = mid
-        else:
-            lo_T = mid
-    bounds = cut(hi_T)
-    bounds[-1] = L
-    while len(bounds) - 1 < world:          # fewer ranges than ranks (tiny chains): split the longest
-        k = int(np.argmax(np.diff(bounds)))
-        bounds.insert(k + 1, (bounds[k] + bounds[k + 1]) // 2)
+    # The greedy fill leaves the remainder to the last range: filled from the left and from the right, boundary by boundary the
+    # mean of the two (a chain with its centre in the middle gets mirror-symmetric ranges).
+    per_site = (0.02142 - 0.02009 * x + 0.02017 * x ** 3) * (1024.0 / L)
+    left = greedy(c1, x2)
+    right = greedy(np.concatenate(([0.0], np.cumsum(per_site[::-1]))), x2[::-1].copy())
+    twice = [a + (L - b) for a, b in zip(left, right[::-1])]
+    bounds = [m // 2 if 2 * k <= world else (m + 1) // 2 for k, m in enumerate(twice)]      # (rounded towards the nearer end)
+    bounds[0], bounds[-1] = 0, L
     for r in range(1, world):          # strictly increasing: no empty range
         bounds[r] = min(max(bounds[r], bounds[r - 1] + 1), L - (world - r))
     return tuple((bounds[r], bounds[r + 1]) for r in range(world))
