@@ -2024,9 +2024,13 @@ extern "C" int tmf_sweep_info_get(tmf_ctx* ctx, tmf_sweep_info* o) {
   o->n_fermion = ctx->n_fermion, o->device_bytes = (int64_t)(ctx->dev_set[0].total + ctx->dev_set[1].total);
   o->n_det = ctx->n_det;
   if (ctx->lu_pending[0] || ctx->lu_pending[1]) {
+    // Only the verdicts of sweeps that have FINISHED on the device (no wait: with an asynchronous download the caller asks
+    // for the stage timers while the site stage is still running, and a synchronisation here kept the next conversion's
+    // host phases - and, on another context, its kernels - from overlapping it; a verdict still on its way is folded by
+    // the next call or by the sweep after next).
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamSynchronize(ctx->s_main));
-    fold_lu_verdict(*ctx, 1 - ctx->cur), fold_lu_verdict(*ctx, ctx->cur);   // older sweep first
+    for (int set : {1 - ctx->cur, ctx->cur})                                   // older sweep first
+      if (ctx->lu_pending[set] && ctx->set_used[set] && hipEventQuery(ctx->set_done[set]) == hipSuccess) fold_lu_verdict(*ctx, set);
   }
   o->lu_min_pivot = ctx->lu_min_pivot, o->lu_max_inverse = ctx->lu_max_inverse, o->lu_fallbacks = ctx->lu_fallbacks;
   const int64_t n_det_all = ctx->n_det;

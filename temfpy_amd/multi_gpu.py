@@ -74,20 +74,21 @@ def shard_sites(L, oc, world):
 def _shard_sites(L, oc, world):
     """Contiguous site ranges that minimise the time of the slowest rank under the cost model
 
-        t(lo, hi) = 1.81 + sum_{i in [lo, hi)} (0.0214 - 0.0201 x_i + 0.0202 x_i^3) * 1024 / L + 3.54 max_i x_i^2   [ms],   x_i = n_i / (L / 2),
+        t(lo, hi) = 1.40 + sum_{i in [lo, hi)} (0.0222 - 0.0074 x_i + 0.0110 x_i^3) * 1024 / L + 1.72 max_i x_i^2   [ms],   x_i = n_i / (L / 2),
 
-    n_i = size of the smaller block at site i.  Fitted (0.26 ms residual, round 3) to the HOST -> HOST time per conversion of 17
-    site ranges of the benchmark chain, conversions pipelined as bench.py does (tools/shard_host_cost.py): a per-site part (host
-    enumeration and site preparation, determinant stage ~ constant in the chi-saturated bulk, eigen / overlap stages ~ n^3)
-    and a per-rank latency that grows with the largest block of the range - the per-cut kernels of a shard with fewer than 256
-    cuts take as long as their slowest workgroup.  (The round-2 fit was to device times only and off by up to 2.2 ms: the end
-    ranks, with the most sites, were host bound.)"""
+    n_i = size of the smaller block at site i.  Fitted (rms 0.16, largest residual 0.43 ms; round 3) to the HOST -> HOST time per
+    conversion of 25 site ranges of the benchmark chain, conversions pipelined as ShardGroup / bench.py do - the download of
+    conversion k under conversion k + 1, consecutive conversions on two alternating contexts (tools/shard_host_cost.py): a
+    per-site part (host enumeration and site preparation, determinant stage ~ constant in the chi-saturated bulk, eigen / overlap
+    stages ~ n^3) and a per-rank latency that grows with the largest block of the range - the per-cut kernels of a shard with
+    fewer than 256 cuts take as long as their slowest workgroup, and two contexts hide about half of it.  (The round-2 fit was to
+    device times of one context and off by up to 2.2 ms: the end ranks, with the most sites, are host bound.)"""
     if world > L:
         raise ValueError(f"{world} ranks for {L} sites: every rank needs at least one site")
     i = np.arange(L)
     n = np.where(i < oc, i + 1, L - i)
     x = n / max(L / 2, 1)
-    c1 = np.concatenate(([0.0], np.cumsum((0.02142 - 0.02009 * x + 0.02017 * x ** 3) * (1024.0 / L))))
+    c1 = np.concatenate(([0.0], np.cumsum((0.02224 - 0.00739 * x + 0.01104 * x ** 3) * (1024.0 / L))))
     x2 = x ** 2
 
     def greedy(c1, x2):
@@ -98,13 +99,13 @@ def _shard_sites(L, oc, world):
             while b[-1] < L and len(b) <= world:
                 lo = b[-1]
                 hi, mx = lo + 1, x2[lo]
-                while hi < L and 1.81 + (c1[hi + 1] - c1[lo]) + 3.54 * max(mx, x2[hi]) <= T:
+                while hi < L and 1.40 + (c1[hi + 1] - c1[lo]) + 1.72 * max(mx, x2[hi]) <= T:
                     mx = max(mx, x2[hi])
                     hi += 1
                 b.append(hi)
             return b
 
-        lo_T, hi_T = 0.0, 1.81 + c1[L] + 3.54 * max(x2)
+        lo_T, hi_T = 0.0, 1.40 + c1[L] + 1.72 * max(x2)
         for _ in range(50):
             mid = 0.5 * (lo_T + hi_T)
             b = cut(mid)
@@ -121,7 +122,7 @@ def _shard_sites(L, oc, world):
 
     # The greedy fill leaves the remainder to the last range: filled from the left and from the right, boundary by boundary the
     # mean of the two (a chain with its centre in the middle gets mirror-symmetric ranges).
-    per_site = (0.02142 - 0.02009 * x + 0.02017 * x ** 3) * (1024.0 / L)
+    per_site = (0.02224 - 0.00739 * x + 0.01104 * x ** 3) * (1024.0 / L)
     left = greedy(c1, x2)
     right = greedy(np.concatenate(([0.0], np.cumsum(per_site[::-1]))), x2[::-1].copy())
     twice = [a + (L - b) for a, b in zip(left, right[::-1])]

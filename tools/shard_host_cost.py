@@ -1,5 +1,6 @@
 """Host -> host time of one rank's site range of the benchmark chain, conversions pipelined as bench.py does (the download of
-conversion k under conversion k + 1), with the engine's stage timers: what the slowest rank of a sharded run costs.
+conversion k under conversion k + 1, consecutive conversions on two alternating contexts like multi_gpu.ShardGroup; EXP_CONTEXTS=1:
+one), with the engine's stage timers: what the slowest rank of a sharded run costs.
 usage: python tools/shard_host_cost.py lo:hi [lo:hi ...]      (default: the ranges shard_sites gives for 8 ranks)"""
 import os, sys, time
 import numpy as np
@@ -15,12 +16,14 @@ L = 1024
 C, _ = slater.correlation_matrix(random_hopping(L, 0))
 tr = to_stopping_condition({"chi_max": 512})
 ranges = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or shard_sites(L, L // 2, 8)[:4]
-eng = Engine("cuda:0")
+engs = [Engine("cuda:0") for _ in range(int(os.environ.get("EXP_CONTEXTS", 2)))]
 ht = int(os.environ.get("EXP_THREADS", 16))
 K = 40
 for rng in ranges:
-    res = []
+    res, turn = [], [0]
     def step():
+        eng = engs[turn[0] % len(engs)]
+        turn[0] += 1
         res.append(eng.run(C, tr, L // 2, L, download="async", threads=ht, site_range=rng))
         if len(res) > 1:
             res.pop(0).wait()
@@ -34,5 +37,5 @@ for rng in ranges:
         res.pop(0).wait()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K
-    tm = {k: round(v * 1e3, 2) for k, v in eng.timings.items() if v * 1e3 >= 0.05}
+    tm = {k: round(v * 1e3, 2) for k, v in engs[0].timings.items() if v * 1e3 >= 0.05}
     print(f"range {rng} ({rng[1] - rng[0]} sites): {dt * 1e3:6.2f} ms host -> host per conversion; stages {tm}", flush=True)
