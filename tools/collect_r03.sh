@@ -31,4 +31,6 @@ cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/prof_c5 -o c5 -- python3 $R/tools/run_cfg5.py --reps 3 > $O/prof_c5.log 2>&1 || exit 1
 cd $R
 python tools/rocpd_stats.py $O/prof_c5/c5_results.db $O/cfg5_gutzwiller_kernel_stats.csv > /dev/null
+python tools/shard_host_cost.py > $O/shard_host_cost_8ranks.log 2>&1
+python tools/shard_host_cost.py 0:292 292:512 0:512 >> $O/shard_host_cost_8ranks.log 2>&1
 echo collected
