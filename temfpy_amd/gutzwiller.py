@@ -1183,10 +1183,16 @@ class _Projector:
         b_hi = max(Bho[j][c] + v[1] * self.sect[j][c] for j in range(Ls) for c, v in Winfo[j].items())
         # (into page-locked memory: the pageable copy of .cpu() moved the 0.3 GB of config 5 at 15 GB/s; the blocks of the result are
         # views of this buffer and keep it alive, torch's host allocator hands a freed one out again)
-        t_b = torch.empty(b_hi - b_lo, dtype=d_ar.dtype, pin_memory=True)
-        t_b.copy_(d_ar[b_lo: b_hi], non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
-        h_b = t_b.numpy()
+        try:
+            t_b = torch.empty(b_hi - b_lo, dtype=d_ar.dtype, pin_memory=True)
+        except RuntimeError:          # (no page-locked memory of that size to be had: the pageable copy)
+            t_b = None
+        if t_b is not None:
+            t_b.copy_(d_ar[b_lo: b_hi], non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+            h_b = t_b.numpy()
+        else:
+            h_b = d_ar[b_lo: b_hi].cpu().numpy()
         cnt = [{c: int(h_cnt[cnt_index[(j, c)]]) for c in self.sect[j]} for j in range(Ls + 1)]
         lam, ch, offs = [], [], []
         for j in range(Ls + 1):
