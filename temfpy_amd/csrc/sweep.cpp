@@ -33,6 +33,7 @@
 #include <functional>
 #include <memory>
 #include <numeric>
+#include <string>
 #include <vector>
 
 #include "common.hpp"
@@ -518,6 +519,39 @@ struct Sweep {
   // span(Q)): tests/soak/soak_small.py seed 30023, 80 instead of 81 orbitals at one cut, weak eigenvalues
   // off by 1 - 5 %.
   int house_general(const std::vector<Slab>& s_in) {
+    // Slabs whose rows fit the panel kernel (1024 complex / 2048 real, LDS of 8 reflectors): factored there with the Q's
+    // left for tmf_house_form_q_batched, which forms them in place (no scratch of the size of the slabs) - about a third of
+    // the time of the global-memory kernel below at n x 256 (76 ms per launch for the 2 046 cuts of a range-12 chain).
+    {
+      i64 mm = 0, mn = 0, tau_tot = 0;
+      for (const Slab& x : s_in)
+        if (x.rows > 0 && x.c1 > 0) mm = std::max(mm, x.rows), mn = std::max(mn, x.c1), tau_tot += (x.c1 + 1) & ~(i64)1;
+      if (mm == 0) return TMF_OK;
+      const i64 row_cap = c.cplx ? 1024 : 2048;
+      const size_t lds = ((size_t)mm * 8 + (size_t)mn + 4) * (size_t)c.el + 64;
+      static const bool allow = !(getenv("TMF_WIDE_QR") && std::string(getenv("TMF_WIDE_QR")) == "global");
+      if (allow && mm <= row_cap && lds <= 150 * 1024) {
+        u64 d_tau;
+        TMF_TRY(alloc_el(tau_tot + 2, &d_tau));
+        std::vector<tmf_slab_desc> d;
+        i64 o = 0;
+        for (const Slab& x : s_in) {
+          if (!(x.rows > 0 && x.c1 > 0)) continue;
+          tmf_slab_desc q{};
+          q.A = x.base, q.Q = d_tau + (u64)(o * c.el), q.R = 0;
+          q.n = (int32_t)x.rows, q.c = (int32_t)x.c1, q.lda = (int32_t)x.ld, q.ldq = 1, q.ldr = 1, q.flags = 8;
+          d.push_back(q);
+          o += (x.c1 + 1) & ~(i64)1;
+        }
+        std::stable_sort(d.begin(), d.end(), [](const tmf_slab_desc& a, const tmf_slab_desc& b) { return (i64)a.n * a.c > (i64)b.n * b.c; });
+        u64 t_d;
+        TMF_TRY(up_vec(d, &t_d));
+        const int nd_ = (int)d.size(), mm_ = (int)mm, mn_ = (int)mn;
+        LATER(tmf_house_slab_batched(c.dtype, (const tmf_slab_desc*)t_d, nd_, mm_, mn_, c.s_main));
+        LATER(tmf_house_form_q_batched(c.dtype, (const tmf_slab_desc*)t_d, nd_, mm_, mn_, c.s_main));
+        return TMF_OK;
+      }
+    }
     std::vector<tmf_qr_desc> d;
     i64 maxm = 0, maxn = 0;
     for (const Slab& x : s_in) {

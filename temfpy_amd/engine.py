@@ -292,6 +292,20 @@ class Engine:
         keep = np.nonzero((rows > 0) & (cols > 0))[0]
         if keep.size == 0:
             return
+        mm, mn = int(rows[keep].max()), int(cols[keep].max())
+        if (os.environ.get("TMF_WIDE_QR") != "global" and mm <= (1024 if self.elem == 16 else 2048)
+                and (mm * 8 + mn + 4) * self.elem + 64 <= 150 * 1024):
+            # rows that fit the panel kernel: factored there, the Q's formed in place afterwards (csrc/sweep.cpp house_general)
+            tau_sz = (cols[keep] + 1) & ~1
+            d_tau = self._alloc(int(tau_sz.sum()) + 2)
+            sd = np.zeros(keep.size, nat.slab_desc)
+            sd["A"], sd["R"], sd["n"], sd["c"], sd["lda"], sd["ldq"], sd["ldr"], sd["flags"] = base[keep], 0, rows[keep], cols[keep], ld[keep], 1, 1, 8
+            sd["Q"] = d_tau.data_ptr() + self.elem * (np.cumsum(tau_sz) - tau_sz)
+            sd = sd[np.argsort(-(sd["n"].astype(np.int64) * sd["c"]), kind="stable")]
+            t_d = self._up(sd)
+            nat.check(self.lib.tmf_house_slab_batched(self.dtype, t_d.data_ptr(), keep.size, mm, mn, self.stream), "tmf_house_slab_batched")
+            nat.check(self.lib.tmf_house_form_q_batched(self.dtype, t_d.data_ptr(), keep.size, mm, mn, self.stream), "tmf_house_form_q_batched")
+            return
         keep = keep[np.argsort(-(rows[keep] * cols[keep]), kind="stable")]
         d = np.zeros(keep.size, nat.qr_desc)
         d["A"], d["R"], d["m"], d["n"], d["lda"], d["ldr"], d["flags"] = base[keep], 0, rows[keep], cols[keep], ld[keep], 1, 0
