@@ -61,12 +61,18 @@ def assert_nambu(C, basis=None, offset=None, name="", rtol=0, atol=1e-10):
     assert n % 2 == 0, f"Got {name} with odd side length (cannot be Nambu)"
     n //= 2
     tol = dict(atol=atol, rtol=rtol)
-    assert_allclose(C, HT(C), **tol, err_msg=f"{name} is not Hermitian")
-    C = (C + HT(C)) / 2
+    Ct = np.array(C.T, order="C", copy=True)   # HT(C), once and row-major (a COPY also when C.T is row-major already)
+    Ct = np.conjugate(Ct, out=Ct) if np.iscomplexobj(Ct) else Ct
+    assert_allclose(C, Ct, **tol, err_msg=f"{name} is not Hermitian")
+    C = C + Ct
+    C *= 0.5
     if basis == "M":
         real = np.eye(2 * n) * offset / 2
         assert_allclose(C.real, real, **tol, err_msg="Unexpected real parts in Majorana basis")
-        C = real + 1j * C.imag
+        if np.iscomplexobj(C):
+            C.real[...] = real        # (in place: C is this function's own array)
+        else:
+            C = real + 1j * C.imag
     elif basis == "C":
         err = f"{name.capitalize()} is not Nambu symmetric"
         assert_allclose(C[::2, ::2], offset * np.eye(n) - C[1::2, 1::2].conj(), **tol, err_msg=err)

@@ -26,13 +26,37 @@ def _report(fn, err_msg, *args, **kw):
                          "must be one of 'raise', 'warn', 'pass'.")
 
 
+def _all_close(a, d, rtol, atol):
+    """np.all(|a - d| <= atol + rtol |d|) for arrays of one shape, evaluated in blocks of rows that stay in the cache (the
+    one-piece expression moves five 16 MB temporaries through memory for a 1024 x 1024 complex matrix: 6 ms per check, two
+    checks and a Hermitisation per Pfaffian conversion).  For rtol = 0 the modulus of a complex difference is only formed where
+    max(|re|, |im|) does not decide the comparison already."""
+    if a.ndim != 2 or a.size < (1 << 16):
+        return bool(np.all(np.abs(a - d) <= atol + rtol * np.abs(d)))
+    step = max(1, (1 << 16) // a.shape[1])
+    for i in range(0, a.shape[0], step):
+        x = a[i: i + step] - d[i: i + step]
+        if rtol == 0:
+            if np.iscomplexobj(x):
+                m = max(np.abs(x.real).max(), np.abs(x.imag).max())
+                if m <= atol * 0.7071067811865475:
+                    continue
+                if m > atol:
+                    return False
+            if not np.all(np.abs(x) <= atol):
+                return False
+        elif not np.all(np.abs(x) <= atol + rtol * np.abs(d[i: i + step])):
+            return False
+    return True
+
+
 def assert_allclose(actual, desired, rtol=1e-7, atol=0.0, equal_nan=True, err_msg="", verbose=False):
     if TEST_ACTION == "pass":
         return
     try:  # fast path: numpy.testing spends ~30 ms per 1024 x 1024 complex comparison building its report
         with np.errstate(invalid="ignore"):
             a, d = np.asarray(actual), np.asarray(desired)
-            if a.shape == d.shape and np.all(np.abs(a - d) <= atol + rtol * np.abs(d)):
+            if a.shape == d.shape and _all_close(a, d, rtol, atol):
                 return
     except (TypeError, ValueError):
         pass

@@ -507,3 +507,34 @@ def test_gutzwiller_table_helpers_vectorised_forms():
     L.add(a), L.add(b)
     tab = L.table()
     assert tab.dtype == nat.qr_desc and tab["m"].tolist() == [1, 2, 0, 0, 0] and tab["n"].tolist() == [0, 0, 3, 4, 5]
+
+
+def test_assert_nambu_leaves_its_input_alone_and_blocked_comparison():
+    """pfaffian.assert_nambu (pfaffian.py:189-286) forms HT(C) once as a row-major COPY (for a column-major input C.T is row-major
+    already, and a conjugation in place would have hit the caller's matrix), Hermitises, and fixes the real parts in place on
+    its own array; testing._all_close = np.all(|a - d| <= atol + rtol |d|) in blocks of rows, also where only the modulus of
+    a complex difference decides."""
+    from temfpy_amd import pfaffian, testing as T
+
+    rng = np.random.default_rng(3)
+    n = 40
+    A = rng.standard_normal((2 * n, 2 * n))
+    H = 1j * (A - A.T)                                   # Majorana-basis Hamiltonian
+    for order in ("C", "F"):
+        X = np.array(H, order=order)
+        keep = X.copy()
+        out = pfaffian.assert_nambu(X, "M", offset=0, name="Hamiltonian")
+        assert np.array_equal(X, keep) and np.array_equal(out, (H + H.conj().T) / 2)
+        Xr = np.array(A + A.T, order=order)
+        keep = Xr.copy()
+        out = pfaffian.assert_nambu(Xr, None, offset=0, name="matrix")
+        assert np.array_equal(Xr, keep) and out.dtype == np.float64 and np.array_equal(out, A + A.T)
+    a = rng.standard_normal((1024, 300)) + 1j * rng.standard_normal((1024, 300))
+    for d, rt, at in ((a + 1e-12, 0, 1e-10), (a + 1e-12, 0, 1e-13), (a + 1e-12, 1e-9, 0), (a + 1e-12, 0, 1.2e-12)):
+        assert T._all_close(a, d, rt, at) == bool(np.all(np.abs(a - d) <= at + rt * np.abs(d)))
+    d = a.copy()
+    d[700, 3] += 1e-10 * (0.8 + 0.8j)                    # |difference| = 1.13e-10, real and imaginary part 0.8e-10 each
+    assert not T._all_close(a, d, 0, 1e-10)
+    d = a.copy()
+    d[5, 5] = np.nan
+    assert not T._all_close(a, d, 0, 1e-10)

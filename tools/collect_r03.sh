@@ -23,8 +23,8 @@ python bench.py > $O/bench_r03.json 2> $O/bench_r03.err || exit 1
 TMF_BENCH_SAME_DEVICE=1 python bench.py --gpus 2 --steps 5 --warmup 2 --cpu-sample 0 > $O/bench_r03_2ranks_one_gpu.json 2> $O/bench_2.err || exit 1
 echo bench done
 python tools/pmc_sq.py $O/pmc_sq/sq_counter_collection.csv $O/pmc_mfma_lds.json > /dev/null 2>&1
-python tools/run_cfg4.py --reps 3 > $O/cfg4_kitaev_L512_chi256.log 2>&1
-python tools/run_cfg4.py --random --reps 3 > $O/cfg4_random_bdg_L512_chi256.log 2>&1
+python tools/run_cfg4.py --reps 6 > $O/cfg4_kitaev_L512_chi256.log 2>&1
+python tools/run_cfg4.py --random --reps 6 > $O/cfg4_random_bdg_L512_chi256.log 2>&1
 python tools/run_cfg5.py --reps 3 --json $O/cfg5_gutzwiller_parallel.json > $O/cfg5_gutzwiller_parallel.log 2>&1
 python tools/run_cfg5.py --reps 3 --method sequential > $O/cfg5_gutzwiller_sequential.log 2>&1
 cd /tmp
