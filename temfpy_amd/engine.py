@@ -36,7 +36,6 @@ from __future__ import annotations
 import logging
 import os
 import time
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
